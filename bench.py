@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play hot path on MI355X: BASELINE.json configs[1]
+(4096 concurrent 8x8 self-play games per GPU, 100 MCTS sims/move, random-init OthelloNN, batched leaf eval).
+
+One *step* = one move round: every one of the 4096 resident games runs 100 lock-step simulations (select ->
+leaf compaction -> one batched OthelloNN evaluation -> expand/backup, x100), then chooses, records and plays
+one move; a finished game is replaced by a fresh one in the same slot (continuous self-play), so all slots
+stay busy for the whole timed region and completed games are counted exactly.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Prints ONE JSON line on rank 0: value = node expansions per second over all GPUs (the BASELINE metric; the
+same line carries games/s and sims/s), `roofline` for the dominant kernel (conv2 implicit GEMM on the fp32
+matrix cores, HIP events on its launch stream) and `cpu_baseline` (the CPU oracle -- the reference algorithm
+with batch-1 leaf evaluation -- timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_EXPANSION = {8: 566428672, 6: 270185472}          # SURVEY.md 8(d), whole OthelloNN forward
+PEAK_F32_MATRIX_TFLOPS = 157.3                             # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def conv2_flop_per_leaf(n, C):
+    return 2 * (n * n) * (9 * C) * C                       # 8x8: 301 989 888 FLOP
+
+
+def cpu_baseline(n, channels, sims, budget_s=15.0):
+    """The oracle port of the reference path (sequential simulations, one game, batch-1 leaf evaluation by the
+    float32 C restatement of OthelloNN on all host cores), timed on a bounded sample: the first plies of one game."""
+    import oracle
+    from othellozero_amd.weights import init_weights
+    w = init_weights(n, seed=0, channels=channels)
+    threads = oracle.lib().orc_nn_max_threads()
+    net = oracle.CNet(w, n, channels=channels, nthreads=threads)
+
+    def run(max_moves):
+        m = oracle.Mcts(n, 1.0, oracle.QMODE_F64, evaluator=net.evaluator())
+        t0 = time.perf_counter()
+        ep = m.episode(sims, 1.0, 0.9, 1234, 0, max_moves=max_moves)
+        return time.perf_counter() - t0, ep
+    t1, ep1 = run(1)
+    moves = max(1, min(n * n - 4, int(budget_s / max(t1, 1e-3))))
+    if moves > 1:
+        t1, ep1 = run(moves)
+    exp = ep1["stats"]["expansions"]
+    return {
+        "value": exp / t1, "unit": "node-expansions/s", "cores": threads, "kind": "port",
+        "sample": f"first {ep1['n_moves']} plies of one {n}x{n} game at {sims} sims/move "
+                  f"({exp} expansions, {ep1['n_moves'] * sims} sims, {t1:.1f} s), batch-1 leaf eval, OpenMP x{threads}",
+        "sims_per_s": ep1["n_moves"] * sims / t1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=100)
+    ap.add_argument("--board", type=int, default=8)
+    ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import torch
+    import torch.distributed as dist
+    from othellozero_amd import _lib
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.distributed import engine_records_tensor, gather_records
+    from othellozero_amd.training import SelfPlayEngine
+
+    _lib.require_gpu()
+    _lib.check(_lib.load().oz_set_device(local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n, G = args.board, args.games
+    net = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0)   # same weights on every rank
+    eng = SelfPlayEngine(net, n, G, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * G,
+                         game_id_stride=world * G, q_mode=_lib.QMODE_F64, refill=True,
+                         record_cap=G * (args.steps + args.warmup + 2))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.run(args.warmup)
+    eng.sync()
+    net.profile(True)
+    s0 = eng.stats()
+    ev0 = eng.eval_time()
+    barrier()
+    t0 = time.perf_counter()
+    eng.run(args.steps, sync=False)
+    eng.sync()
+    pooled = gather_records(engine_records_tensor(eng, dev))       # the path's only exchange step
+    barrier()
+    dt = time.perf_counter() - t0
+    s1 = eng.stats()
+    ev1 = eng.eval_time()
+    conv2_ms, conv2_launches = net.profile_read()
+
+    d = {k: s1[k] - s0[k] for k in ("simulations", "expansions", "terminal_hits", "node_visits", "moves", "games_completed")}
+    vec = torch.tensor([d["expansions"], d["simulations"], d["games_completed"], d["moves"], d["node_visits"]],
+                       dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    exp_all, sims_all, games_all, moves_all, visits_all = (float(x) for x in vec.tolist())
+
+    if rank == 0:
+        flop_conv2 = d["expansions"] * conv2_flop_per_leaf(n, args.channels)
+        achieved = flop_conv2 / (conv2_ms * 1e-3) / 1e12 if conv2_ms > 0 else 0.0
+        nn_ms = ev1["ms"] - ev0["ms"]
+        out = {
+            "metric": "mcts_node_expansions_per_sec", "value": exp_all / dt, "unit": "node-expansions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{G} concurrent {n}x{n} self-play games per GPU, {args.sims} sims/move, batched leaf eval "
+                            "(BASELINE configs[1]); step = one move round (100 lock-step simulations + one move per game), "
+                            "finished games refilled",
+                "games_per_gpu": G, "sims_per_move": args.sims, "board": n, "net": f"OthelloNN {args.channels} filters, random init seed 0",
+                "q_mode": "float64 (NumPy 1.18.5 promotion)", "parallelism": f"games sharded x{world}, all-gather of move records",
+            },
+            "games_per_s": games_all / dt, "sims_per_s": sims_all / dt, "moves_per_s": moves_all / dt,
+            "games_completed": int(games_all), "expansions": int(exp_all), "simulations": int(sims_all),
+            "expansions_per_sim": exp_all / max(sims_all, 1), "node_visits_per_sim": visits_all / max(sims_all, 1),
+            "pooled_records": int(pooled.shape[0]),
+            "nn_forward_ms_total_rank0": nn_ms, "nn_fraction_of_wall_rank0": nn_ms * 1e-3 / dt,
+            "whole_net_tflops_rank0": d["expansions"] * FLOP_PER_EXPANSION.get(n, 0) / max(nn_ms * 1e-3, 1e-9) / 1e12,
+            "roofline": {
+                "kernel": "k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                "launches": int(conv2_launches), "avg_launch_ms": conv2_ms / max(conv2_launches, 1),
+                "flop_per_leaf": conv2_flop_per_leaf(n, args.channels),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, args.channels, args.sims)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,201 @@
+/*
+ * othellozero_amd.h -- C ABI of libothellozero_amd.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the self-play hot path of Galtvam/OthelloZero.  The
+ * reference has no FFI layer (its boundary is Python duck typing), so each entry
+ * point below cites the reference interface it replaces (file:line under the
+ * reference tree); othellozero_amd/*.py binds them with ctypes and re-creates
+ * the reference's Python surfaces on top.
+ *
+ * Conventions: plain pointers and sizes, caller-owned output buffers, int status
+ * return (0 = OZ_OK) + oz_last_error() (thread-local string); no exceptions
+ * cross the ABI.  Unless a parameter says "device pointer" every pointer is a
+ * host pointer.  Boards: two uint64 bitboards, bit = row*8 + col for every board
+ * size n in {4,6,8} (n x n corner of an 8x8 grid).  own/opp = channel 0/1 of a
+ * mover-canonical state; black/white = absolute colours.  Squares are reported
+ * as sq = row*8 + col; NN policy vectors are indexed row*n + col.
+ * All objects are internally serialised (a mutex per object): concurrent calls
+ * from ThreadWorker-style Python threads (workers.py:33-37,82-90) are safe.
+ */
+#ifndef OTHELLOZERO_AMD_H
+#define OTHELLOZERO_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OZ_OK 0
+#define OZ_ERR_HIP 1       /* a HIP runtime call failed                         */
+#define OZ_ERR_ARG 2       /* bad argument                                      */
+#define OZ_ERR_CAPACITY 3  /* a per-game node/edge table overflowed             */
+#define OZ_ERR_KEY 4       /* the reference would raise KeyError here           */
+#define OZ_ERR_STATE 5     /* call sequence error                               */
+
+/* Q accumulation regime (SURVEY.md R-FP): what `N*Q + value` promotes to */
+#define OZ_QMODE_NEP50 0   /* NumPy >= 2: float32 once a float32 value arrives  */
+#define OZ_QMODE_F64 1     /* NumPy 1.18.5 (requirements.txt:19): float64       */
+
+/* per-game status after a select pass */
+#define OZ_LEAF_IDLE 0       /* game slot not searching                          */
+#define OZ_LEAF_TERMINAL 1   /* simulation ended on a finished board (MCTS/__init__.py:39-40) */
+#define OZ_LEAF_EVAL 2       /* first visit: needs NN evaluation (MCTS/__init__.py:44-57)     */
+
+const char* oz_last_error(void);
+int oz_version(void);
+int oz_device_count(void);
+int oz_set_device(int device);       /* device used by objects created afterwards on this thread */
+
+/* ------------------------------------------------------------------ rules
+ * Batched Othello/__init__.py static board functions, one HIP thread per position. */
+/* get_player_valid_actions (:208-214): legal[i] = bit mask of legal squares for the side holding own[i] */
+int oz_rules_legal_moves(const uint64_t* own, const uint64_t* opp, int n, int count, uint64_t* legal);
+/* flip_board_squares (:237-247) as the side holding own[i] on sq[i] (no legality check) */
+int oz_rules_apply_moves(const uint64_t* own, const uint64_t* opp, const uint8_t* sq, int n, int count,
+                         uint64_t* own_out, uint64_t* opp_out);
+/* has_board_finished (:249-252), get_board_players_points / get_board_winning_player (:254-260; draw -> ch0) */
+int oz_rules_status(const uint64_t* ch0, const uint64_t* ch1, int n, int count, uint8_t* finished,
+                    int32_t* pts0, int32_t* pts1, int8_t* winner /* +1 ch0, -1 ch1 */);
+/* OthelloGame.play (:136-159): flip, switch player, pass / finish logic. player: +1 BLACK, -1 WHITE */
+int oz_rules_play(const uint64_t* black, const uint64_t* white, const int8_t* player, const uint8_t* sq, int n,
+                  int count, uint64_t* black_out, uint64_t* white_out, int8_t* player_out, uint8_t* finished_out);
+
+/* ------------------------------------------------------------------ network
+ * NNetWrapper (Net/NNet.py:22-101) inference side; OthelloNN graph (Net/OthelloNN.py:42-56). */
+typedef struct oz_net oz_net;
+/* ONN with `channels` conv filters (reference: 512), for boards n x n, batches up to max_batch */
+int oz_net_create(oz_net** out, int n, int channels, int max_batch);
+/* deterministic integer-hash stand-in for predict() (test nets; formula in oracle/oz_oracle.c orc_stub_predict) */
+int oz_net_create_stub(oz_net** out, int n, uint64_t salt, uint64_t keep_mask, int max_batch);
+int oz_net_destroy(oz_net* net);
+/* weights in keras Model.get_weights() order: 40 arrays for ONN (model.set_weights / get_weights, Net/NNet.py:98-101) */
+int oz_net_num_weights(const oz_net* net);
+int oz_net_weight_size(const oz_net* net, int index, int64_t* nelem);
+int oz_net_set_weight(oz_net* net, int index, const float* data, int64_t nelem);
+int oz_net_get_weight(const oz_net* net, int index, float* data, int64_t nelem);
+/* fold BN (epsilon 1e-3, moving statistics) + re-layout for the kernels; call after the last set_weight */
+int oz_net_commit(oz_net* net);
+/* NNetWrapper.predict (Net/NNet.py:70-87) for `count` canonical boards: pi[count][n*n] float32, v[count] float32 */
+int oz_net_predict(oz_net* net, const uint64_t* own, const uint64_t* opp, int count, float* pi, float* v);
+/* timing hook for bench.py: run the forward `iters` times on `count` resident boards, return avg ms per forward (HIP events) */
+int oz_net_time_forward(oz_net* net, int count, int iters, float* ms_avg);
+/* HIP-event timing of the dominant launch (conv2 implicit GEMM) on the stream it is launched on */
+int oz_net_profile(oz_net* net, int enable);
+int oz_net_profile_read(oz_net* net, double* conv2_ms_total, int64_t* conv2_launches);
+
+/* ------------------------------------------------------------------ search
+ * OthelloMCTS / MCTS (othelo_mcts.py:9-88, MCTS/__init__.py:19-187): num_games independent
+ * instances, one wavefront per instance, tables resident in HBM. */
+typedef struct oz_mcts oz_mcts;
+int oz_mcts_create(oz_mcts** out, int n, int num_games, int node_cap, int edge_cap, double c, int q_mode);
+int oz_mcts_destroy(oz_mcts* m);
+int oz_mcts_reset(oz_mcts* m, int game /* -1 = all */);                 /* fresh OthelloMCTS() */
+/* roots of the next simulations: canonical boards (othelo_mcts.py:22-26); active[i]=0 leaves slot i idle */
+int oz_mcts_set_roots(oz_mcts* m, const uint64_t* own, const uint64_t* opp, const uint8_t* active);
+/* OthelloMCTS.simulate x nsims for every active slot, leaves evaluated in one batch per step by `net` */
+int oz_mcts_simulate(oz_mcts* m, oz_net* net, int nsims);
+/* the same split for a host-side evaluator (any Python object with .predict):
+ *   select -> leaves -> [caller evaluates OZ_LEAF_EVAL slots] -> backup */
+int oz_mcts_select(oz_mcts* m);
+int oz_mcts_leaves(oz_mcts* m, int32_t* status, uint64_t* own, uint64_t* opp);
+int oz_mcts_backup(oz_mcts* m, const float* pi /* [num_games][n*n] */, const float* v /* [num_games] */);
+/* value returned by the last simulate() of each slot and its dynamic type (0 int, 1 float32, 2 float64) */
+int oz_mcts_last_value(oz_mcts* m, double* value, int32_t* vtype, int32_t* depth);
+/* N(state, action) of the current root for every square (MCTS/__init__.py:73-84): counts[g][64];
+ * rc[g]: 0 ok, 1 root unknown (all zero), 2 KeyError (root never selected from) */
+int oz_mcts_root_counts(oz_mcts* m, int32_t* counts, uint64_t* legal, int32_t* rc);
+/* table inspection (parity tests): nodes of slot `game` in expansion order */
+int oz_mcts_num_nodes(oz_mcts* m, int32_t* num_nodes /* [num_games] */);
+int oz_mcts_dump_node(oz_mcts* m, int game, int index, uint64_t* own, uint64_t* opp, int32_t* Ns, uint64_t* legal,
+                      int32_t* N /*64*/, double* Q /*64*/, uint8_t* qtag /*64: 1 = float32-typed*/, double* P /*64*/);
+/* counters since creation: [0] simulations [1] node visits [2] expansions [3] terminal hits [4] uniform-prior fallbacks */
+int oz_mcts_stats(oz_mcts* m, int64_t* out5);
+
+/* ------------------------------------------------------------------ self-play
+ * execute_episode (training.py:26-72) for num_games concurrent games in lock step. */
+typedef struct oz_selfplay oz_selfplay;
+typedef struct {
+    int32_t n;              /* board size 4/6/8 */
+    int32_t num_games;      /* concurrent game slots */
+    int32_t sims;           /* num_simulations per move (>= 2) */
+    int32_t q_mode;         /* OZ_QMODE_* */
+    double c;               /* degree_exploration */
+    double temperature;     /* policy_temperature: 0 -> max-visit with stream tie-break, else first max of N */
+    double e_greedy;        /* coin <= e_greedy -> greedy */
+    uint64_t seed;          /* RNG streams keyed (seed, global game id, ply) */
+    uint64_t first_game_id; /* global id of slot 0 (multi-GPU sharding: rank*num_games) */
+    uint64_t game_id_stride;/* id step when a slot is refilled (world_size*num_games) */
+    int32_t refill;         /* 1: a finished slot immediately starts a new game */
+    int32_t node_cap;       /* per-game node table capacity (0 = sims*61+64) */
+    int32_t edge_cap;       /* per-game edge pool capacity (0 = node_cap*14) */
+    int32_t record_cap;     /* move records kept for export (0 = num_games*64*4) */
+} oz_selfplay_config;
+
+/* one move of one game; 8-fold symmetry expansion (training.py:13-23) happens in oz_examples_expand */
+typedef struct {
+    uint64_t black, white;  /* absolute board BEFORE the move (per-move snapshot) */
+    uint64_t final_black, final_white; /* board at the end of that game (the reference's aliased view, T2) */
+    uint64_t game_id;
+    uint8_t ply;
+    uint8_t action;         /* sq = row*8+col */
+    int8_t player;          /* mover: +1 BLACK, -1 WHITE */
+    int8_t z;               /* +1 if winner == mover else -1 (draw -> BLACK wins) */
+    uint8_t greedy;         /* 1 = greedy branch of the coin */
+    uint8_t pad[3];
+} oz_record;
+
+typedef struct {
+    int64_t simulations, node_visits, expansions, terminal_hits, fallbacks;
+    int64_t moves, games_completed, records;
+    int32_t live_games, overflow;
+} oz_selfplay_stats;
+
+int oz_selfplay_create(oz_selfplay** out, const oz_selfplay_config* cfg, oz_net* net);
+int oz_selfplay_destroy(oz_selfplay* sp);
+/* `rounds` move rounds: every live game runs cfg.sims simulations, chooses, records and plays one move.
+ * Asynchronous (stream ordered); oz_selfplay_sync waits. */
+int oz_selfplay_run(oz_selfplay* sp, int rounds);
+int oz_selfplay_sync(oz_selfplay* sp);
+int oz_selfplay_get_stats(oz_selfplay* sp, oz_selfplay_stats* out);
+/* per-slot view: boards, player to move, finished flag, plies played, global game id */
+int oz_selfplay_state(oz_selfplay* sp, uint64_t* black, uint64_t* white, int8_t* player, uint8_t* finished,
+                      int32_t* ply, uint64_t* game_id);
+/* records of COMPLETED games, in completion order; returns how many were written */
+int oz_selfplay_records(oz_selfplay* sp, oz_record* out, int64_t max_records, int64_t* written);
+/* same, device to device, for the RCCL all-gather (dst = device pointer, e.g. a torch tensor) */
+int oz_selfplay_records_device(oz_selfplay* sp, void* dst_device, int64_t max_records, int64_t* written);
+/* root visit counts of the last move round, counts[num_games][64] (parity tests) */
+int oz_selfplay_last_counts(oz_selfplay* sp, int32_t* counts);
+/* HIP-event time of the evaluator (NN) launches since creation, and their count */
+int oz_selfplay_eval_time(oz_selfplay* sp, double* ms_total, int64_t* launches, int64_t* leaves);
+
+/* ------------------------------------------------------------------ arena
+ * duel_between_agents with two NeuralNetworkOthelloAgent (agents.py:44-84): net_a = BLACK, net_b = WHITE,
+ * one OthelloMCTS per agent per game, temperature 0, ties broken by the RNG_TIE stream. */
+typedef struct oz_arena oz_arena;
+int oz_arena_create(oz_arena** out, int n, int num_games, int sims, double c, int q_mode, uint64_t seed,
+                    uint64_t first_game_id, oz_net* net_a, oz_net* net_b, int node_cap, int edge_cap);
+int oz_arena_destroy(oz_arena* a);
+int oz_arena_run(oz_arena* a);       /* plays all games to the end (synchronous) */
+int oz_arena_results(oz_arena* a, int8_t* winner /* +1 net_a */, int32_t* points, int32_t* n_moves,
+                     uint8_t* actions /* [num_games][128] */, int8_t* players /* [num_games][128] */,
+                     uint64_t* final_black, uint64_t* final_white);
+
+/* ------------------------------------------------------------------ examples
+ * training_example_symmetries (training.py:13-23) + the returned tuple layout of execute_episode (:58-72):
+ * for each record 8 examples in the reference's order; boards[count*8][n][n][2] uint8 {0,1},
+ * policy_index[count*8] (one-hot position row*n+col), z[count*8].
+ * alias_final != 0 reproduces the reference's aliasing quirk (boards show the final position). */
+int oz_examples_expand(const oz_record* records, int64_t count, int n, int alias_final, uint8_t* boards,
+                       int32_t* policy_index, int8_t* z);
+int oz_symmetry_table(int n, int32_t* perm /* [8][n*n] source index of every output cell */);
+
+/* ------------------------------------------------------------------ diagnostics
+ * device arithmetic behind the PUCT / backup formulas (MCTS/__init__.py:68,168-170), for bit-exact
+ * comparison with the host: sqrt(a), a/b in float64; a/b and (a*b+a)/b in float32 (no FMA contraction). */
+int oz_selftest_arith(const double* a, const double* b, int count, double* sqrt_a, double* div_ab, float* fdiv_ab,
+                      float* fchain);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,147 @@
+"""NNetWrapper -- drop-in for Net/NNet.py:22-101 (inference side) on the HIP library.
+
+Same constructor arguments, `.network_type`, `.predict(board) -> (pi (n,n) float32, v float32)`,
+`.copy()`, `.save_checkpoint(path)`, `.load_checkpoint(path)`.  Added: `.predict_batch`,
+`.get_weights()/.set_weights()` (keras Model.get_weights() order), `StubNetWrapper`.
+Training (`.train`, Net/NNet.py:53-68) and Keras HDF5 files are out of this round's scope
+(SURVEY.md section 8(f)); they raise NotImplementedError instead of silently doing something else.
+"""
+import ctypes as C
+from enum import Enum, auto
+
+import numpy as np
+
+from . import _lib
+from .weights import init_weights, onn_shapes
+
+
+class NeuralNets(Enum):          # Net/NNet.py:14-16
+    ONN = auto()
+    BNN = auto()
+
+
+class _NetHandle:
+    def __init__(self):
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().oz_net_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+class NNetWrapper(_NetHandle):
+    def __init__(self, board_size=(8, 8), batch_size=32, epochs=10, num_channels_1=512, num_channels_2=256,
+                 lr=0.001, dropout=0.3, network=NeuralNets.ONN, max_batch=1, seed=0, weights=None):
+        super().__init__()
+        self.board_size_x, self.board_size_y = board_size
+        assert self.board_size_x == self.board_size_y, "square boards only"
+        self.action_size = self.board_size_x * self.board_size_y
+        self.batch_size, self.epochs, self.lr, self.dropout = batch_size, epochs, lr, dropout
+        self.network_type = network
+        self.num_channels = num_channels_1          # num_channels_2 is accepted but unused (OthelloNN.py:39)
+        self.max_batch = int(max_batch)
+        if network is not NeuralNets.ONN:
+            raise NotImplementedError("only NeuralNets.ONN is implemented (BNN: SURVEY.md section 8(f) item 4)")
+        lib = _lib.require_gpu()
+        _lib.check(lib.oz_net_create(C.byref(self._h), self.board_size_x, self.num_channels, self.max_batch))
+        self.set_weights(weights if weights is not None else init_weights(self.board_size_x, seed, self.num_channels))
+
+    # ---- weights (model.get_weights / set_weights, Net/NNet.py:98-101)
+    def set_weights(self, weights):
+        lib = _lib.load()
+        shapes = onn_shapes(self.board_size_x, self.num_channels)
+        assert len(weights) == len(shapes), f"expected {len(shapes)} arrays"
+        for i, (w, shp) in enumerate(zip(weights, shapes)):
+            a = np.ascontiguousarray(w, dtype=np.float32)
+            assert a.shape == tuple(shp), f"weight {i}: shape {a.shape} != {shp}"
+            _lib.check(lib.oz_net_set_weight(self._h, i, _lib.p_f32(a), a.size))
+        _lib.check(lib.oz_net_commit(self._h))
+
+    def get_weights(self):
+        lib = _lib.load()
+        out = []
+        for i, shp in enumerate(onn_shapes(self.board_size_x, self.num_channels)):
+            a = np.zeros(shp, dtype=np.float32)
+            _lib.check(lib.oz_net_get_weight(self._h, i, _lib.p_f32(a), a.size))
+            out.append(a)
+        return out
+
+    # ---- inference
+    def predict_batch(self, own, opp):
+        """canonical bitboards (uint64 arrays) -> pi (B, n, n) float32, v (B,) float32"""
+        own = np.ascontiguousarray(own, dtype=np.uint64).ravel()
+        opp = np.ascontiguousarray(opp, dtype=np.uint64).ravel()
+        B, n = own.size, self.board_size_x
+        pi = np.zeros((B, n, n), dtype=np.float32)
+        v = np.zeros(B, dtype=np.float32)
+        lib = _lib.load()
+        for s in range(0, B, self.max_batch):
+            e = min(B, s + self.max_batch)
+            _lib.check(lib.oz_net_predict(self._h, _lib.p_u64(own[s:e]), _lib.p_u64(opp[s:e]), e - s,
+                                          _lib.p_f32(pi[s:e]), _lib.p_f32(v[s:e])))
+        return pi, v
+
+    def predict(self, board):
+        """Net/NNet.py:70-87: board (n,n,2) -> (pi.reshape(n,n), v[0][0])"""
+        own, opp = _lib.pack_board(board)
+        pi, v = self.predict_batch(np.array([own], np.uint64), np.array([opp], np.uint64))
+        return pi[0], v[0]
+
+    def train(self, examples, verbose=None):
+        raise NotImplementedError("NNetWrapper.train (Net/NNet.py:53-68) is outside the self-play hot path "
+                                  "(SURVEY.md section 8(f) item 2)")
+
+    # ---- checkpoints: the reference writes Keras HDF5 (Net/NNet.py:90-96); h5py is not available here, so
+    # checkpoints are .npz files holding the same 40 arrays in get_weights() order.
+    def save_checkpoint(self, filepath):
+        if filepath.endswith(".h5"):
+            raise NotImplementedError("Keras HDF5 checkpoints need an HDF5 writer (SURVEY.md section 8(f) item 1); "
+                                      "use a .npz path")
+        np.savez(filepath, *self.get_weights())
+
+    def load_checkpoint(self, filepath):
+        if filepath.endswith(".h5"):
+            raise NotImplementedError("Keras HDF5 checkpoints need an HDF5 reader (SURVEY.md section 8(f) item 1); "
+                                      "use a .npz path")
+        with np.load(filepath if filepath.endswith(".npz") else filepath + ".npz") as z:
+            self.set_weights([z[f"arr_{i}"] for i in range(len(z.files))])
+
+    def copy(self):
+        return NNetWrapper((self.board_size_x, self.board_size_y), network=self.network_type,
+                           num_channels_1=self.num_channels, max_batch=self.max_batch, weights=self.get_weights())
+
+    # ---- profiling hooks used by bench.py
+    def time_forward(self, count, iters=3):
+        ms = C.c_float()
+        _lib.check(_lib.load().oz_net_time_forward(self._h, count, iters, C.byref(ms)))
+        return ms.value
+
+    def profile(self, enable=True):
+        _lib.check(_lib.load().oz_net_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        ms, cnt = C.c_double(), C.c_int64()
+        _lib.check(_lib.load().oz_net_profile_read(self._h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+
+class StubNetWrapper(_NetHandle):
+    """Device-side deterministic test network (integer hash of the board; formula: oracle/oz_oracle.c
+    orc_stub_predict).  Duck-types NNetWrapper for the search / self-play engines."""
+
+    def __init__(self, board_size=(8, 8), salt=0, keep_mask=0, max_batch=1):
+        super().__init__()
+        self.board_size_x, self.board_size_y = board_size
+        self.action_size = self.board_size_x * self.board_size_y
+        self.network_type = NeuralNets.ONN
+        self.max_batch = int(max_batch)
+        self.salt, self.keep_mask = salt, keep_mask
+        lib = _lib.require_gpu()
+        _lib.check(lib.oz_net_create_stub(C.byref(self._h), self.board_size_x, salt, keep_mask, self.max_batch))
+
+    predict_batch = NNetWrapper.predict_batch
+    predict = NNetWrapper.predict

@@ -1,0 +1,172 @@
+"""ctypes binding of libothellozero_amd.so (include/othellozero_amd.h).
+
+There is NO fallback: if the HIP library cannot be loaded, importing anything that
+computes raises `OzLibraryError`.  The library is built in-tree by
+`python -m othellozero_amd.build` (hipcc --offload-arch=gfx950).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libothellozero_amd.so")
+
+OZ_OK, OZ_ERR_HIP, OZ_ERR_ARG, OZ_ERR_CAPACITY, OZ_ERR_KEY, OZ_ERR_STATE = range(6)
+QMODE_NEP50, QMODE_F64 = 0, 1
+LEAF_IDLE, LEAF_TERMINAL, LEAF_EVAL = 0, 1, 2
+VT_INT, VT_F32, VT_F64 = 0, 1, 2
+
+
+class OzLibraryError(RuntimeError):
+    pass
+
+
+class OzError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[oz error {code}] {msg}")
+        self.code = code
+
+
+class SelfplayConfig(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("num_games", C.c_int32), ("sims", C.c_int32), ("q_mode", C.c_int32),
+        ("c", C.c_double), ("temperature", C.c_double), ("e_greedy", C.c_double),
+        ("seed", C.c_uint64), ("first_game_id", C.c_uint64), ("game_id_stride", C.c_uint64),
+        ("refill", C.c_int32), ("node_cap", C.c_int32), ("edge_cap", C.c_int32), ("record_cap", C.c_int32),
+    ]
+
+
+class SelfplayStats(C.Structure):
+    _fields_ = [
+        ("simulations", C.c_int64), ("node_visits", C.c_int64), ("expansions", C.c_int64),
+        ("terminal_hits", C.c_int64), ("fallbacks", C.c_int64),
+        ("moves", C.c_int64), ("games_completed", C.c_int64), ("records", C.c_int64),
+        ("live_games", C.c_int32), ("overflow", C.c_int32),
+    ]
+
+
+# numpy view of oz_record (48 bytes)
+RECORD_DTYPE = np.dtype([
+    ("black", "<u8"), ("white", "<u8"), ("final_black", "<u8"), ("final_white", "<u8"), ("game_id", "<u8"),
+    ("ply", "u1"), ("action", "u1"), ("player", "i1"), ("z", "i1"), ("greedy", "u1"), ("pad", "u1", (3,)),
+])
+assert RECORD_DTYPE.itemsize == 48
+
+_u64p, _i32p, _f32p, _f64p = (C.POINTER(t) for t in (C.c_uint64, C.c_int32, C.c_float, C.c_double))
+_u8p, _i8p, _i64p, _vp = C.POINTER(C.c_uint8), C.POINTER(C.c_int8), C.POINTER(C.c_int64), C.c_void_p
+
+# name -> argtypes: every symbol include/othellozero_amd.h declares (tests check the export list)
+SIGNATURES = {
+    "oz_version": [], "oz_device_count": [], "oz_set_device": [C.c_int],
+    "oz_rules_legal_moves": [_u64p, _u64p, C.c_int, C.c_int, _u64p],
+    "oz_rules_apply_moves": [_u64p, _u64p, _u8p, C.c_int, C.c_int, _u64p, _u64p],
+    "oz_rules_status": [_u64p, _u64p, C.c_int, C.c_int, _u8p, _i32p, _i32p, _i8p],
+    "oz_rules_play": [_u64p, _u64p, _i8p, _u8p, C.c_int, C.c_int, _u64p, _u64p, _i8p, _u8p],
+    "oz_net_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int],
+    "oz_net_create_stub": [C.POINTER(_vp), C.c_int, C.c_uint64, C.c_uint64, C.c_int],
+    "oz_net_destroy": [_vp], "oz_net_num_weights": [_vp],
+    "oz_net_weight_size": [_vp, C.c_int, _i64p],
+    "oz_net_set_weight": [_vp, C.c_int, _f32p, C.c_int64],
+    "oz_net_get_weight": [_vp, C.c_int, _f32p, C.c_int64],
+    "oz_net_commit": [_vp],
+    "oz_net_predict": [_vp, _u64p, _u64p, C.c_int, _f32p, _f32p],
+    "oz_net_time_forward": [_vp, C.c_int, C.c_int, _f32p],
+    "oz_net_profile": [_vp, C.c_int], "oz_net_profile_read": [_vp, _f64p, _i64p],
+    "oz_mcts_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int],
+    "oz_mcts_destroy": [_vp], "oz_mcts_reset": [_vp, C.c_int],
+    "oz_mcts_set_roots": [_vp, _u64p, _u64p, _u8p],
+    "oz_mcts_simulate": [_vp, _vp, C.c_int], "oz_mcts_select": [_vp],
+    "oz_mcts_leaves": [_vp, _i32p, _u64p, _u64p],
+    "oz_mcts_backup": [_vp, _f32p, _f32p],
+    "oz_mcts_last_value": [_vp, _f64p, _i32p, _i32p],
+    "oz_mcts_root_counts": [_vp, _i32p, _u64p, _i32p],
+    "oz_mcts_num_nodes": [_vp, _i32p],
+    "oz_mcts_dump_node": [_vp, C.c_int, C.c_int, _u64p, _u64p, _i32p, _u64p, _i32p, _f64p, _u8p, _f64p],
+    "oz_mcts_stats": [_vp, _i64p],
+    "oz_selfplay_create": [C.POINTER(_vp), C.POINTER(SelfplayConfig), _vp],
+    "oz_selfplay_destroy": [_vp], "oz_selfplay_run": [_vp, C.c_int], "oz_selfplay_sync": [_vp],
+    "oz_selfplay_get_stats": [_vp, C.POINTER(SelfplayStats)],
+    "oz_selfplay_state": [_vp, _u64p, _u64p, _i8p, _u8p, _i32p, _u64p],
+    "oz_selfplay_records": [_vp, _vp, C.c_int64, _i64p],
+    "oz_selfplay_records_device": [_vp, _vp, C.c_int64, _i64p],
+    "oz_selfplay_last_counts": [_vp, _i32p],
+    "oz_selfplay_eval_time": [_vp, _f64p, _i64p, _i64p],
+    "oz_arena_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_uint64, _vp, _vp, C.c_int, C.c_int],
+    "oz_arena_destroy": [_vp], "oz_arena_run": [_vp],
+    "oz_arena_results": [_vp, _i8p, _i32p, _i32p, _u8p, _i8p, _u64p, _u64p],
+    "oz_examples_expand": [_vp, C.c_int64, C.c_int, C.c_int, _u8p, _i32p, _i8p],
+    "oz_symmetry_table": [C.c_int, _i32p],
+    "oz_selftest_arith": [_f64p, _f64p, C.c_int, _f64p, _f64p, _f32p, _f32p],
+}
+
+_LIB = None
+
+
+def load(path=None):
+    """Load the HIP library (no compute).  Raises OzLibraryError if it is missing or unloadable."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OzLibraryError(
+            f"{p} not found: the HIP extension is required (no CPU fallback). Build it with "
+            "`python -m othellozero_amd.build` (hipcc --offload-arch=gfx950).")
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:
+        raise OzLibraryError(f"cannot load {p}: {e}") from e
+    lib.oz_last_error.restype = C.c_char_p
+    lib.oz_last_error.argtypes = []
+    for name, args in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise OzLibraryError(f"{p} does not export {name}") from e
+        fn.argtypes = args
+        fn.restype = C.c_int
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc != OZ_OK:
+        msg = load().oz_last_error().decode("utf-8", "replace")
+        if rc == OZ_ERR_KEY:
+            raise KeyError(msg)
+        raise OzError(rc, msg)
+
+
+def require_gpu():
+    lib = load()
+    if lib.oz_device_count() <= 0:
+        raise OzLibraryError("no HIP device visible: othellozero_amd computes on an MI355X only (no CPU fallback)")
+    return lib
+
+
+# numpy -> pointer helpers
+def p_u64(a): return a.ctypes.data_as(_u64p)
+def p_i32(a): return a.ctypes.data_as(_i32p)
+def p_f32(a): return a.ctypes.data_as(_f32p)
+def p_f64(a): return a.ctypes.data_as(_f64p)
+def p_u8(a): return a.ctypes.data_as(_u8p)
+def p_i8(a): return a.ctypes.data_as(_i8p)
+def p_i64(a): return a.ctypes.data_as(_i64p)
+
+
+def pack_board(board):
+    """(n,n,2) array-like (channel 0, channel 1) -> two python ints, bit = row*8 + col."""
+    b = np.asarray(board).astype(bool)
+    n = b.shape[0]
+    w = (np.uint64(1) << (np.arange(n, dtype=np.uint64)[:, None] * np.uint64(8) + np.arange(n, dtype=np.uint64)[None, :]))
+    return int(w[b[:, :, 0]].sum(dtype=np.uint64)), int(w[b[:, :, 1]].sum(dtype=np.uint64))
+
+
+def unpack_board(c0, c1, n):
+    sq = (np.arange(n, dtype=np.uint64)[:, None] * np.uint64(8) + np.arange(n, dtype=np.uint64)[None, :])
+    out = np.zeros((n, n, 2), dtype=bool)
+    out[:, :, 0] = (np.uint64(c0) >> sq) & np.uint64(1)
+    out[:, :, 1] = (np.uint64(c1) >> sq) & np.uint64(1)
+    return out

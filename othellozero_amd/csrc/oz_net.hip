@@ -1,0 +1,547 @@
+// oz_net.hip -- batched leaf evaluation: OthelloNN inference (K9-K12) for gfx950.
+//
+// Replaces NNetWrapper.predict (Net/NNet.py:70-87) over the Keras graph of Net/OthelloNN.py:42-56:
+//   conv1 3x3 same 2->C, conv2 3x3 same C->C, conv3 3x3 valid, conv4 3x3 valid (each + BN + ReLU),
+//   Flatten (h,w,c), Dense 1024 + BN + ReLU, Dense 512 + BN + ReLU, softmax(n*n) head, tanh head.
+// BN uses moving statistics with epsilon 1e-3 (Keras default) folded into a per-channel scale/shift;
+// Dropout is identity at inference.
+//
+// Kernels:
+//   k_conv1       bitboards -> NHWC activations; the plane unpack (K9) is fused, K = 18, VALU.
+//   k_gemm_f32    implicit-GEMM 3x3 convolution / dense layer on the fp32 matrix cores
+//                 (v_mfma_f32_32x32x2_f32): 128x128x32 block tile, 4 waves of 64x64 (2x2 MFMA tiles),
+//                 A (activation rows, gathered per 3x3 tap with zero fill) and B (weights, stored
+//                 [Cout][K] so k is contiguous) staged through padded LDS tiles, register-prefetch
+//                 double buffering, fused scale/shift/ReLU epilogue.  MFMA-bound: 64 MFMAs (4096
+//                 cycles) per 32 KB of staged operands.
+//   k_heads       policy softmax + value tanh, one wavefront per position.
+// Every output row is an independent k-ordered fp32 FMA chain, so a position's (pi, v) does not
+// depend on where in the batch it sits (the search relies on that for reproducibility).
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "oz_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- conv1 (+ plane unpack)
+// out[m][co] = relu(scale[co] * sum_{tap,ch} x[b][y+ky-1][x+kx-1][ch] * W[tap][ch][co] + shift[co])
+// one thread per (row m, 4 consecutive output channels)
+__global__ __launch_bounds__(256) void k_conv1(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
+                                               const int* __restrict__ d_count, int n, int C,
+                                               const float* __restrict__ W /*[9][2][C]*/, const float* __restrict__ scale,
+                                               const float* __restrict__ shift, float* __restrict__ out /*[B][n*n][C]*/) {
+    const int P = n * n, cq = C >> 2;
+    const long long M = (long long)(*d_count) * P;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long m = idx / cq;
+    if (m >= M) return;
+    const int c4 = (int)(idx % cq) * 4;
+    const int b = (int)(m / P), pix = (int)(m % P), y = pix / n, x = pix % n;
+    const uint64_t o = own[b], p = opp[b];
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = y + ky - 1, ix = x + kx - 1;
+            if (iy < 0 || iy >= n || ix < 0 || ix >= n) continue;
+            const int sq = iy * 8 + ix;
+            const float a0 = (float)((o >> sq) & 1), a1 = (float)((p >> sq) & 1);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(W + (size_t)((ky * 3 + kx) * 2 + 0) * C + c4);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(W + (size_t)((ky * 3 + kx) * 2 + 1) * C + c4);
+            acc0 = fmaf(a0, w0[0], acc0); acc1 = fmaf(a0, w0[1], acc1); acc2 = fmaf(a0, w0[2], acc2); acc3 = fmaf(a0, w0[3], acc3);
+            acc0 = fmaf(a1, w1[0], acc0); acc1 = fmaf(a1, w1[1], acc1); acc2 = fmaf(a1, w1[2], acc2); acc3 = fmaf(a1, w1[3], acc3);
+        }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4), sh = *reinterpret_cast<const f32x4*>(shift + c4);
+    f32x4 r;
+    r[0] = fmaxf(fmaf(acc0, sc[0], sh[0]), 0.f); r[1] = fmaxf(fmaf(acc1, sc[1], sh[1]), 0.f);
+    r[2] = fmaxf(fmaf(acc2, sc[2], sh[2]), 0.f); r[3] = fmaxf(fmaf(acc3, sc[3], sh[3]), 0.f);
+    *reinterpret_cast<f32x4*>(out + (size_t)m * C + c4) = r;
+}
+
+// ---------------------------------------------------------------- implicit GEMM on fp32 MFMA
+#define GM_BM 128
+#define GM_BN 128
+#define GM_BK 32
+#define GM_LDS_STRIDE 36   // floats per staged row: 32 + 4 pad -> conflict-free ds_read_b128 / ds_write_b128
+
+struct GemmGeom {
+    int Hin, Hout, pad, Cin, taps;   // taps = 9 (3x3 conv) or 1 (dense: Hin = Hout = 1, pad = 0)
+    int N, K;                        // output channels, taps*Cin
+    int relu;
+};
+
+// out[M][N] = act((A[M][K] . Wt[N][K]^T) * scale + shift), M = *d_count * Hout^2, rows (b, oy, ox)
+__global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ in, const float* __restrict__ Wt,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     float* __restrict__ out, const int* __restrict__ d_count,
+                                                     GemmGeom g, int num_mt) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][GM_BM * GM_LDS_STRIDE];   // [buf][A|B][row][k]
+    // XCD-aware tile order: the N/128 column tiles of one row tile run on the same XCD (ids b, b+8 share an L2)
+    const int nnt = g.N / GM_BN;
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    const int mt = (j / nnt) * 8 + xcd, nt = j % nnt;
+    const int P = g.Hout * g.Hout;
+    const long long M = (long long)(*d_count) * P;
+    if (mt >= num_mt || (long long)mt * GM_BM >= M) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int chunk = tid & 7, srow = tid >> 3;          // staging: row srow + 32*i, k offset chunk*4
+
+    // per staged A row: base offset of input pixel (oy-pad, ox-pad) and the 9-bit tap validity mask
+    long long abase[4];
+    unsigned amask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long m = (long long)mt * GM_BM + srow + 32 * i;
+        abase[i] = 0; amask[i] = 0;
+        if (m < M) {
+            const int b = (int)(m / P), pix = (int)(m % P), oy = pix / g.Hout, ox = pix % g.Hout;
+            abase[i] = (((long long)b * g.Hin + (oy - g.pad)) * g.Hin + (ox - g.pad)) * g.Cin;
+            unsigned mk = 0;
+            for (int t = 0; t < g.taps; ++t) {
+                const int iy = oy - g.pad + t / 3, ix = ox - g.pad + t % 3;
+                if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Hin) mk |= 1u << t;
+            }
+            amask[i] = mk;
+        }
+    }
+    const float* brow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) brow[i] = Wt + (size_t)(nt * GM_BN + srow + 32 * i) * g.K + chunk * 4;
+
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+        const int k0 = kt * GM_BK, tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin;
+        const long long toff = ((long long)(tap / 3) * g.Hin + (tap % 3)) * g.Cin + ci0 + chunk * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            ra[i] = ((amask[i] >> tap) & 1) ? *reinterpret_cast<const f32x4*>(in + abase[i] + toff) : z;
+            rb[i] = *reinterpret_cast<const f32x4*>(brow[i] + k0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&lds[buf][0][(srow + 32 * i) * GM_LDS_STRIDE + chunk * 4]) = ra[i];
+            *reinterpret_cast<f32x4*>(&lds[buf][1][(srow + 32 * i) * GM_LDS_STRIDE + chunk * 4]) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    const int nk = g.K / GM_BK;
+    const int r32 = lane & 31, half = lane >> 5;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* At = &lds[buf][0][(wm * 64 + r32) * GM_LDS_STRIDE + half * 4];
+        const float* Bt = &lds[buf][1][(wn * 64 + r32) * GM_LDS_STRIDE + half * 4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // lane (r, half) holds k = 8s + 4*half + {0..3}: MFMA j pairs k = 8s+j (half 0) with 8s+4+j (half 1)
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(At + s * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(At + 32 * GM_LDS_STRIDE + s * 8);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bt + s * 8);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bt + 32 * GM_LDS_STRIDE + s * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b1[q], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b0[q], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b1[q], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int col = nt * GM_BN + wn * 64 + jj * 32 + r32;
+        const float sc = scale[col], sh = shift[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = (long long)mt * GM_BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < M) {
+                    float v = fmaf(acc[i][jj][r], sc, sh);
+                    if (g.relu) v = v > 0.f ? v : 0.f;
+                    out[(size_t)m * g.N + col] = v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------- heads
+// one wave per position: logits[a] = f2 . Wpi[:,a] + bpi[a] -> softmax; v = tanh(f2 . Wv + bv)
+__global__ __launch_bounds__(64) void k_heads(const float* __restrict__ f2 /*[B][512]*/, const int* __restrict__ d_count,
+                                              int A, const float* __restrict__ Wpi /*[512][A]*/, const float* __restrict__ bpi,
+                                              const float* __restrict__ Wv /*[512]*/, const float* __restrict__ bv,
+                                              float* __restrict__ pi, float* __restrict__ v) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= *d_count) return;
+    const float* x = f2 + (size_t)b * 512;
+    float logit = 0.f, vpart = 0.f;
+    const bool act = lane < A;
+    for (int i = 0; i < 512; ++i) {
+        const float xi = x[i];
+        if (act) logit = fmaf(xi, Wpi[(size_t)i * A + lane], logit);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vpart = fmaf(x[lane * 8 + i], Wv[lane * 8 + i], vpart);
+    logit = act ? logit + bpi[lane] : -INFINITY;
+    float mx = logit;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float e = act ? expf(logit - mx) : 0.f, s = e;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); vpart += __shfl_xor(vpart, off, 64); }
+    if (act) pi[(size_t)b * A + lane] = e / s;
+    if (lane == 0) v[b] = tanhf(vpart + bv[0]);
+}
+
+// ---------------------------------------------------------------- stub evaluator (test nets)
+__global__ __launch_bounds__(64) void k_stub(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
+                                             const int* __restrict__ d_count, int n, uint64_t salt, uint64_t keep,
+                                             float* __restrict__ pi, float* __restrict__ v) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= *d_count) return;
+    const uint64_t o = own[b], p = opp[b];
+    const int r = lane >> 3, c = lane & 7;
+    const bool inb = r < n && c < n;
+    uint32_t w = 0;
+    if (inb) {
+        const uint64_t u = oz_stub_h(o, p, salt, (uint64_t)lane);
+        w = (uint32_t)((u >> 40) & 0xFFFF);
+        if (((u >> 8) & keep) != 0) w = 0;
+    }
+    uint32_t sum = w;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (sum == 0) { if (lane == 0) w = 1; sum = 1; }
+    if (inb) pi[(size_t)b * n * n + r * n + c] = (float)w / (float)sum;
+    if (lane == 0) {
+        const int32_t m = (int32_t)(oz_stub_h(o, p, salt, 64) >> 40);
+        v[b] = (float)(m - 8388608) / 8388608.0f;
+    }
+}
+
+// ================================================================ host objects
+struct StubNet : oz_net {
+    uint64_t salt = 0, keep = 0;
+    int forward_device(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi,
+                       float* d_v, hipStream_t s) override {
+        hipLaunchKernelGGL(k_stub, dim3(max_count), dim3(64), 0, s, d_own, d_opp, d_count, n, salt, keep, d_pi, d_v);
+        OZ_HIP(hipGetLastError());
+        return OZ_OK;
+    }
+};
+
+struct OnnNet : oz_net {
+    int F = 0, A = 0;
+    std::vector<std::vector<float>> w;      // 40 arrays, keras get_weights() order
+    bool committed = false;
+    // device
+    float *d_w1 = nullptr, *d_wt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // conv2..4, fc1, fc2 as [N][K]
+    float *d_scale[6] = {}, *d_shift[6] = {};
+    float *d_wpi = nullptr, *d_bpi = nullptr, *d_wv = nullptr, *d_bv = nullptr;
+    float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *act4 = nullptr, *f1 = nullptr, *f2 = nullptr;
+    float *ones = nullptr, *zeros = nullptr;
+    std::vector<void*> allocs;
+    // profiling of the dominant launch (conv2)
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double conv2_ms = 0; long long conv2_launches = 0;
+
+    template <typename T> int alloc(T** p, size_t count) {
+        OZ_HIP(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+        allocs.push_back(*p);
+        return OZ_OK;
+    }
+    std::vector<int64_t> sizes() const {
+        std::vector<int64_t> s;
+        const int cins[4] = {2, C, C, C};
+        for (int l = 0; l < 4; ++l) { s.push_back(9ll * cins[l] * C); for (int k = 0; k < 5; ++k) s.push_back(C); }
+        s.push_back((int64_t)F * 1024); for (int k = 0; k < 5; ++k) s.push_back(1024);
+        s.push_back(1024ll * 512); for (int k = 0; k < 5; ++k) s.push_back(512);
+        s.push_back(512ll * A); s.push_back(A); s.push_back(512); s.push_back(1);
+        return s;
+    }
+    ~OnnNet() override {
+        hipSetDevice(device);
+        for (auto& pr : pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+        for (void* p : allocs) hipFree(p);
+    }
+
+    int launch_gemm(const float* in, const float* Wt, int layer, float* out, const int* d_count, int max_count, int Hin,
+                    int Hout, int pad, int Cin, int taps, int N, hipStream_t s) {
+        GemmGeom g;
+        g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.relu = 1;
+        const long long Mmax = (long long)max_count * Hout * Hout;
+        const int num_mt = (int)((Mmax + GM_BM - 1) / GM_BM);
+        const int grid = ((num_mt + 7) / 8) * 8 * (N / GM_BN);
+        hipLaunchKernelGGL(k_gemm_f32, dim3(grid), dim3(256), 0, s, in, Wt, d_scale[layer], d_shift[layer], out, d_count, g, num_mt);
+        OZ_HIP(hipGetLastError());
+        return OZ_OK;
+    }
+
+    int forward_device(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi,
+                       float* d_v, hipStream_t s) override {
+        if (!committed) { oz_set_error("network weights not committed (call oz_net_commit)"); return OZ_ERR_STATE; }
+        if (max_count > max_batch) { oz_set_error("batch %d exceeds max_batch %d", max_count, max_batch); return OZ_ERR_ARG; }
+        const int P = n * n;
+        {
+            const long long threads = (long long)max_count * P * (C / 4);
+            hipLaunchKernelGGL(k_conv1, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, C,
+                               d_w1, d_scale[0], d_shift[0], act1);
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile && pending.size() > 4096) { if (int rc = collect_profile()) return rc; }
+        if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); OZ_HIP(hipEventRecord(e0, s)); }
+        if (int rc = launch_gemm(act1, d_wt[0], 1, act2, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
+        if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
+        if (int rc = launch_gemm(act2, d_wt[1], 2, act3, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
+        if (int rc = launch_gemm(act3, d_wt[2], 3, act4, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
+        if (int rc = launch_gemm(act4, d_wt[3], 4, f1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
+        if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
+        hipLaunchKernelGGL(k_heads, dim3(max_count), dim3(64), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        OZ_HIP(hipGetLastError());
+        return OZ_OK;
+    }
+    int collect_profile() {
+        for (auto& pr : pending) {
+            float ms = 0;
+            OZ_HIP(hipEventSynchronize(pr.second));
+            OZ_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+            conv2_ms += ms; conv2_launches += 1;
+            hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+        }
+        pending.clear();
+        return OZ_OK;
+    }
+};
+
+int oz_net_forward_device(oz_net* net, const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count,
+                          float* d_pi, float* d_v, hipStream_t s) {
+    return net->forward_device(d_own, d_opp, d_count, max_count, d_pi, d_v, s);
+}
+
+OZ_API int oz_net_create(oz_net** out, int n, int channels, int max_batch) {
+    OZ_REQUIRE(out, "null out pointer");
+    OZ_REQUIRE(n == 6 || n == 8, "OthelloNN needs board size 6 or 8 (two 'valid' 3x3 convolutions); got %d", n);
+    OZ_REQUIRE(channels >= 128 && channels % 128 == 0, "channels must be a positive multiple of 128 (got %d)", channels);
+    OZ_REQUIRE(max_batch > 0, "max_batch must be positive");
+    OnnNet* net = new OnnNet();
+    net->kind = 0; net->n = n; net->C = channels; net->max_batch = max_batch; net->device = oz_current_device();
+    net->F = (n - 4) * (n - 4) * channels; net->A = n * n;
+    auto sz = net->sizes();
+    net->w.resize(sz.size());
+    for (size_t i = 0; i < sz.size(); ++i) net->w[i].assign((size_t)sz[i], 0.f);
+    // BN defaults: gamma 1, variance 1
+    for (int l = 0; l < 6; ++l) {
+        std::fill(net->w[6 * l + 2].begin(), net->w[6 * l + 2].end(), 1.f);
+        std::fill(net->w[6 * l + 5].begin(), net->w[6 * l + 5].end(), 1.f);
+    }
+    *out = net;
+    return OZ_OK;
+}
+
+OZ_API int oz_net_create_stub(oz_net** out, int n, uint64_t salt, uint64_t keep_mask, int max_batch) {
+    OZ_REQUIRE(out, "null out pointer");
+    OZ_REQUIRE(n == 4 || n == 6 || n == 8, "board size must be 4, 6 or 8");
+    StubNet* net = new StubNet();
+    net->kind = 1; net->n = n; net->C = 0; net->max_batch = max_batch; net->device = oz_current_device();
+    net->salt = salt; net->keep = keep_mask;
+    *out = net;
+    return OZ_OK;
+}
+
+OZ_API int oz_net_destroy(oz_net* net) { delete net; return OZ_OK; }
+
+static OnnNet* as_onn(oz_net* net) { return net && net->kind == 0 ? static_cast<OnnNet*>(net) : nullptr; }
+
+OZ_API int oz_net_num_weights(const oz_net* net) { return net && net->kind == 0 ? 40 : 0; }
+OZ_API int oz_net_weight_size(const oz_net* net, int index, int64_t* nelem) {
+    const OnnNet* o = as_onn(const_cast<oz_net*>(net));
+    OZ_REQUIRE(o && nelem, "not an OthelloNN network");
+    OZ_REQUIRE(index >= 0 && index < 40, "weight index out of range");
+    *nelem = (int64_t)o->w[index].size();
+    return OZ_OK;
+}
+OZ_API int oz_net_set_weight(oz_net* net, int index, const float* data, int64_t nelem) {
+    OnnNet* o = as_onn(net);
+    OZ_REQUIRE(o && data, "not an OthelloNN network");
+    OZ_REQUIRE(index >= 0 && index < 40, "weight index out of range");
+    OZ_REQUIRE(nelem == (int64_t)o->w[index].size(), "weight %d: expected %lld elements, got %lld", index, (long long)o->w[index].size(), (long long)nelem);
+    std::lock_guard<std::mutex> lk(o->mu);
+    memcpy(o->w[index].data(), data, sizeof(float) * (size_t)nelem);
+    o->committed = false;
+    return OZ_OK;
+}
+OZ_API int oz_net_get_weight(const oz_net* net, int index, float* data, int64_t nelem) {
+    const OnnNet* o = as_onn(const_cast<oz_net*>(net));
+    OZ_REQUIRE(o && data, "not an OthelloNN network");
+    OZ_REQUIRE(index >= 0 && index < 40, "weight index out of range");
+    OZ_REQUIRE(nelem == (int64_t)o->w[index].size(), "weight %d: size mismatch", index);
+    memcpy(data, o->w[index].data(), sizeof(float) * (size_t)nelem);
+    return OZ_OK;
+}
+
+static int upload(OnnNet* o, float** dst, const std::vector<float>& h) {
+    if (!*dst) { if (int rc = o->alloc(dst, h.size())) return rc; }
+    OZ_HIP(hipMemcpy(*dst, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+    return OZ_OK;
+}
+
+OZ_API int oz_net_commit(oz_net* net) {
+    OnnNet* o = as_onn(net);
+    OZ_REQUIRE(o, "not an OthelloNN network");
+    std::lock_guard<std::mutex> lk(o->mu);
+    hipSetDevice(o->device);
+    const int C = o->C, n = o->n;
+    // BN fold (epsilon 1e-3): y = (x + bias - mean) * gamma / sqrt(var + eps) + beta
+    const int widths[6] = {C, C, C, C, 1024, 512};
+    for (int l = 0; l < 6; ++l) {
+        std::vector<float> sc(widths[l]), sh(widths[l]);
+        const auto &bias = o->w[6 * l + 1], &g = o->w[6 * l + 2], &be = o->w[6 * l + 3], &mu = o->w[6 * l + 4], &var = o->w[6 * l + 5];
+        for (int c = 0; c < widths[l]; ++c) {
+            const double s = (double)g[c] / sqrt((double)var[c] + 1e-3);
+            sc[c] = (float)s;
+            sh[c] = (float)(((double)bias[c] - (double)mu[c]) * s + (double)be[c]);
+        }
+        if (int rc = upload(o, &o->d_scale[l], sc)) return rc;
+        if (int rc = upload(o, &o->d_shift[l], sh)) return rc;
+    }
+    if (int rc = upload(o, &o->d_w1, o->w[0])) return rc;                       // [9][2][C] as stored
+    // conv2..4 kernels (3,3,Cin,Cout) -> [Cout][K], k = tap*Cin + ci ; dense (in,out) -> [out][in]
+    const int gl[5] = {6, 12, 18, 24, 30};
+    const int Ks[5] = {9 * C, 9 * C, 9 * C, o->F, 1024}, Ns[5] = {C, C, C, 1024, 512};
+    for (int i = 0; i < 5; ++i) {
+        const auto& src = o->w[gl[i]];
+        std::vector<float> t((size_t)Ks[i] * Ns[i]);
+        for (int k = 0; k < Ks[i]; ++k)
+            for (int c = 0; c < Ns[i]; ++c) t[(size_t)c * Ks[i] + k] = src[(size_t)k * Ns[i] + c];
+        if (int rc = upload(o, &o->d_wt[i], t)) return rc;
+    }
+    if (int rc = upload(o, &o->d_wpi, o->w[36])) return rc;
+    if (int rc = upload(o, &o->d_bpi, o->w[37])) return rc;
+    if (int rc = upload(o, &o->d_wv, o->w[38])) return rc;
+    if (int rc = upload(o, &o->d_bv, o->w[39])) return rc;
+    if (!o->act1) {
+        const size_t B = (size_t)o->max_batch;
+        if (int rc = o->alloc(&o->act1, B * n * n * C)) return rc;
+        if (int rc = o->alloc(&o->act2, B * n * n * C)) return rc;
+        if (int rc = o->alloc(&o->act3, B * (n - 2) * (n - 2) * C)) return rc;
+        if (int rc = o->alloc(&o->act4, B * (size_t)o->F)) return rc;
+        if (int rc = o->alloc(&o->f1, B * 1024)) return rc;
+        if (int rc = o->alloc(&o->f2, B * 512)) return rc;
+    }
+    OZ_HIP(hipDeviceSynchronize());
+    o->committed = true;
+    return OZ_OK;
+}
+
+OZ_API int oz_net_predict(oz_net* net, const uint64_t* own, const uint64_t* opp, int count, float* pi, float* v) {
+    OZ_REQUIRE(net && own && opp && pi && v, "null argument");
+    OZ_REQUIRE(count >= 0 && count <= net->max_batch, "count %d outside [0, max_batch=%d]", count, net->max_batch);
+    if (count == 0) return OZ_OK;
+    std::lock_guard<std::mutex> lk(net->mu);
+    hipSetDevice(net->device);
+    const int n2 = net->n * net->n;
+    uint64_t *d_own = nullptr, *d_opp = nullptr; int* d_count = nullptr; float *d_pi = nullptr, *d_v = nullptr;
+    int rc = OZ_OK;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_own, 8ull * count)) != hipSuccess || (e = hipMalloc((void**)&d_opp, 8ull * count)) != hipSuccess ||
+        (e = hipMalloc((void**)&d_count, 4)) != hipSuccess || (e = hipMalloc((void**)&d_pi, 4ull * count * n2)) != hipSuccess ||
+        (e = hipMalloc((void**)&d_v, 4ull * count)) != hipSuccess) {
+        oz_set_error("hipMalloc failed: %s", hipGetErrorString(e)); rc = OZ_ERR_HIP;
+    }
+    if (!rc) {
+        hipMemcpy(d_own, own, 8ull * count, hipMemcpyHostToDevice);
+        hipMemcpy(d_opp, opp, 8ull * count, hipMemcpyHostToDevice);
+        hipMemcpy(d_count, &count, 4, hipMemcpyHostToDevice);
+        rc = net->forward_device(d_own, d_opp, d_count, count, d_pi, d_v, 0);
+    }
+    if (!rc) {
+        if ((e = hipDeviceSynchronize()) != hipSuccess) { oz_set_error("forward failed: %s", hipGetErrorString(e)); rc = OZ_ERR_HIP; }
+    }
+    if (!rc) {
+        hipMemcpy(pi, d_pi, 4ull * count * n2, hipMemcpyDeviceToHost);
+        hipMemcpy(v, d_v, 4ull * count, hipMemcpyDeviceToHost);
+    }
+    hipFree(d_own); hipFree(d_opp); hipFree(d_count); hipFree(d_pi); hipFree(d_v);
+    return rc;
+}
+
+__global__ void k_fill_boards(uint64_t* own, uint64_t* opp, int count, uint64_t valid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t a = oz_sm64(0x1234 + i), b = oz_sm64(0x9876 + 7ull * i), e = oz_sm64(0x5555 + 3ull * i);
+    own[i] = a & ~b & e & valid;
+    opp[i] = b & ~a & e & valid;
+}
+
+OZ_API int oz_net_time_forward(oz_net* net, int count, int iters, float* ms_avg) {
+    OZ_REQUIRE(net && ms_avg, "null argument");
+    OZ_REQUIRE(count > 0 && count <= net->max_batch && iters > 0, "bad count / iters");
+    std::lock_guard<std::mutex> lk(net->mu);
+    hipSetDevice(net->device);
+    const int n2 = net->n * net->n;
+    uint64_t *d_own, *d_opp; int* d_count; float *d_pi, *d_v;
+    OZ_HIP(hipMalloc((void**)&d_own, 8ull * count)); OZ_HIP(hipMalloc((void**)&d_opp, 8ull * count));
+    OZ_HIP(hipMalloc((void**)&d_count, 4)); OZ_HIP(hipMalloc((void**)&d_pi, 4ull * count * n2)); OZ_HIP(hipMalloc((void**)&d_v, 4ull * count));
+    hipLaunchKernelGGL(k_fill_boards, dim3((count + 255) / 256), dim3(256), 0, 0, d_own, d_opp, count, oz_valid_mask(net->n));
+    hipMemcpy(d_count, &count, 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    int rc = net->forward_device(d_own, d_opp, d_count, count, d_pi, d_v, 0);   // warm-up
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters && !rc; ++i) rc = net->forward_device(d_own, d_opp, d_count, count, d_pi, d_v, 0);
+    hipEventRecord(e1, 0);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_avg = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(d_own); hipFree(d_opp); hipFree(d_count); hipFree(d_pi); hipFree(d_v);
+    if (rc) return rc;
+    OZ_HIP(e);
+    return OZ_OK;
+}
+
+// profiling of the dominant launch (conv2 implicit GEMM): HIP events on the launching stream
+OZ_API int oz_net_profile(oz_net* net, int enable) {
+    OnnNet* o = as_onn(net);
+    OZ_REQUIRE(o, "not an OthelloNN network");
+    std::lock_guard<std::mutex> lk(o->mu);
+    o->profile = enable != 0;
+    return OZ_OK;
+}
+OZ_API int oz_net_profile_read(oz_net* net, double* conv2_ms_total, int64_t* conv2_launches) {
+    OnnNet* o = as_onn(net);
+    OZ_REQUIRE(o, "not an OthelloNN network");
+    std::lock_guard<std::mutex> lk(o->mu);
+    hipSetDevice(o->device);
+    if (int rc = o->collect_profile()) return rc;
+    if (conv2_ms_total) *conv2_ms_total = o->conv2_ms;
+    if (conv2_launches) *conv2_launches = o->conv2_launches;
+    return OZ_OK;
+}

@@ -1,0 +1,1119 @@
+// oz_search.hip -- PUCT search (K4-K7, K13), self-play and arena drivers for gfx950.
+//
+// Replaces MCTS/__init__.py:19-187 + othelo_mcts.py:9-88 (search) and training.py:26-72,
+// agents.py:44-84 (drivers).  Design (MI355X-first, not a translation):
+//   * every game owns one OthelloMCTS instance = one open-addressing table keyed by the exact
+//     128-bit (own, opp) pair (replaces sha1, MCTS/__init__.py:7-16) plus SoA node / edge pools,
+//     all resident in HBM; nothing is rebuilt between moves (sub-tree / transposition reuse);
+//   * ONE WAVEFRONT PER GAME: lane == board square.  PUCT argmax (MCTS/__init__.py:65,168-170)
+//     is a 64-lane max-reduction + ballot, lowest lane wins ties (== Python's first maximum in
+//     ascending square order); table probes are 64-wide ballots; the backup walks all path levels
+//     in parallel (one lane per level);
+//   * lock step: every active game advances exactly one simulation per step (simulations of one
+//     game are sequential in the reference; no virtual loss), leaves that need the network are
+//     compacted by ballot + prefix sum into one dense batch (deterministic slot order), evaluated
+//     by one NN launch sequence, then expanded / backed up;
+//   * float semantics that decide discrete outcomes are restated exactly (SURVEY.md R-FP):
+//     U in float64 evaluated left to right with no FMA contraction, P normalised with NumPy's
+//     pairwise order, Q accumulated in the dynamic type NumPy would use (q_mode).
+#pragma clang fp contract(off)
+#include <math.h>
+#include <string.h>
+
+#include "oz_internal.h"
+
+enum { VT_INT = 0, VT_F32 = 1, VT_F64 = 2 };
+#define OZ_MAX_DEPTH 64
+#define OZ_TAG_F32 0x80000000u
+#define OZ_NSTAT 5
+enum { ST_SIMS = 0, ST_VISITS = 1, ST_EXPAND = 2, ST_TERMINAL = 3, ST_FALLBACK = 4 };
+enum { EF_NODES = 1, EF_EDGES = 2, EF_DEPTH = 4, EF_NOMOVE = 8, EF_RECORDS = 16, EF_ROOT = 32 };
+
+struct MctsDev {
+    int G, n, n2, node_cap, edge_cap, ht_cap;
+    uint64_t valid;
+    double c;
+    int qmode;
+    uint64_t *node_own, *node_opp, *node_legal;
+    int *node_Ns, *node_ebase, *node_count, *edge_count;
+    uint32_t* edge_N;          // visit count | OZ_TAG_F32 when Q is float32-typed
+    double *edge_Q, *edge_P;
+    int* ht;
+    uint64_t *root_own, *root_opp;
+    uint8_t* active;
+    int* leaf_status;
+    uint64_t *leaf_own, *leaf_opp, *leaf_legal;
+    int *depth, *term_value, *leaf_slot;
+    int2* path;                // [G][OZ_MAX_DEPTH] (node, edge)
+    uint64_t *batch_own, *batch_opp;
+    int* batch_count;
+    float *pi, *v;
+    double* last_value;
+    int* last_vtype;
+    unsigned long long* stat;  // [G][OZ_NSTAT]
+    int* error_flag;
+};
+
+// ---------------------------------------------------------------- wave helpers (wave = 64 lanes)
+__device__ __forceinline__ double wave_max_f64(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double y = __shfl_xor(x, off, 64);
+        x = y > x ? y : x;
+    }
+    return x;
+}
+__device__ __forceinline__ int wave_max_i32(int x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int y = __shfl_xor(x, off, 64);
+        x = y > x ? y : x;
+    }
+    return x;
+}
+
+__device__ __forceinline__ uint32_t key_hash(uint64_t own, uint64_t opp) {
+    return (uint32_t)(oz_sm64(own * 0x2545F4914F6CDD1DULL ^ oz_sm64(opp)) >> 17);
+}
+
+// 64-wide linear probe.  Returns the node index or -1; *free_slot = first empty slot of the probe
+// sequence (where an insert must go).  All lanes get the same results.
+__device__ int ht_find(const int* __restrict__ ht, int cap, const uint64_t* __restrict__ nown,
+                       const uint64_t* __restrict__ nopp, uint64_t own, uint64_t opp, int lane, int* free_slot) {
+    const int mask = cap - 1;
+    int base = (int)(key_hash(own, opp) & (uint32_t)mask);
+    for (int probed = 0; probed < cap; probed += 64, base = (base + 64) & mask) {
+        const int idx = ht[(base + lane) & mask];
+        const bool empty = idx < 0;
+        const bool match = !empty && nown[idx] == own && nopp[idx] == opp;
+        const uint64_t mb = __ballot(match), eb = __ballot(empty);
+        if (mb) {
+            const int ml = oz_ctz(mb);
+            if (!eb || ml < oz_ctz(eb)) return __shfl(idx, ml, 64);
+        }
+        if (eb) {
+            *free_slot = (base + oz_ctz(eb)) & mask;
+            return -1;
+        }
+    }
+    *free_slot = -1;
+    return -1;
+}
+
+// NumPy pairwise sum of a contiguous float64 vector, 8 <= len <= 128 (np.sum at MCTS/__init__.py:49-51)
+__device__ double pairwise_sum(const double* a, int len) {
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < len - (len % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < len; ++i) res += a[i];
+    return res;
+}
+
+// ---------------------------------------------------------------- K4: select / descend
+// MCTS.simulate down to the first terminal or unexpanded state (MCTS/__init__.py:39-44,58-67),
+// get_next_state (othelo_mcts.py:43-49).  One wave per game.
+__global__ __launch_bounds__(64) void k_select(MctsDev t) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!t.active[g]) {
+        if (lane == 0) t.leaf_status[g] = OZ_LEAF_IDLE;
+        return;
+    }
+    uint64_t own = t.root_own[g], opp = t.root_opp[g];
+    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    const int* ht = t.ht + (size_t)g * t.ht_cap;
+    int2* path = t.path + (size_t)g * OZ_MAX_DEPTH;
+    int depth = 0, status, tval = 0, err = 0;
+    uint64_t legal;
+    for (;;) {
+        legal = oz_legal(own, opp, t.valid);
+        if (legal == 0 && oz_legal(opp, own, t.valid) == 0) {       // is_terminal_state, othelo_mcts.py:28-29
+            // get_state_reward: winner of the ch0 view, draw -> ch0; simulate returns -reward
+            tval = oz_popc(own) >= oz_popc(opp) ? -1 : 1;
+            status = OZ_LEAF_TERMINAL;
+            break;
+        }
+        int fs;
+        const int node = ht_find(ht, t.ht_cap, t.node_own + nb, t.node_opp + nb, own, opp, lane, &fs);
+        if (node < 0) { status = OZ_LEAF_EVAL; break; }
+        if (legal == 0) { err = EF_NOMOVE; status = OZ_LEAF_IDLE; break; }   // reference: max() of empty list
+        if (depth >= OZ_MAX_DEPTH) { err = EF_DEPTH; status = OZ_LEAF_IDLE; break; }
+        const int Ns = t.node_Ns[nb + node], ebase = t.node_ebase[nb + node];
+        const bool is_legal = (legal >> lane) & 1;
+        const int rank = oz_popc(legal & ((1ULL << lane) - 1ULL));
+        double U = -INFINITY;
+        if (is_legal) {
+            const size_t e = eb + ebase + rank;
+            const int N = (int)(t.edge_N[e] & ~OZ_TAG_F32);
+            const double Q = t.edge_Q[e], P = t.edge_P[e];
+            const double bound = sqrt((double)Ns) / (double)(1 + N);       // MCTS/__init__.py:169
+            U = Q + (t.c * P) * bound;                                     // :170, left to right
+        }
+        const double m = wave_max_f64(U);
+        const int best = oz_ctz(__ballot(is_legal && U == m));             // first maximum
+        const int brank = oz_popc(legal & ((1ULL << best) - 1ULL));
+        if (lane == 0) path[depth] = make_int2(node, ebase + brank);
+        ++depth;
+        oz_apply(own, opp, best);
+        if (oz_legal(opp, own, t.valid) != 0) { uint64_t s = own; own = opp; opp = s; }   // swap only if the opponent can move
+    }
+    if (lane == 0) {
+        t.leaf_status[g] = status;
+        t.leaf_own[g] = own; t.leaf_opp[g] = opp; t.leaf_legal[g] = legal;
+        t.depth[g] = depth; t.term_value[g] = tval;
+        unsigned long long* st = t.stat + (size_t)g * OZ_NSTAT;
+        st[ST_SIMS] += 1; st[ST_VISITS] += (unsigned long long)(depth + 1);
+        if (status == OZ_LEAF_TERMINAL) st[ST_TERMINAL] += 1;
+        if (err) atomicOr(t.error_flag, err);
+    }
+}
+
+// ---------------------------------------------------------------- K13: leaf compaction
+// ballot + prefix sum over the games; slot order = game order (deterministic).
+__global__ __launch_bounds__(1024) void k_compact(MctsDev t) {
+    __shared__ int wtot[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int start = 0; start < t.G; start += 1024) {
+        const int g = start + tid;
+        const bool flag = g < t.G && t.leaf_status[g] == OZ_LEAF_EVAL;
+        const uint64_t b = __ballot(flag);
+        const int pre = oz_popc(b & ((1ULL << lane) - 1ULL));
+        if (lane == 0) wtot[w] = oz_popc(b);
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int i = 0; i < 16; ++i) { int x = wtot[i]; if (i < w) woff += x; total += x; }
+        const int base = base_s;
+        if (flag) {
+            const int slot = base + woff + pre;
+            t.leaf_slot[g] = slot;
+            t.batch_own[slot] = t.leaf_own[g];
+            t.batch_opp[slot] = t.leaf_opp[g];
+        }
+        __syncthreads();
+        if (tid == 0) base_s = base + total;
+        __syncthreads();
+    }
+    if (tid == 0) *t.batch_count = base_s;
+}
+
+// ---------------------------------------------------------------- K5 + K6: expand and backup
+__device__ __forceinline__ void q_update(const MctsDev& t, size_t e, double val, int vt) {
+    const uint32_t nt = t.edge_N[e];
+    const int N = (int)(nt & ~OZ_TAG_F32);
+    const bool q32 = (nt & OZ_TAG_F32) != 0;
+    const double Q = t.edge_Q[e];
+    uint32_t tag = 0;
+    double q;
+    if (t.qmode == OZ_QMODE_F64 || (!q32 && vt != VT_F32)) {
+        q = ((double)N * Q + val) / (double)(N + 1);                 // MCTS/__init__.py:68 in float64
+    } else {                                                          // NumPy >= 2 weak-scalar promotion
+        const float prod = q32 ? (float)N * (float)Q : (float)((double)N * Q);
+        const float s = prod + (float)val;
+        q = (double)(s / (float)(N + 1));
+        tag = OZ_TAG_F32;
+    }
+    t.edge_Q[e] = q;
+    t.edge_N[e] = (uint32_t)(N + 1) | tag;
+}
+
+// slot_is_game != 0: pi / v are indexed by game (host evaluator path); else by compacted slot.
+__global__ __launch_bounds__(64) void k_expand_backup(MctsDev t, int slot_is_game) {
+    __shared__ double arr[64];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int status = t.leaf_status[g];
+    if (status == OZ_LEAF_IDLE) return;
+    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    double value;
+    int vt;
+    if (status == OZ_LEAF_EVAL) {
+        // first visit (MCTS/__init__.py:44-57): P = pi * mask, normalised; uniform over legal if the sum is 0
+        const uint64_t own = t.leaf_own[g], opp = t.leaf_opp[g], legal = t.leaf_legal[g];
+        const int slot = slot_is_game ? g : t.leaf_slot[g];
+        const int r = lane >> 3, c = lane & 7, n = t.n;
+        const bool inb = r < n && c < n, is_legal = (legal >> lane) & 1;
+        const int a = r * n + c;
+        double p = is_legal ? (double)t.pi[(size_t)slot * t.n2 + a] : 0.0;     // float32 * float64 mask
+        if (inb) arr[a] = p;
+        __syncthreads();
+        const double sum = pairwise_sum(arr, t.n2);
+        const int cnt = oz_popc(legal);
+        if (sum > 0) p = p / sum;
+        else p = is_legal ? 1.0 / (double)cnt : 0.0;                           // mask / np.sum(mask)
+        const int node = t.node_count[g], ebase = t.edge_count[g];
+        const bool ok = node < t.node_cap && ebase + cnt <= t.edge_cap;
+        if (ok) {
+            int fs;
+            ht_find(t.ht + (size_t)g * t.ht_cap, t.ht_cap, t.node_own + nb, t.node_opp + nb, own, opp, lane, &fs);
+            if (is_legal) {
+                const size_t e = eb + ebase + oz_popc(legal & ((1ULL << lane) - 1ULL));
+                t.edge_N[e] = 0; t.edge_Q[e] = 0.0; t.edge_P[e] = p;
+            }
+            if (lane == 0) {
+                t.node_own[nb + node] = own; t.node_opp[nb + node] = opp; t.node_legal[nb + node] = legal;
+                t.node_Ns[nb + node] = 0; t.node_ebase[nb + node] = ebase;
+                t.node_count[g] = node + 1; t.edge_count[g] = ebase + cnt;
+                t.ht[(size_t)g * t.ht_cap + fs] = node;
+            }
+        }
+        if (lane == 0) {
+            unsigned long long* st = t.stat + (size_t)g * OZ_NSTAT;
+            st[ST_EXPAND] += 1;
+            if (!(sum > 0)) st[ST_FALLBACK] += 1;
+            if (!ok) atomicOr(t.error_flag, node >= t.node_cap ? EF_NODES : EF_EDGES);
+        }
+        value = -(double)t.v[slot];                                            // return -v (:57)
+        vt = t.qmode == OZ_QMODE_F64 ? VT_F64 : VT_F32;
+    } else {
+        value = (double)t.term_value[g];
+        vt = VT_INT;
+    }
+    // backup (MCTS/__init__.py:68-71): the level-d caller sees the leaf value negated (depth-1-d) times
+    const int depth = t.depth[g];
+    if (lane < depth) {
+        const int2 pe = t.path[(size_t)g * OZ_MAX_DEPTH + lane];
+        const double val = ((depth - 1 - lane) & 1) ? -value : value;
+        q_update(t, eb + pe.y, val, vt);
+        t.node_Ns[nb + pe.x] += 1;
+    }
+    if (lane == 0) {
+        t.last_value[g] = (depth & 1) ? -value : value;
+        t.last_vtype[g] = vt;
+    }
+}
+
+// ---------------------------------------------------------------- host object
+struct oz_mcts {
+    MctsDev d;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    std::mutex mu;
+    bool selected = false;
+    std::vector<void*> allocs;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double eval_ms = 0; long long eval_launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+
+    template <typename T> int alloc(T** p, size_t count) {
+        OZ_HIP(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+        allocs.push_back(*p);
+        return OZ_OK;
+    }
+};
+
+static int next_pow2(int x) { int p = 64; while (p < x) p <<= 1; return p; }
+
+static int mcts_reset_locked(oz_mcts* m, int game) {
+    MctsDev& d = m->d;
+    if (game < 0) {
+        OZ_HIP(hipMemsetAsync(d.node_count, 0, sizeof(int) * d.G, m->stream));
+        OZ_HIP(hipMemsetAsync(d.edge_count, 0, sizeof(int) * d.G, m->stream));
+        OZ_HIP(hipMemsetAsync(d.ht, 0xFF, sizeof(int) * (size_t)d.G * d.ht_cap, m->stream));
+    } else {
+        OZ_REQUIRE(game < d.G, "game index %d out of range", game);
+        OZ_HIP(hipMemsetAsync(d.node_count + game, 0, sizeof(int), m->stream));
+        OZ_HIP(hipMemsetAsync(d.edge_count + game, 0, sizeof(int), m->stream));
+        OZ_HIP(hipMemsetAsync(d.ht + (size_t)game * d.ht_cap, 0xFF, sizeof(int) * (size_t)d.ht_cap, m->stream));
+    }
+    return OZ_OK;
+}
+
+static int mcts_create(oz_mcts** out, int n, int G, int node_cap, int edge_cap, double c, int q_mode) {
+    OZ_REQUIRE(n == 4 || n == 6 || n == 8, "board size must be 4, 6 or 8 (got %d)", n);
+    OZ_REQUIRE(G > 0 && node_cap > 0 && edge_cap > 0, "num_games, node_cap and edge_cap must be positive");
+    OZ_REQUIRE(q_mode == OZ_QMODE_NEP50 || q_mode == OZ_QMODE_F64, "unknown q_mode %d", q_mode);
+    oz_mcts* m = new oz_mcts();
+    m->device = oz_current_device();
+    MctsDev& d = m->d;
+    memset(&d, 0, sizeof d);
+    d.G = G; d.n = n; d.n2 = n * n; d.node_cap = node_cap; d.edge_cap = edge_cap;
+    d.ht_cap = next_pow2(2 * node_cap);
+    d.valid = oz_valid_mask(n); d.c = c; d.qmode = q_mode;
+    const size_t GN = (size_t)G * node_cap, GE = (size_t)G * edge_cap;
+    int rc = OZ_OK;
+#define A(ptr, cnt) if (!rc) rc = m->alloc(&d.ptr, cnt)
+    A(node_own, GN); A(node_opp, GN); A(node_legal, GN); A(node_Ns, GN); A(node_ebase, GN);
+    A(node_count, G); A(edge_count, G);
+    A(edge_N, GE); A(edge_Q, GE); A(edge_P, GE);
+    A(ht, (size_t)G * d.ht_cap);
+    A(root_own, G); A(root_opp, G); A(active, G);
+    A(leaf_status, G); A(leaf_own, G); A(leaf_opp, G); A(leaf_legal, G);
+    A(depth, G); A(term_value, G); A(leaf_slot, G); A(path, (size_t)G * OZ_MAX_DEPTH);
+    A(batch_own, G); A(batch_opp, G); A(batch_count, 1);
+    A(pi, (size_t)G * d.n2); A(v, G);
+    A(last_value, G); A(last_vtype, G);
+    A(stat, (size_t)G * OZ_NSTAT); A(error_flag, 1);
+#undef A
+    if (!rc && hipStreamCreate(&m->stream) != hipSuccess) { oz_set_error("hipStreamCreate failed"); rc = OZ_ERR_HIP; }
+    if (!rc) {
+        hipMemsetAsync(d.stat, 0, sizeof(unsigned long long) * (size_t)G * OZ_NSTAT, m->stream);
+        hipMemsetAsync(d.error_flag, 0, sizeof(int), m->stream);
+        hipMemsetAsync(d.active, 0, G, m->stream);
+        hipMemsetAsync(d.leaf_status, 0, sizeof(int) * G, m->stream);
+        hipMemsetAsync(d.batch_count, 0, sizeof(int), m->stream);
+        hipMemsetAsync(d.last_value, 0, sizeof(double) * G, m->stream);
+        hipMemsetAsync(d.last_vtype, 0, sizeof(int) * G, m->stream);
+        hipMemsetAsync(d.depth, 0, sizeof(int) * G, m->stream);
+        rc = mcts_reset_locked(m, -1);
+        if (!rc && hipStreamSynchronize(m->stream) != hipSuccess) { oz_set_error("stream sync failed"); rc = OZ_ERR_HIP; }
+    }
+    if (rc) {
+        for (void* p : m->allocs) hipFree(p);
+        if (m->stream) hipStreamDestroy(m->stream);
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return OZ_OK;
+}
+
+static void mcts_destroy(oz_mcts* m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    hipStreamSynchronize(m->stream);
+    for (auto& pr : m->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (void* p : m->allocs) hipFree(p);
+    hipStreamDestroy(m->stream);
+    delete m;
+}
+
+static int check_error_flag(oz_mcts* m) {
+    int ef = 0;
+    OZ_HIP(hipMemcpyAsync(&ef, m->d.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    OZ_HIP(hipStreamSynchronize(m->stream));
+    if (ef & (EF_NODES | EF_EDGES)) {
+        oz_set_error("per-game %s table overflow (node_cap=%d edge_cap=%d): raise the capacity",
+                     (ef & EF_NODES) ? "node" : "edge", m->d.node_cap, m->d.edge_cap);
+        return OZ_ERR_CAPACITY;
+    }
+    if (ef & EF_RECORDS) { oz_set_error("move-record buffer overflow: raise record_cap or drain records more often"); return OZ_ERR_CAPACITY; }
+    if (ef & EF_DEPTH) { oz_set_error("search path deeper than %d", OZ_MAX_DEPTH); return OZ_ERR_CAPACITY; }
+    if (ef & EF_NOMOVE) { oz_set_error("a revisited state has no legal action (the reference raises ValueError: max() arg is an empty sequence)"); return OZ_ERR_STATE; }
+    if (ef & EF_ROOT) { oz_set_error("root state missing from the search table after the simulations"); return OZ_ERR_KEY; }
+    return OZ_OK;
+}
+
+// one lock-step simulation for every active game, leaves evaluated by `net` (all on m->stream)
+static int mcts_step_async(oz_mcts* m, oz_net* net, bool time_eval) {
+    MctsDev& d = m->d;
+    hipLaunchKernelGGL(k_select, dim3(d.G), dim3(64), 0, m->stream, d);
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, m->stream, d);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (time_eval) {
+        OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1));
+        OZ_HIP(hipEventRecord(e0, m->stream));
+    }
+    if (int rc = oz_net_forward_device(net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, m->stream)) return rc;
+    if (time_eval) {
+        OZ_HIP(hipEventRecord(e1, m->stream));
+        m->pending.push_back({e0, e1});
+    }
+    hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, m->stream, d, 0);
+    OZ_HIP(hipGetLastError());
+    return OZ_OK;
+}
+
+static int mcts_collect_eval_time(oz_mcts* m) {
+    for (auto& pr : m->pending) {
+        float ms = 0;
+        OZ_HIP(hipEventSynchronize(pr.second));
+        OZ_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        m->eval_ms += ms; m->eval_launches += 1;
+        hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+    }
+    m->pending.clear();
+    return OZ_OK;
+}
+
+OZ_API int oz_mcts_create(oz_mcts** out, int n, int num_games, int node_cap, int edge_cap, double c, int q_mode) {
+    OZ_REQUIRE(out, "null out pointer");
+    return mcts_create(out, n, num_games, node_cap, edge_cap, c, q_mode);
+}
+OZ_API int oz_mcts_destroy(oz_mcts* m) { mcts_destroy(m); return OZ_OK; }
+
+OZ_API int oz_mcts_reset(oz_mcts* m, int game) {
+    OZ_REQUIRE(m, "null mcts");
+    std::lock_guard<std::mutex> lk(m->mu);
+    hipSetDevice(m->device);
+    if (int rc = mcts_reset_locked(m, game)) return rc;
+    OZ_HIP(hipStreamSynchronize(m->stream));
+    m->selected = false;
+    return OZ_OK;
+}
+
+OZ_API int oz_mcts_set_roots(oz_mcts* m, const uint64_t* own, const uint64_t* opp, const uint8_t* active) {
+    OZ_REQUIRE(m && own && opp, "null argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    hipSetDevice(m->device);
+    const int G = m->d.G;
+    for (int i = 0; i < G; ++i)
+        OZ_REQUIRE((own[i] & opp[i]) == 0 && ((own[i] | opp[i]) & ~m->d.valid) == 0, "root %d is not a valid %dx%d board", i, m->d.n, m->d.n);
+    OZ_HIP(hipMemcpyAsync(m->d.root_own, own, 8ull * G, hipMemcpyHostToDevice, m->stream));
+    OZ_HIP(hipMemcpyAsync(m->d.root_opp, opp, 8ull * G, hipMemcpyHostToDevice, m->stream));
+    if (active) OZ_HIP(hipMemcpyAsync(m->d.active, active, G, hipMemcpyHostToDevice, m->stream));
+    else OZ_HIP(hipMemsetAsync(m->d.active, 1, G, m->stream));
+    OZ_HIP(hipStreamSynchronize(m->stream));
+    m->selected = false;
+    return OZ_OK;
+}
+
+OZ_API int oz_mcts_simulate(oz_mcts* m, oz_net* net, int nsims) {
+    OZ_REQUIRE(m && net, "null argument");
+    OZ_REQUIRE(net->n == m->d.n, "network board size %d != search board size %d", net->n, m->d.n);
+    OZ_REQUIRE(net->max_batch >= m->d.G, "network max_batch %d < num_games %d", net->max_batch, m->d.G);
+    std::lock_guard<std::mutex> lk(m->mu);
+    std::lock_guard<std::mutex> lkn(net->mu);
+    hipSetDevice(m->device);
+    for (int s = 0; s < nsims; ++s)
+        if (int rc = mcts_step_async(m, net, false)) return rc;
+    m->selected = false;
+    return check_error_flag(m);
+}
+
+OZ_API int oz_mcts_select(oz_mcts* m) {
+    OZ_REQUIRE(m, "null mcts");
+    std::lock_guard<std::mutex> lk(m->mu);
+    hipSetDevice(m->device);
+    hipLaunchKernelGGL(k_select, dim3(m->d.G), dim3(64), 0, m->stream, m->d);
+    OZ_HIP(hipGetLastError());
+    m->selected = true;
+    return check_error_flag(m);
+}
+
+OZ_API int oz_mcts_leaves(oz_mcts* m, int32_t* status, uint64_t* own, uint64_t* opp) {
+    OZ_REQUIRE(m && status && own && opp, "null argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    OZ_REQUIRE(m->selected, "oz_mcts_leaves: call oz_mcts_select first");
+    hipSetDevice(m->device);
+    const int G = m->d.G;
+    OZ_HIP(hipMemcpyAsync(status, m->d.leaf_status, 4ull * G, hipMemcpyDeviceToHost, m->stream));
+    OZ_HIP(hipMemcpyAsync(own, m->d.leaf_own, 8ull * G, hipMemcpyDeviceToHost, m->stream));
+    OZ_HIP(hipMemcpyAsync(opp, m->d.leaf_opp, 8ull * G, hipMemcpyDeviceToHost, m->stream));
+    OZ_HIP(hipStreamSynchronize(m->stream));
+    return OZ_OK;
+}
+
+OZ_API int oz_mcts_backup(oz_mcts* m, const float* pi, const float* v) {
+    OZ_REQUIRE(m && pi && v, "null argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (!m->selected) { oz_set_error("oz_mcts_backup: call oz_mcts_select first"); return OZ_ERR_STATE; }
+    hipSetDevice(m->device);
+    const int G = m->d.G;
+    OZ_HIP(hipMemcpyAsync(m->d.pi, pi, 4ull * G * m->d.n2, hipMemcpyHostToDevice, m->stream));
+    OZ_HIP(hipMemcpyAsync(m->d.v, v, 4ull * G, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_expand_backup, dim3(G), dim3(64), 0, m->stream, m->d, 1);
+    OZ_HIP(hipGetLastError());
+    m->selected = false;
+    return check_error_flag(m);
+}
+
+OZ_API int oz_mcts_last_value(oz_mcts* m, double* value, int32_t* vtype, int32_t* depth) {
+    OZ_REQUIRE(m, "null mcts");
+    std::lock_guard<std::mutex> lk(m->mu);
+    hipSetDevice(m->device);
+    const int G = m->d.G;
+    if (value) OZ_HIP(hipMemcpyAsync(value, m->d.last_value, 8ull * G, hipMemcpyDeviceToHost, m->stream));
+    if (vtype) OZ_HIP(hipMemcpyAsync(vtype, m->d.last_vtype, 4ull * G, hipMemcpyDeviceToHost, m->stream));
+    if (depth) OZ_HIP(hipMemcpyAsync(depth, m->d.depth, 4ull * G, hipMemcpyDeviceToHost, m->stream));
+    OZ_HIP(hipStreamSynchronize(m->stream));
+    return OZ_OK;
+}
+
+// N(state, action) for the root of every slot (MCTS/__init__.py:73-84,172-175)
+__global__ __launch_bounds__(64) void k_root_counts(MctsDev t, int32_t* counts, uint64_t* legal_out, int32_t* rc_out) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const uint64_t own = t.root_own[g], opp = t.root_opp[g];
+    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    const uint64_t legal = oz_legal(own, opp, t.valid);
+    int fs;
+    const int node = ht_find(t.ht + (size_t)g * t.ht_cap, t.ht_cap, t.node_own + nb, t.node_opp + nb, own, opp, lane, &fs);
+    int cnt = 0, rc = 0;
+    if (node < 0) rc = 1;
+    else if (t.node_Ns[nb + node] == 0) rc = 2;          // _Nsa[hash] still empty -> KeyError in the reference
+    else if ((legal >> lane) & 1)
+        cnt = (int)(t.edge_N[eb + t.node_ebase[nb + node] + oz_popc(legal & ((1ULL << lane) - 1ULL))] & ~OZ_TAG_F32);
+    counts[(size_t)g * 64 + lane] = cnt;
+    if (lane == 0) { legal_out[g] = legal; rc_out[g] = rc; }
+}
+
+OZ_API int oz_mcts_root_counts(oz_mcts* m, int32_t* counts, uint64_t* legal, int32_t* rc) {
+    OZ_REQUIRE(m && counts && legal && rc, "null argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    hipSetDevice(m->device);
+    const int G = m->d.G;
+    int32_t* dc; uint64_t* dl; int32_t* dr;
+    OZ_HIP(hipMalloc((void**)&dc, 4ull * G * 64)); OZ_HIP(hipMalloc((void**)&dl, 8ull * G)); OZ_HIP(hipMalloc((void**)&dr, 4ull * G));
+    hipLaunchKernelGGL(k_root_counts, dim3(G), dim3(64), 0, m->stream, m->d, dc, dl, dr);
+    hipMemcpyAsync(counts, dc, 4ull * G * 64, hipMemcpyDeviceToHost, m->stream);
+    hipMemcpyAsync(legal, dl, 8ull * G, hipMemcpyDeviceToHost, m->stream);
+    hipMemcpyAsync(rc, dr, 4ull * G, hipMemcpyDeviceToHost, m->stream);
+    hipError_t e = hipStreamSynchronize(m->stream);
+    hipFree(dc); hipFree(dl); hipFree(dr);
+    OZ_HIP(e);
+    return OZ_OK;
+}
+
+OZ_API int oz_mcts_num_nodes(oz_mcts* m, int32_t* num_nodes) {
+    OZ_REQUIRE(m && num_nodes, "null argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    hipSetDevice(m->device);
+    OZ_HIP(hipMemcpyAsync(num_nodes, m->d.node_count, 4ull * m->d.G, hipMemcpyDeviceToHost, m->stream));
+    OZ_HIP(hipStreamSynchronize(m->stream));
+    return OZ_OK;
+}
+
+OZ_API int oz_mcts_dump_node(oz_mcts* m, int game, int index, uint64_t* own, uint64_t* opp, int32_t* Ns, uint64_t* legal,
+                             int32_t* N, double* Q, uint8_t* qtag, double* P) {
+    OZ_REQUIRE(m, "null mcts");
+    std::lock_guard<std::mutex> lk(m->mu);
+    hipSetDevice(m->device);
+    MctsDev& d = m->d;
+    OZ_REQUIRE(game >= 0 && game < d.G, "game index out of range");
+    OZ_HIP(hipStreamSynchronize(m->stream));
+    int nn = 0;
+    OZ_HIP(hipMemcpy(&nn, d.node_count + game, 4, hipMemcpyDeviceToHost));
+    OZ_REQUIRE(index >= 0 && index < nn, "node index %d out of range (%d nodes)", index, nn);
+    const size_t ni = (size_t)game * d.node_cap + index;
+    int ebase = 0;
+    OZ_HIP(hipMemcpy(own, d.node_own + ni, 8, hipMemcpyDeviceToHost));
+    OZ_HIP(hipMemcpy(opp, d.node_opp + ni, 8, hipMemcpyDeviceToHost));
+    OZ_HIP(hipMemcpy(legal, d.node_legal + ni, 8, hipMemcpyDeviceToHost));
+    OZ_HIP(hipMemcpy(Ns, d.node_Ns + ni, 4, hipMemcpyDeviceToHost));
+    OZ_HIP(hipMemcpy(&ebase, d.node_ebase + ni, 4, hipMemcpyDeviceToHost));
+    const int cnt = __builtin_popcountll(*legal);
+    uint32_t nt[64]; double q[64], p[64];
+    const size_t e0 = (size_t)game * d.edge_cap + ebase;
+    OZ_HIP(hipMemcpy(nt, d.edge_N + e0, 4ull * cnt, hipMemcpyDeviceToHost));
+    OZ_HIP(hipMemcpy(q, d.edge_Q + e0, 8ull * cnt, hipMemcpyDeviceToHost));
+    OZ_HIP(hipMemcpy(p, d.edge_P + e0, 8ull * cnt, hipMemcpyDeviceToHost));
+    for (int s = 0; s < 64; ++s) { N[s] = 0; Q[s] = 0; qtag[s] = 0; P[s] = 0; }
+    int k = 0;
+    for (int s = 0; s < 64; ++s)
+        if ((*legal >> s) & 1) { N[s] = (int)(nt[k] & ~OZ_TAG_F32); qtag[s] = (nt[k] & OZ_TAG_F32) ? 1 : 0; Q[s] = q[k]; P[s] = p[k]; ++k; }
+    return OZ_OK;
+}
+
+static int mcts_stats_locked(oz_mcts* m, int64_t* out5) {
+    const size_t cnt = (size_t)m->d.G * OZ_NSTAT;
+    std::vector<unsigned long long> h(cnt);
+    OZ_HIP(hipMemcpyAsync(h.data(), m->d.stat, 8 * cnt, hipMemcpyDeviceToHost, m->stream));
+    OZ_HIP(hipStreamSynchronize(m->stream));
+    for (int k = 0; k < OZ_NSTAT; ++k) out5[k] = 0;
+    for (size_t i = 0; i < cnt; ++i) out5[i % OZ_NSTAT] += (int64_t)h[i];
+    return OZ_OK;
+}
+OZ_API int oz_mcts_stats(oz_mcts* m, int64_t* out5) {
+    OZ_REQUIRE(m && out5, "null argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    hipSetDevice(m->device);
+    return mcts_stats_locked(m, out5);
+}
+
+// ================================================================ self-play driver
+struct GamesDev {
+    int G, n;
+    uint64_t valid;
+    uint64_t *black, *white, *game_id;
+    int8_t* player;
+    uint8_t* finished;
+    int* ply;
+    // per-slot move log of the game in progress
+    uint64_t *log_black, *log_white;      // [G][64]
+    uint8_t *log_action, *log_greedy;     // [G][64]
+    int8_t* log_player;                   // [G][64]
+    int32_t* last_counts;                 // [G][64]
+    oz_record* records;
+    unsigned long long* counters;         // [0] records [1] games completed [2] moves
+    long long record_cap;
+    uint64_t seed, id_stride;
+    double temperature, e_greedy;
+    int refill, init_black_set;
+    uint64_t init_black, init_white;
+};
+
+__global__ void k_sp_roots(GamesDev gm, MctsDev t, int mover_filter /* 0 all, +1 / -1: only games with that mover */) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= gm.G) return;
+    const int p = gm.player[g];
+    const bool act = !gm.finished[g] && (mover_filter == 0 || mover_filter == p);
+    t.active[g] = act ? 1 : 0;
+    if (act) {
+        t.root_own[g] = p == 1 ? gm.black[g] : gm.white[g];
+        t.root_opp[g] = p == 1 ? gm.white[g] : gm.black[g];
+    }
+}
+
+// K7: root policy extraction + action choice + OthelloGame.play + example recording
+// (othelo_mcts.py:51-67, training.py:45-67 / agents.py:52-68).  One wave per game.
+//   arena != 0: agents.py semantics (temperature 0, argmax over valid actions of the one-hot).
+__global__ __launch_bounds__(64) void k_sp_move(GamesDev gm, MctsDev t, int arena) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!t.active[g]) return;
+    const uint64_t own = t.root_own[g], opp = t.root_opp[g];
+    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    const uint64_t legal = oz_legal(own, opp, t.valid);
+    int fs;
+    const int node = ht_find(t.ht + (size_t)g * t.ht_cap, t.ht_cap, t.node_own + nb, t.node_opp + nb, own, opp, lane, &fs);
+    if (node < 0 || t.node_Ns[nb + node] == 0) {          // KeyError path of the reference (sims < 2)
+        if (lane == 0) atomicOr(t.error_flag, EF_ROOT);
+        return;
+    }
+    const bool is_legal = (legal >> lane) & 1;
+    int cnt = 0;
+    if (is_legal) cnt = (int)(t.edge_N[eb + t.node_ebase[nb + node] + oz_popc(legal & ((1ULL << lane) - 1ULL))] & ~OZ_TAG_F32);
+    gm.last_counts[(size_t)g * 64 + lane] = cnt;
+    const int ply = gm.ply[g];
+    const uint64_t gid = gm.game_id[g];
+    const int mx = wave_max_i32(cnt);                      // >= 1 once the root has been selected from
+    int action, greedy = 1;
+    if (arena || gm.temperature == 0.0) {
+        // bests = argwhere(p == p.max()) over the whole board; random.choice(bests) -> RNG_TIE stream
+        const uint64_t bests = __ballot(is_legal && cnt == mx);
+        const int nbests = oz_popc(bests);
+        action = oz_kth_bit(bests, (int)(oz_rng(gm.seed, gid, (uint64_t)ply, OZ_RNG_TIE) % (uint64_t)nbests));
+    } else {
+        // N**(1/T) / sum is monotone in N: argwhere(policy == policy.max())[0] = first max-visit square
+        action = oz_ctz(__ballot(is_legal && cnt == mx));
+    }
+    if (!arena) {
+        const double coin = oz_rng_unit(oz_rng(gm.seed, gid, (uint64_t)ply, OZ_RNG_COIN));
+        if (!(coin <= gm.e_greedy)) {                      // training.py:53-56
+            greedy = 0;
+            action = oz_kth_bit(legal, (int)(oz_rng(gm.seed, gid, (uint64_t)ply, OZ_RNG_EXPLORE) % (uint64_t)oz_popc(legal)));
+        }
+    }
+    uint64_t black = gm.black[g], white = gm.white[g];
+    int player = gm.player[g], fin = 0;
+    const size_t lb = (size_t)g * 64;
+    if (lane == 0 && ply < 64) {
+        gm.log_black[lb + ply] = black; gm.log_white[lb + ply] = white;
+        gm.log_action[lb + ply] = (uint8_t)action; gm.log_player[lb + ply] = (int8_t)player;
+        gm.log_greedy[lb + ply] = (uint8_t)greedy;
+    }
+    oz_game_play(black, white, player, fin, action, gm.valid);
+    const int nply = ply + 1;
+    if (fin) {
+        // get_winning_player: draw -> BLACK; z = +1 if winner == mover else -1 (training.py:69-72)
+        const int winner = oz_popc(black) >= oz_popc(white) ? 1 : -1;
+        unsigned long long base = 0;
+        if (lane == 0) {
+            base = atomicAdd(&gm.counters[0], (unsigned long long)nply);
+            atomicAdd(&gm.counters[1], 1ULL);
+        }
+        base = __shfl(base, 0, 64);
+        if (lane < nply) {                                 // lane i writes the record of ply i
+            if ((long long)(base + lane) < gm.record_cap) {
+                oz_record r;
+                const bool cur = lane == ply;              // this ply's log entry is still in registers
+                r.black = cur ? gm.black[g] : gm.log_black[lb + lane];
+                r.white = cur ? gm.white[g] : gm.log_white[lb + lane];
+                r.final_black = black; r.final_white = white; r.game_id = gid;
+                r.ply = (uint8_t)lane; r.action = cur ? (uint8_t)action : gm.log_action[lb + lane];
+                r.player = cur ? gm.player[g] : gm.log_player[lb + lane];
+                r.z = (int8_t)(winner == r.player ? 1 : -1);
+                r.greedy = cur ? (uint8_t)greedy : gm.log_greedy[lb + lane];
+                r.pad[0] = r.pad[1] = r.pad[2] = 0;
+                gm.records[base + lane] = r;
+            } else atomicOr(t.error_flag, EF_RECORDS);
+        }
+    }
+    if (lane == 0) atomicAdd(&gm.counters[2], 1ULL);
+    if (fin && gm.refill) {
+        // a fresh OthelloGame + a fresh OthelloMCTS in the same slot (training.py:30-32)
+        for (int i = lane; i < t.ht_cap; i += 64) t.ht[(size_t)g * t.ht_cap + i] = -1;
+        if (lane == 0) {
+            t.node_count[g] = 0; t.edge_count[g] = 0;
+            gm.black[g] = gm.init_black; gm.white[g] = gm.init_white; gm.player[g] = 1;
+            gm.finished[g] = 0; gm.ply[g] = 0; gm.game_id[g] = gid + gm.id_stride;
+        }
+    } else if (lane == 0) {
+        gm.black[g] = black; gm.white[g] = white; gm.player[g] = (int8_t)player;
+        gm.finished[g] = (uint8_t)fin; gm.ply[g] = nply;
+    }
+}
+
+static void initial_board(int n, uint64_t* black, uint64_t* white) {     // Othello/__init__.py:177-184
+    const int h = n / 2;
+    *white = (1ULL << ((h - 1) * 8 + h - 1)) | (1ULL << (h * 8 + h));
+    *black = (1ULL << ((h - 1) * 8 + h)) | (1ULL << (h * 8 + h - 1));
+}
+
+struct oz_selfplay {
+    oz_selfplay_config cfg;
+    oz_mcts* m = nullptr;
+    oz_net* net = nullptr;
+    GamesDev gm;
+    std::vector<void*> allocs;
+    std::mutex mu;
+    long long records_read = 0;
+    template <typename T> int alloc(T** p, size_t count) {
+        OZ_HIP(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+        allocs.push_back(*p);
+        return OZ_OK;
+    }
+};
+
+static int games_alloc(oz_selfplay* sp, int G, int n, long long record_cap) {
+    GamesDev& gm = sp->gm;
+    memset(&gm, 0, sizeof gm);
+    gm.G = G; gm.n = n; gm.valid = oz_valid_mask(n); gm.record_cap = record_cap;
+    int rc = OZ_OK;
+#define A(ptr, cnt) if (!rc) rc = sp->alloc(&gm.ptr, cnt)
+    A(black, G); A(white, G); A(game_id, G); A(player, G); A(finished, G); A(ply, G);
+    A(log_black, (size_t)G * 64); A(log_white, (size_t)G * 64); A(log_action, (size_t)G * 64);
+    A(log_greedy, (size_t)G * 64); A(log_player, (size_t)G * 64); A(last_counts, (size_t)G * 64);
+    A(records, (size_t)record_cap); A(counters, 4);
+#undef A
+    return rc;
+}
+
+static int games_init(oz_selfplay* sp, uint64_t first_id, hipStream_t s) {
+    GamesDev& gm = sp->gm;
+    const int G = gm.G;
+    uint64_t b, w;
+    initial_board(gm.n, &b, &w);
+    gm.init_black = b; gm.init_white = w;
+    std::vector<uint64_t> hb(G, b), hw(G, w), ids(G);
+    for (int i = 0; i < G; ++i) ids[i] = first_id + (uint64_t)i;
+    std::vector<int8_t> pl(G, 1);
+    OZ_HIP(hipMemcpyAsync(gm.black, hb.data(), 8ull * G, hipMemcpyHostToDevice, s));
+    OZ_HIP(hipMemcpyAsync(gm.white, hw.data(), 8ull * G, hipMemcpyHostToDevice, s));
+    OZ_HIP(hipMemcpyAsync(gm.game_id, ids.data(), 8ull * G, hipMemcpyHostToDevice, s));
+    OZ_HIP(hipMemcpyAsync(gm.player, pl.data(), G, hipMemcpyHostToDevice, s));
+    OZ_HIP(hipMemsetAsync(gm.finished, 0, G, s));
+    OZ_HIP(hipMemsetAsync(gm.ply, 0, 4ull * G, s));
+    OZ_HIP(hipMemsetAsync(gm.counters, 0, 8 * 4, s));
+    OZ_HIP(hipMemsetAsync(gm.last_counts, 0, 4ull * G * 64, s));
+    OZ_HIP(hipStreamSynchronize(s));
+    return OZ_OK;
+}
+
+OZ_API int oz_selfplay_create(oz_selfplay** out, const oz_selfplay_config* cfg, oz_net* net) {
+    OZ_REQUIRE(out && cfg && net, "null argument");
+    OZ_REQUIRE(cfg->sims >= 2, "num_simulations must be >= 2 (with 1 the reference raises KeyError at othelo_mcts.py:66)");
+    OZ_REQUIRE(cfg->num_games > 0, "num_games must be positive");
+    OZ_REQUIRE(net->n == cfg->n, "network board size %d != %d", net->n, cfg->n);
+    OZ_REQUIRE(net->max_batch >= cfg->num_games, "network max_batch %d < num_games %d", net->max_batch, cfg->num_games);
+    oz_selfplay* sp = new oz_selfplay();
+    sp->cfg = *cfg; sp->net = net;
+    const int max_plies = cfg->n * cfg->n - 4;
+    const int node_cap = cfg->node_cap > 0 ? cfg->node_cap : cfg->sims * (max_plies + 1) + 64;
+    const int edge_cap = cfg->edge_cap > 0 ? cfg->edge_cap : node_cap * 14;
+    const long long rcap = cfg->record_cap > 0 ? cfg->record_cap : (long long)cfg->num_games * 64 * 4;
+    int rc = mcts_create(&sp->m, cfg->n, cfg->num_games, node_cap, edge_cap, cfg->c, cfg->q_mode);
+    if (!rc) rc = games_alloc(sp, cfg->num_games, cfg->n, rcap);
+    if (!rc) {
+        sp->gm.seed = cfg->seed; sp->gm.id_stride = cfg->game_id_stride ? cfg->game_id_stride : (uint64_t)cfg->num_games;
+        sp->gm.temperature = cfg->temperature; sp->gm.e_greedy = cfg->e_greedy; sp->gm.refill = cfg->refill;
+        rc = games_init(sp, cfg->first_game_id, sp->m->stream);
+    }
+    if (rc) {
+        for (void* p : sp->allocs) hipFree(p);
+        mcts_destroy(sp->m);
+        delete sp;
+        return rc;
+    }
+    *out = sp;
+    return OZ_OK;
+}
+
+OZ_API int oz_selfplay_destroy(oz_selfplay* sp) {
+    if (!sp) return OZ_OK;
+    hipSetDevice(sp->m->device);
+    hipStreamSynchronize(sp->m->stream);
+    for (void* p : sp->allocs) hipFree(p);
+    mcts_destroy(sp->m);
+    delete sp;
+    return OZ_OK;
+}
+
+OZ_API int oz_selfplay_run(oz_selfplay* sp, int rounds) {
+    OZ_REQUIRE(sp, "null selfplay");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    std::lock_guard<std::mutex> lkn(sp->net->mu);
+    oz_mcts* m = sp->m;
+    hipSetDevice(m->device);
+    const int G = sp->gm.G;
+    for (int r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, m->stream, sp->gm, m->d, 0);
+        for (int s = 0; s < sp->cfg.sims; ++s)
+            if (int rc = mcts_step_async(m, sp->net, true)) return rc;
+        hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, m->stream, sp->gm, m->d, 0);
+        OZ_HIP(hipGetLastError());
+        if (m->pending.size() > 4096) { if (int rc = mcts_collect_eval_time(m)) return rc; }
+    }
+    return OZ_OK;
+}
+
+OZ_API int oz_selfplay_sync(oz_selfplay* sp) {
+    OZ_REQUIRE(sp, "null selfplay");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    hipSetDevice(sp->m->device);
+    if (int rc = check_error_flag(sp->m)) return rc;
+    return mcts_collect_eval_time(sp->m);
+}
+
+OZ_API int oz_selfplay_get_stats(oz_selfplay* sp, oz_selfplay_stats* out) {
+    OZ_REQUIRE(sp && out, "null argument");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    hipSetDevice(sp->m->device);
+    int64_t s5[OZ_NSTAT];
+    if (int rc = mcts_stats_locked(sp->m, s5)) return rc;
+    unsigned long long c[4];
+    OZ_HIP(hipMemcpy(c, sp->gm.counters, sizeof c, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> fin(sp->gm.G);
+    OZ_HIP(hipMemcpy(fin.data(), sp->gm.finished, sp->gm.G, hipMemcpyDeviceToHost));
+    int ef = 0;
+    OZ_HIP(hipMemcpy(&ef, sp->m->d.error_flag, 4, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->simulations = s5[ST_SIMS]; out->node_visits = s5[ST_VISITS]; out->expansions = s5[ST_EXPAND];
+    out->terminal_hits = s5[ST_TERMINAL]; out->fallbacks = s5[ST_FALLBACK];
+    out->records = (int64_t)c[0]; out->games_completed = (int64_t)c[1]; out->moves = (int64_t)c[2];
+    int live = 0;
+    for (uint8_t f : fin) live += f ? 0 : 1;
+    out->live_games = live; out->overflow = ef;
+    return OZ_OK;
+}
+
+OZ_API int oz_selfplay_state(oz_selfplay* sp, uint64_t* black, uint64_t* white, int8_t* player, uint8_t* finished,
+                             int32_t* ply, uint64_t* game_id) {
+    OZ_REQUIRE(sp, "null selfplay");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    hipSetDevice(sp->m->device);
+    OZ_HIP(hipStreamSynchronize(sp->m->stream));
+    const int G = sp->gm.G;
+    if (black) OZ_HIP(hipMemcpy(black, sp->gm.black, 8ull * G, hipMemcpyDeviceToHost));
+    if (white) OZ_HIP(hipMemcpy(white, sp->gm.white, 8ull * G, hipMemcpyDeviceToHost));
+    if (player) OZ_HIP(hipMemcpy(player, sp->gm.player, G, hipMemcpyDeviceToHost));
+    if (finished) OZ_HIP(hipMemcpy(finished, sp->gm.finished, G, hipMemcpyDeviceToHost));
+    if (ply) OZ_HIP(hipMemcpy(ply, sp->gm.ply, 4ull * G, hipMemcpyDeviceToHost));
+    if (game_id) OZ_HIP(hipMemcpy(game_id, sp->gm.game_id, 8ull * G, hipMemcpyDeviceToHost));
+    return OZ_OK;
+}
+
+static int selfplay_records(oz_selfplay* sp, void* dst, int64_t max_records, int64_t* written, hipMemcpyKind kind) {
+    OZ_REQUIRE(sp && written, "null argument");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    hipSetDevice(sp->m->device);
+    OZ_HIP(hipStreamSynchronize(sp->m->stream));
+    unsigned long long total = 0;
+    OZ_HIP(hipMemcpy(&total, sp->gm.counters, 8, hipMemcpyDeviceToHost));
+    long long n = (long long)total;
+    if (n > sp->gm.record_cap) n = sp->gm.record_cap;
+    if (n > max_records) n = max_records;
+    if (n > 0) {
+        OZ_REQUIRE(dst, "null destination");
+        OZ_HIP(hipMemcpy(dst, sp->gm.records, sizeof(oz_record) * (size_t)n, kind));
+    }
+    *written = n;
+    return OZ_OK;
+}
+OZ_API int oz_selfplay_records(oz_selfplay* sp, oz_record* out, int64_t max_records, int64_t* written) {
+    return selfplay_records(sp, out, max_records, written, hipMemcpyDeviceToHost);
+}
+OZ_API int oz_selfplay_records_device(oz_selfplay* sp, void* dst_device, int64_t max_records, int64_t* written) {
+    return selfplay_records(sp, dst_device, max_records, written, hipMemcpyDeviceToDevice);
+}
+
+OZ_API int oz_selfplay_last_counts(oz_selfplay* sp, int32_t* counts) {
+    OZ_REQUIRE(sp && counts, "null argument");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    hipSetDevice(sp->m->device);
+    OZ_HIP(hipStreamSynchronize(sp->m->stream));
+    OZ_HIP(hipMemcpy(counts, sp->gm.last_counts, 4ull * sp->gm.G * 64, hipMemcpyDeviceToHost));
+    return OZ_OK;
+}
+
+OZ_API int oz_selfplay_eval_time(oz_selfplay* sp, double* ms_total, int64_t* launches, int64_t* leaves) {
+    OZ_REQUIRE(sp, "null selfplay");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    hipSetDevice(sp->m->device);
+    if (int rc = mcts_collect_eval_time(sp->m)) return rc;
+    if (ms_total) *ms_total = sp->m->eval_ms;
+    if (launches) *launches = sp->m->eval_launches;
+    if (leaves) {
+        int64_t s5[OZ_NSTAT];
+        if (int rc = mcts_stats_locked(sp->m, s5)) return rc;
+        *leaves = s5[ST_EXPAND];
+    }
+    return OZ_OK;
+}
+
+// ================================================================ arena
+struct oz_arena {
+    oz_selfplay games;           // reuses the game-state arrays (games.m = agent A's search)
+    oz_mcts* mb = nullptr;       // agent B's search
+    oz_net *na = nullptr, *nb = nullptr;
+    int sims = 0;
+    std::mutex mu;
+    // full move lists (arena games are not refilled): [G][128]
+    uint8_t* d_actions = nullptr; int8_t* d_players = nullptr;
+    int* d_nmoves = nullptr;
+};
+
+// copies the slot's move log into the arena move list before k_sp_move overwrites nothing (log is per ply)
+__global__ void k_arena_collect(GamesDev gm, uint8_t* actions, int8_t* players, int* nmoves) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= gm.G) return;
+    const int k = gm.ply[g];
+    nmoves[g] = k;
+    for (int i = 0; i < k && i < 64; ++i) {
+        actions[(size_t)g * 128 + i] = gm.log_action[(size_t)g * 64 + i];
+        players[(size_t)g * 128 + i] = gm.log_player[(size_t)g * 64 + i];
+    }
+}
+
+OZ_API int oz_arena_create(oz_arena** out, int n, int num_games, int sims, double c, int q_mode, uint64_t seed,
+                           uint64_t first_game_id, oz_net* net_a, oz_net* net_b, int node_cap, int edge_cap) {
+    OZ_REQUIRE(out && net_a && net_b, "null argument");
+    OZ_REQUIRE(sims >= 2, "num_simulations must be >= 2");
+    OZ_REQUIRE(net_a->n == n && net_b->n == n, "network board size mismatch");
+    OZ_REQUIRE(net_a->max_batch >= num_games && net_b->max_batch >= num_games, "network max_batch < num_games");
+    oz_arena* a = new oz_arena();
+    a->na = net_a; a->nb = net_b; a->sims = sims;
+    const int max_plies = n * n - 4;
+    // each agent searches only on its own turns: about half the plies
+    const int ncap = node_cap > 0 ? node_cap : sims * (max_plies / 2 + 2) + 64;
+    const int ecap = edge_cap > 0 ? edge_cap : ncap * 14;
+    oz_selfplay* sp = &a->games;
+    memset(&sp->cfg, 0, sizeof sp->cfg);
+    sp->cfg.n = n; sp->cfg.num_games = num_games; sp->cfg.sims = sims; sp->cfg.c = c; sp->cfg.q_mode = q_mode; sp->cfg.seed = seed;
+    int rc = mcts_create(&sp->m, n, num_games, ncap, ecap, c, q_mode);
+    if (!rc) rc = mcts_create(&a->mb, n, num_games, ncap, ecap, c, q_mode);
+    if (!rc) rc = games_alloc(sp, num_games, n, (long long)num_games * 64);
+    if (!rc) {
+        sp->gm.seed = seed; sp->gm.id_stride = 0; sp->gm.temperature = 0; sp->gm.e_greedy = 1.0; sp->gm.refill = 0;
+        rc = games_init(sp, first_game_id, sp->m->stream);
+    }
+    if (!rc && hipMalloc((void**)&a->d_actions, (size_t)num_games * 128) != hipSuccess) rc = OZ_ERR_HIP;
+    if (!rc && hipMalloc((void**)&a->d_players, (size_t)num_games * 128) != hipSuccess) rc = OZ_ERR_HIP;
+    if (!rc && hipMalloc((void**)&a->d_nmoves, 4ull * num_games) != hipSuccess) rc = OZ_ERR_HIP;
+    if (rc) {
+        for (void* p : sp->allocs) hipFree(p);
+        mcts_destroy(sp->m); mcts_destroy(a->mb);
+        if (a->d_actions) hipFree(a->d_actions);
+        if (a->d_players) hipFree(a->d_players);
+        if (a->d_nmoves) hipFree(a->d_nmoves);
+        delete a;
+        if (rc == OZ_ERR_HIP) oz_set_error("arena allocation failed");
+        return rc;
+    }
+    *out = a;
+    return OZ_OK;
+}
+
+OZ_API int oz_arena_destroy(oz_arena* a) {
+    if (!a) return OZ_OK;
+    hipSetDevice(a->games.m->device);
+    hipStreamSynchronize(a->games.m->stream);
+    hipStreamSynchronize(a->mb->stream);
+    for (void* p : a->games.allocs) hipFree(p);
+    mcts_destroy(a->games.m); mcts_destroy(a->mb);
+    hipFree(a->d_actions); hipFree(a->d_players); hipFree(a->d_nmoves);
+    delete a;
+    return OZ_OK;
+}
+
+OZ_API int oz_arena_run(oz_arena* a) {
+    OZ_REQUIRE(a, "null arena");
+    std::lock_guard<std::mutex> lk(a->mu);
+    oz_selfplay* sp = &a->games;
+    oz_mcts *ma = sp->m, *mb = a->mb;
+    hipSetDevice(ma->device);
+    const int G = sp->gm.G;
+    hipStream_t s = ma->stream;          // both searches are driven on agent A's stream (they share game state)
+    hipStream_t sb_saved = mb->stream;
+    mb->stream = s;
+    int rc = OZ_OK;
+    const int max_rounds = sp->gm.n * sp->gm.n;      // every round plays one ply in every live game
+    std::vector<uint8_t> fin(G);
+    for (int round = 0; round < max_rounds && !rc; ++round) {
+        // BLACK movers search in agent A's tables with net A, WHITE movers in agent B's with net B
+        hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, ma->d, 1);
+        hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, mb->d, -1);
+        {
+            std::lock_guard<std::mutex> la(a->na->mu);
+            for (int i = 0; i < a->sims && !rc; ++i) rc = mcts_step_async(ma, a->na, false);
+        }
+        if (!rc) {
+            std::lock_guard<std::mutex> lb(a->nb->mu);
+            for (int i = 0; i < a->sims && !rc; ++i) rc = mcts_step_async(mb, a->nb, false);
+        }
+        if (rc) break;
+        hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, ma->d, 1);
+        hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, mb->d, 1);
+        if (hipGetLastError() != hipSuccess) { oz_set_error("arena kernel launch failed"); rc = OZ_ERR_HIP; break; }
+        if ((round & 3) == 3 || round + 1 == max_rounds) {
+            if ((rc = check_error_flag(ma))) break;
+            if ((rc = check_error_flag(mb))) break;
+            if (hipMemcpy(fin.data(), sp->gm.finished, G, hipMemcpyDeviceToHost) != hipSuccess) { oz_set_error("memcpy failed"); rc = OZ_ERR_HIP; break; }
+            bool all = true;
+            for (uint8_t f : fin) all = all && f;
+            if (all) break;
+        }
+    }
+    mb->stream = sb_saved;
+    if (rc) return rc;
+    OZ_HIP(hipStreamSynchronize(s));
+    return OZ_OK;
+}
+
+OZ_API int oz_arena_results(oz_arena* a, int8_t* winner, int32_t* points, int32_t* n_moves, uint8_t* actions,
+                            int8_t* players, uint64_t* final_black, uint64_t* final_white) {
+    OZ_REQUIRE(a, "null arena");
+    std::lock_guard<std::mutex> lk(a->mu);
+    oz_selfplay* sp = &a->games;
+    hipSetDevice(sp->m->device);
+    const int G = sp->gm.G;
+    hipLaunchKernelGGL(k_arena_collect, dim3((G + 255) / 256), dim3(256), 0, sp->m->stream, sp->gm, a->d_actions, a->d_players, a->d_nmoves);
+    OZ_HIP(hipStreamSynchronize(sp->m->stream));
+    std::vector<uint64_t> b(G), w(G);
+    OZ_HIP(hipMemcpy(b.data(), sp->gm.black, 8ull * G, hipMemcpyDeviceToHost));
+    OZ_HIP(hipMemcpy(w.data(), sp->gm.white, 8ull * G, hipMemcpyDeviceToHost));
+    for (int g = 0; g < G; ++g) {
+        const int pb = __builtin_popcountll(b[g]), pw = __builtin_popcountll(w[g]);
+        if (winner) winner[g] = pb >= pw ? 1 : -1;               // draw -> BLACK agent (agents.py:83-84)
+        if (points) points[g] = pb >= pw ? pb : pw;
+        if (final_black) final_black[g] = b[g];
+        if (final_white) final_white[g] = w[g];
+    }
+    if (n_moves) OZ_HIP(hipMemcpy(n_moves, a->d_nmoves, 4ull * G, hipMemcpyDeviceToHost));
+    if (actions) OZ_HIP(hipMemcpy(actions, a->d_actions, (size_t)G * 128, hipMemcpyDeviceToHost));
+    if (players) OZ_HIP(hipMemcpy(players, a->d_players, (size_t)G * 128, hipMemcpyDeviceToHost));
+    return OZ_OK;
+}
+
+// ================================================================ diagnostics
+// Device arithmetic used by the PUCT / backup formulas, exposed so the parity tests can compare it with the
+// host libm / IEEE results bit for bit: sqrt (float64), division (float64, float32), float32 multiply-add chain.
+__global__ void k_selftest_arith(const double* a, const double* b, int count, double* sq, double* dv, float* fdv, float* fq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    sq[i] = sqrt(a[i]);
+    dv[i] = a[i] / b[i];
+    const float x = (float)a[i], y = (float)b[i];
+    fdv[i] = x / y;
+    fq[i] = (x * y + x) / y;       // must stay mul, add, div (no FMA contraction)
+}
+OZ_API int oz_selftest_arith(const double* a, const double* b, int count, double* sqrt_a, double* div_ab, float* fdiv_ab,
+                             float* fchain) {
+    OZ_REQUIRE(a && b && sqrt_a && div_ab && fdiv_ab && fchain && count > 0, "bad argument");
+    oz_current_device();
+    double *da, *db, *ds, *dd; float *df, *dq;
+    OZ_HIP(hipMalloc((void**)&da, 8ull * count)); OZ_HIP(hipMalloc((void**)&db, 8ull * count));
+    OZ_HIP(hipMalloc((void**)&ds, 8ull * count)); OZ_HIP(hipMalloc((void**)&dd, 8ull * count));
+    OZ_HIP(hipMalloc((void**)&df, 4ull * count)); OZ_HIP(hipMalloc((void**)&dq, 4ull * count));
+    hipMemcpy(da, a, 8ull * count, hipMemcpyHostToDevice); hipMemcpy(db, b, 8ull * count, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_selftest_arith, dim3((count + 255) / 256), dim3(256), 0, 0, da, db, count, ds, dd, df, dq);
+    hipError_t e = hipDeviceSynchronize();
+    hipMemcpy(sqrt_a, ds, 8ull * count, hipMemcpyDeviceToHost); hipMemcpy(div_ab, dd, 8ull * count, hipMemcpyDeviceToHost);
+    hipMemcpy(fdiv_ab, df, 4ull * count, hipMemcpyDeviceToHost); hipMemcpy(fchain, dq, 4ull * count, hipMemcpyDeviceToHost);
+    hipFree(da); hipFree(db); hipFree(ds); hipFree(dd); hipFree(df); hipFree(dq);
+    OZ_HIP(e);
+    return OZ_OK;
+}

@@ -1,0 +1,81 @@
+"""Multi-GPU self-play: shard games over ranks, pool move records with ONE all-gather.
+
+Replaces the reference's only "parallelism": WorkerManager splitting episodes over workers and
+concatenating their result lists (workers.py:168-184,298-303) and the ssh/pickle return path
+(workers.py:147-159).  Games are independent, so the data path has no collective; the only exchange
+is the all-gather of compact 48-byte move records at the end of a self-play batch (RCCL over xGMI
+with backend "nccl", gloo on CPU).  The 8-fold symmetry expansion happens AFTER the gather
+(training.expand_examples), so ~18x fewer bytes cross the links.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._lib import RECORD_DTYPE
+
+RECORD_BYTES = RECORD_DTYPE.itemsize
+
+
+def shard_games(total_games, rank, world_size):
+    """contiguous block of global game ids for `rank` (first ranks take the remainder): (first_id, count)"""
+    base, rem = divmod(total_games, world_size)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def records_to_tensor(records, device="cpu"):
+    rec = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+    t = torch.from_numpy(rec.view(np.uint8).reshape(-1, RECORD_BYTES).copy())
+    return t.to(device)
+
+
+def tensor_to_records(t):
+    a = t.detach().cpu().contiguous().numpy().reshape(-1)
+    return a.view(RECORD_DTYPE).copy()
+
+
+def gather_records(local, group=None):
+    """all-gather variable-length record tensors (uint8 [R_i, 48]) -> uint8 [sum R_i, 48] on every rank,
+    ordered by rank.  Counts are gathered first, payloads are padded to the per-rank maximum."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    dev = local.device
+    cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts)
+    if mx == 0:
+        return local
+    padded = torch.zeros((mx, RECORD_BYTES), dtype=torch.uint8, device=dev)
+    padded[: local.shape[0]] = local
+    out = torch.empty((world * mx, RECORD_BYTES), dtype=torch.uint8, device=dev)
+    if dev.type == "cuda" and hasattr(dist, "all_gather_into_tensor"):
+        dist.all_gather_into_tensor(out, padded, group=group)
+    else:
+        _all_gather_list(out, padded, world, group)
+    return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(world)], dim=0)
+
+
+def _all_gather_list(out, padded, world, group):
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    for r, p in enumerate(parts):
+        out[r * padded.shape[0]: (r + 1) * padded.shape[0]] = p
+
+
+def engine_records_tensor(engine, device):
+    """move records of the engine's completed games as a uint8 [R, 48] tensor on `device`, copied device to
+    device from the engine's HBM buffer (no host round trip)."""
+    total = engine.stats()["records"]
+    t = torch.empty((max(total, 1), RECORD_BYTES), dtype=torch.uint8, device=device)
+    written = engine.records_to_device(t.data_ptr(), total) if total else 0
+    return t[:written]
+
+
+def pooled_selfplay_records(engine, device, group=None):
+    """records of every rank's completed games, identical on all ranks, sorted by (game_id, ply)"""
+    allrec = tensor_to_records(gather_records(engine_records_tensor(engine, device), group))
+    return allrec[np.lexsort((allrec["ply"], allrec["game_id"]))]

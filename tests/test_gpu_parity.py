@@ -1,0 +1,515 @@
+"""GPU parity tests (pytest -m gpu, real MI355X): the HIP path through the C ABI vs the reference-generated
+golden fixtures and vs the CPU oracle on the same seeded inputs.  Bit-exact for boards, moves, visit counts
+and the float64/float32 search tables; <= 1e-5 for the network outputs (tolerance stated per test)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_golden
+from oracle import nn_numpy
+
+pytestmark = pytest.mark.gpu
+
+QT_F32 = 1
+
+
+@pytest.fixture(scope="module")
+def oz():
+    import othellozero_amd  # noqa: F401
+    from othellozero_amd import _lib
+    _lib.require_gpu()
+    return _lib
+
+
+# ------------------------------------------------------------------ device arithmetic
+def test_device_arithmetic_is_ieee(oz):
+    """sqrt / division / float32 mul-add-div on the device are bit-identical to the host (PUCT, backup)."""
+    lib = oz.load()
+    rs = np.random.RandomState(0)
+    a = np.concatenate([np.arange(0, 1 << 20, dtype=np.float64), rs.rand(200000) * 1e4, rs.standard_normal(100000)])
+    b = np.concatenate([1.0 + np.arange(0, 1 << 20, dtype=np.float64) % 4097, rs.rand(200000) + 1e-3,
+                        rs.standard_normal(100000) + 3.0])
+    a = np.abs(a)
+    n = a.size
+    sq, dv = np.zeros(n), np.zeros(n)
+    fd, fq = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    oz.check(lib.oz_selftest_arith(oz.p_f64(a), oz.p_f64(b), n, oz.p_f64(sq), oz.p_f64(dv), oz.p_f32(fd), oz.p_f32(fq)))
+    assert np.array_equal(sq, np.sqrt(a))
+    assert np.array_equal(dv, a / b)
+    x, y = a.astype(np.float32), b.astype(np.float32)
+    assert np.array_equal(fd, x / y)
+    assert np.array_equal(fq, (x * y + x) / y)
+
+
+# ------------------------------------------------------------------ rules
+def test_rules_vs_golden(oz, golden_rules):
+    from othellozero_amd import Othello as O
+    g = golden_rules
+    for n in (4, 6, 8):
+        sel = g["n"] == n
+        b, w = g["black"][sel], g["white"][sel]
+        assert np.array_equal(O.rules_legal_moves(b, w, n), g["legal_black"][sel])
+        assert np.array_equal(O.rules_legal_moves(w, b, n), g["legal_white"][sel])
+        fin, p0, p1, win = O.rules_status(b, w, n)
+        assert np.array_equal(fin, g["finished"][sel]) and np.array_equal(win, g["winner"][sel])
+        assert np.array_equal(p0, g["pts_black"][sel]) and np.array_equal(p1, g["pts_white"][sel])
+        msel = g["n"][g["mv_pos"]] == n
+        pos = g["mv_pos"][msel]
+        isb = g["mv_player"][msel] == 1
+        own = np.where(isb, g["black"][pos], g["white"][pos])
+        opp = np.where(isb, g["white"][pos], g["black"][pos])
+        o2, p2 = O.rules_apply_moves(own, opp, g["mv_sq"][msel], n)
+        assert np.array_equal(np.where(isb, o2, p2), g["mv_black"][msel])
+        assert np.array_equal(np.where(isb, p2, o2), g["mv_white"][msel])
+        psel = g["pl_n"] == n
+        b2, w2, pl2, f2 = O.rules_play(g["pl_black"][psel], g["pl_white"][psel], g["pl_player"][psel], g["pl_sq"][psel], n)
+        assert np.array_equal(b2, g["pl_black2"][psel]) and np.array_equal(w2, g["pl_white2"][psel])
+        assert np.array_equal(pl2, g["pl_player2"][psel]) and np.array_equal(f2, g["pl_finished2"][psel])
+
+
+def test_rules_vs_oracle_random_boards(oz):
+    """2e4 random fillings per size (dense runs -> flip-through), every legal move applied"""
+    from othellozero_amd import Othello as O
+    L = oracle.lib()
+    rs = np.random.RandomState(5)
+    for n in (4, 6, 8):
+        cnt = 20000
+        valid = sum(1 << (r * 8 + c) for r in range(n) for c in range(n))
+        a = rs.randint(0, 1 << 62, size=cnt, dtype=np.int64).astype(np.uint64) * np.uint64(4) + rs.randint(0, 4, size=cnt).astype(np.uint64)
+        b = rs.randint(0, 1 << 62, size=cnt, dtype=np.int64).astype(np.uint64) * np.uint64(4) + rs.randint(0, 4, size=cnt).astype(np.uint64)
+        e = rs.randint(0, 1 << 62, size=cnt, dtype=np.int64).astype(np.uint64) * np.uint64(4) + rs.randint(0, 4, size=cnt).astype(np.uint64)
+        own = a & ~b & (e | a) & np.uint64(valid)
+        opp = b & ~a & np.uint64(valid)
+        legal = O.rules_legal_moves(own, opp, n)
+        idx = rs.choice(cnt, 2000, replace=False)
+        for i in idx:
+            assert int(legal[i]) == L.orc_legal_mask(int(own[i]), int(opp[i]), n, 0)
+        mo, mp, ms = [], [], []
+        for i in idx:
+            for s in oracle.mask_to_squares(legal[i]):
+                mo.append(own[i]); mp.append(opp[i]); ms.append(s)
+        o2, p2 = O.rules_apply_moves(np.array(mo, np.uint64), np.array(mp, np.uint64), np.array(ms, np.uint8), n)
+        for j in range(0, len(mo), 7):
+            x, y = C.c_uint64(int(mo[j])), C.c_uint64(int(mp[j]))
+            L.orc_apply_move(C.byref(x), C.byref(y), n, 0, int(ms[j]))
+            assert (int(o2[j]), int(p2[j])) == (x.value, y.value)
+
+
+def test_rules_edge_cases(oz):
+    from othellozero_amd import Othello as O
+    assert O.rules_legal_moves(np.zeros(0, np.uint64), np.zeros(0, np.uint64), 8).size == 0      # empty batch
+    full = np.uint64(0xFFFFFFFFFFFFFFFF)
+    fin, p0, p1, win = O.rules_status([full, 0, 0], [0, full, 0], 8)
+    assert list(fin) == [1, 1, 1] and list(win) == [1, -1, 1] and list(p0) == [64, 0, 0]          # empty board: draw -> ch0
+    # flip-through known answer: . O O X O X  flips 3
+    b = (1 << 3) | (1 << 5); w = (1 << 1) | (1 << 2) | (1 << 4)
+    o2, p2 = O.rules_apply_moves([b], [w], [0], 8)
+    assert int(o2[0]) == b | w | 1 and int(p2[0]) == 0
+
+
+def test_othello_game_dropin(oz, golden_rules):
+    """OthelloGame instance API replayed over golden play() transitions, board mutated in place"""
+    from othellozero_amd.Othello import BoardView, OthelloGame, OthelloPlayer
+    g = golden_rules
+    game, view = None, None
+    played = 0
+    for j in range(len(g["pl_n"])):
+        n = int(g["pl_n"][j])
+        if game is None or game.has_finished():
+            game = OthelloGame(n)
+            view = game.board(BoardView.TWO_CHANNELS)
+            if oracle.pack_board(view) != (int(g["pl_black"][j]), int(g["pl_white"][j])):
+                game = None
+                continue
+        if oracle.pack_board(view) != (int(g["pl_black"][j]), int(g["pl_white"][j])) or game.board_size != n:
+            game = None
+            continue
+        sq = int(g["pl_sq"][j])
+        assert game.current_player.value == int(g["pl_player"][j])
+        acts = [tuple(int(x) for x in a) for a in game.get_valid_actions()]
+        assert (sq >> 3, sq & 7) in acts and acts == sorted(acts)
+        game.play(sq >> 3, sq & 7)
+        assert oracle.pack_board(view) == (int(g["pl_black2"][j]), int(g["pl_white2"][j]))   # same array object
+        assert game.current_player.value == int(g["pl_player2"][j]) and game.has_finished() == bool(g["pl_finished2"][j])
+        played += 1
+        if played > 400:
+            break
+    assert played > 300
+    with pytest.raises(AssertionError):
+        fin = OthelloGame(4, initial_board=np.ones((4, 4, 2), dtype=bool) & np.array([True, False]))
+        fin.play(0, 0)
+
+
+def test_symmetry_expansion(oz):
+    from othellozero_amd import _lib
+    from othellozero_amd.training import expand_examples, training_example_symmetries
+    g = load_golden("symmetries.npz")
+    for n in (4, 6, 8):
+        perm = np.zeros((8, n * n), np.int32)
+        _lib.check(_lib.load().oz_symmetry_table(n, _lib.p_i32(perm)))
+        assert np.array_equal(perm, g[f"perm_{n}"])
+    rs = np.random.RandomState(1)
+    n = 8
+    rec = np.zeros(50, dtype=_lib.RECORD_DTYPE)
+    rec["black"] = rs.randint(0, 1 << 62, 50); rec["white"] = rs.randint(0, 1 << 62, 50) & ~rec["black"]
+    rec["final_black"] = rs.randint(0, 1 << 62, 50); rec["final_white"] = ~rec["final_black"]
+    rec["action"] = rs.randint(0, 64, 50); rec["z"] = rs.choice([-1, 1], 50)
+    for alias in (False, True):
+        boards, pol, z = expand_examples(rec, n, alias_final=alias)
+        for i in range(50):
+            src = _lib.unpack_board(int(rec["final_black" if alias else "black"][i]), int(rec["final_white" if alias else "white"][i]), n)
+            onehot = np.zeros((n, n)); a = int(rec["action"][i]); onehot[a >> 3, a & 7] = 1
+            for t, (sb, sp) in enumerate(training_example_symmetries(src, onehot)):
+                assert np.array_equal(boards[8 * i + t].astype(bool), sb)
+                assert int(pol[8 * i + t]) == int(np.argmax(sp)) and z[8 * i + t] == rec["z"][i]
+
+
+# ------------------------------------------------------------------ search
+class PyStubNet:
+    """host-side duck-typed net (like the reference's tests would use): oracle's stub formula"""
+    def __init__(self, n, salt, keep, f64):
+        from othellozero_amd.NNet import NeuralNets
+        self.network_type = NeuralNets.ONN
+        self.n, self.salt, self.keep, self.f64 = n, salt, keep, f64
+        self.calls = 0
+
+    def predict(self, board):
+        self.calls += 1
+        own, opp = oracle.pack_board(board)
+        return oracle.stub_predict(own, opp, self.n, self.salt, self.keep)
+
+
+def _check_tables(dump, g, prefix):
+    boards = g[prefix + "boards"]
+    assert len(dump) == len(boards)
+    for i, nd in enumerate(dump):
+        assert (nd["k0"], nd["k1"]) == (int(boards[i][0]), int(boards[i][1])), (prefix, i)
+        assert nd["Ns"] == int(g[prefix + "Ns"][i]) and nd["legal"] == int(g[prefix + "legal"][i])
+        assert np.array_equal(nd["P"], g[prefix + "P"][i]), (prefix, i)
+        assert np.array_equal(nd["N"], g[prefix + "N"][i]), (prefix, i)
+        assert np.array_equal(nd["Q"], g[prefix + "Q"][i]), (prefix, i)
+        if g[prefix + "edges_init"][i]:
+            for sq in oracle.mask_to_squares(nd["legal"]):
+                if nd["N"][sq]:
+                    assert (nd["qtag"][sq] == 1) == (g[prefix + "qtype"][i][sq] == QT_F32), (prefix, i, sq)
+
+
+@pytest.mark.parametrize("device_net", [False, True])
+def test_mcts_traces_vs_golden(oz, golden_mcts, device_net):
+    """OthelloMCTS.simulate sim by sim: full (Ns, Nsa, Qsa, Psa) tables, return values and their dynamic types
+    after k simulations, for a host-side duck-typed net and for the device stub net."""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.Othello import OthelloPlayer
+    from othellozero_amd.othelo_mcts import OthelloMCTS
+    g = golden_mcts
+    for name in g["names"]:
+        name = str(name)
+        n, player, salt, keep, qmode, nsims = (int(x) for x in g[f"{name}/meta"])
+        c = float(g[f"{name}/c"][0])
+        root = oz.unpack_board(int(g[f"{name}/root"][0]), int(g[f"{name}/root"][1]), n)
+        net = StubNetWrapper((n, n), salt, keep) if device_net else PyStubNet(n, salt, keep, qmode == 1)
+        m = OthelloMCTS(n, net, c, q_mode=qmode, node_cap=1024)
+        pl = OthelloPlayer(player)
+        done, rets, rts = 0, [], []
+        for cp in g[f"{name}/cps"]:
+            while done < int(cp):
+                r = m.simulate(root, pl)
+                rets.append(float(r))
+                rts.append(0 if isinstance(r, int) else (1 if isinstance(r, np.float32) else 2))
+                done += 1
+            _check_tables(m.dump(), g, f"{name}/cp{int(cp)}/")
+        assert np.array_equal(np.array(rets), g[f"{name}/ret"]), name
+        assert np.array_equal(np.array(rts, np.uint8), g[f"{name}/ret_type"]), name
+        state = root if player == 1 else root[:, :, ::-1]
+        assert np.array_equal(m.get_policy_action_probabilities(state, 1), g[f"{name}/pi_T1"]), name
+        if not device_net:
+            assert net.calls == len(g[f"{name}/cp{int(g[f'{name}/cps'][-1])}/boards"])     # one predict per expansion
+
+
+def test_mcts_keyerror_and_unknown_state(oz):
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.Othello import OthelloGame, OthelloPlayer
+    from othellozero_amd.othelo_mcts import OthelloMCTS
+    m = OthelloMCTS(6, StubNetWrapper((6, 6), 1), 1)
+    root = OthelloGame.initial_board(6)
+    assert m.N(root) == 0 and m.N(root, (1, 2)) == 0               # unknown state -> 0 (MCTS/__init__.py:173-174)
+    m.simulate(root, OthelloPlayer.BLACK)                          # only expands the root
+    with pytest.raises(KeyError):
+        m.N(root, (1, 2))                                          # _Nsa[hash] is still {}
+    with pytest.raises(KeyError):
+        m.get_policy_action_probabilities(root, 1)
+    m.simulate(root, OthelloPlayer.BLACK)
+    assert m.N(root) == 1 and sum(m.N(root, a) for a in m.get_state_actions(root)) == 1
+
+
+# ------------------------------------------------------------------ drivers
+def _patch_rng(monkeypatch, seed, game, ply_of):
+    L = oracle.lib()
+    monkeypatch.setattr(random, "random", lambda: (L.orc_rng(seed, game, ply_of(), 0) >> 11) * (1.0 / 9007199254740992.0))
+    monkeypatch.setattr(random, "choice", lambda seq: seq[L.orc_rng(seed, game, ply_of(), 2) % len(seq)])
+    monkeypatch.setattr(np.random, "choice", lambda k: L.orc_rng(seed, game, ply_of(), 1) % k)
+
+
+@pytest.mark.parametrize("name", ["ep8_25", "ep8_25_f64", "ep8_T0", "ep6_50_f64_c2", "ep6_sparse", "ep4_60"])
+def test_execute_episode_dropin_vs_golden(oz, golden_episodes, monkeypatch, name):
+    """training.execute_episode with the reference's own random calls patched exactly as the fixture generator
+    patched them for the reference: same moves, same returned examples (incl. the aliasing quirk), same z."""
+    from othellozero_amd import training
+    from othellozero_amd.Othello import OthelloGame
+    g = golden_episodes
+    n, sims, seed, game, salt, keep, qmode, k = (int(x) for x in g[f"{name}/meta"])
+    c, T, eg = (float(x) for x in g[f"{name}/params"])
+    ply = [0]
+    orig_play = OthelloGame.play
+
+    def counting_play(self, row, col):
+        orig_play(self, row, col)
+        ply[0] += 1
+    monkeypatch.setattr(OthelloGame, "play", counting_play)
+    _patch_rng(monkeypatch, seed, game, lambda: ply[0])
+    net = PyStubNet(n, salt, keep, qmode == 1)
+    T_arg = int(T) if T == int(T) else T
+    ex = training.execute_episode(n, net, int(c) if c == int(c) else c, sims, T_arg, eg, q_mode=qmode)
+    assert len(ex) == 8 * k
+    eb, ep, ez = g[f"{name}/ex_board"], g[f"{name}/ex_policy"], g[f"{name}/ex_z"]
+    for i, (b, p, z) in enumerate(ex):
+        assert b.dtype == np.bool_ and p.dtype == np.float64 and isinstance(z, int)
+        assert oracle.pack_board(b) == (int(eb[i][0]), int(eb[i][1])), (name, i)
+        assert int(np.argmax(p)) == int(ep[i]) and p.sum() == 1.0 and z == int(ez[i]), (name, i)
+    assert net.calls == int(g[f"{name}/n_expansions"][0])
+
+
+def test_selfplay_engine_vs_golden_episodes(oz, golden_episodes):
+    """the batched engine (device stub net, counter RNG streams) replays the reference's episodes move for move"""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    g = golden_episodes
+    for name in g["names"]:
+        name = str(name)
+        n, sims, seed, game, salt, keep, qmode, k = (int(x) for x in g[f"{name}/meta"])
+        c, T, eg = (float(x) for x in g[f"{name}/params"])
+        eng = SelfPlayEngine(StubNetWrapper((n, n), salt, keep, max_batch=1), n, 1, sims, c, T, eg, seed=seed,
+                             first_game_id=game, q_mode=qmode)
+        counts = []
+        for _ in range(k):
+            eng.run(1)
+            counts.append(eng.last_counts()[0].copy())
+        rec = eng.records()
+        assert rec.size == k and eng.stats()["live_games"] == 0, name
+        assert np.array_equal(rec["action"], g[f"{name}/action"]) and np.array_equal(rec["player"], g[f"{name}/player"]), name
+        assert np.array_equal(rec["black"], g[f"{name}/black"]) and np.array_equal(rec["white"], g[f"{name}/white"]), name
+        assert np.array_equal(np.array(counts), g[f"{name}/counts"]), name
+        assert eng.stats()["expansions"] == int(g[f"{name}/n_expansions"][0]), name
+        assert np.array_equal(np.repeat(rec["z"], 8), g[f"{name}/ex_z"]), name
+
+
+@pytest.mark.parametrize("n,sims,T,qmode,keep", [(8, 40, 1.0, 1, 0), (6, 60, 0.0, 0, 0), (6, 30, 1.0, 0, 7), (4, 50, 1.0, 1, 3)])
+def test_selfplay_engine_vs_oracle_many_games(oz, n, sims, T, qmode, keep):
+    """64 concurrent games in lock step == 64 sequential oracle episodes (moves, snapshots, z, counters)"""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    G, seed, first = 64, 777, 1000
+    eng = SelfPlayEngine(StubNetWrapper((n, n), 9, keep, max_batch=G), n, G, sims, 1.25, T, 0.8, seed=seed,
+                         first_game_id=first, q_mode=qmode)
+    rec = eng.play_to_end()
+    st = eng.stats()
+    tot = dict(visits=0, expansions=0, terminal=0, fallback=0)
+    off = 0
+    for gi in range(G):
+        m = oracle.Mcts(n, 1.25, qmode, salt=9, keep_mask=keep)
+        ep = m.episode(sims, T, 0.8, seed, first + gi)
+        k = ep["n_moves"]
+        r = rec[off:off + k]; off += k
+        assert np.all(r["game_id"] == first + gi) and np.array_equal(r["ply"], np.arange(k))
+        assert np.array_equal(r["action"], ep["action"]) and np.array_equal(r["player"], ep["player"]), gi
+        assert np.array_equal(r["black"], ep["black"]) and np.array_equal(r["white"], ep["white"]), gi
+        assert np.array_equal(r["z"], ep["z"]) and np.array_equal(r["greedy"], ep["greedy"]), gi
+        assert np.all(r["final_black"] == ep["final_black"]) and np.all(r["final_white"] == ep["final_white"])
+        for key in tot:
+            tot[key] += ep["stats"][key]
+    assert off == rec.size
+    assert (st["node_visits"], st["expansions"], st["terminal_hits"], st["fallbacks"]) == \
+        (tot["visits"], tot["expansions"], tot["terminal"], tot["fallback"])
+    assert st["games_completed"] == G and st["moves"] == rec.size
+    if keep:
+        assert st["fallbacks"] > 0
+
+
+def test_selfplay_refill_and_capacity_error(oz):
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    net = StubNetWrapper((4, 4), 3, 0, max_batch=8)
+    eng = SelfPlayEngine(net, 4, 8, 20, refill=True, seed=1, first_game_id=0, game_id_stride=8)
+    eng.run(40)
+    st = eng.stats()
+    assert st["games_completed"] >= 16 and st["live_games"] == 8
+    rec = eng.records()
+    ids = np.unique(rec["game_id"])
+    assert ids.size == st["games_completed"] and ids.max() >= 8          # refilled slots carry new global ids
+    for gid in ids[:12]:                                                 # a refilled game == a fresh oracle episode
+        ep = oracle.Mcts(4, 1.0, 1, salt=3).episode(20, 1.0, 0.9, 1, int(gid))
+        r = rec[rec["game_id"] == gid]
+        assert np.array_equal(r["action"], ep["action"]) and np.array_equal(r["z"], ep["z"])
+    small = SelfPlayEngine(net, 4, 8, 20, node_cap=16, edge_cap=64)
+    with pytest.raises(oz.OzError) as ei:
+        small.run(12)
+    assert ei.value.code == oz.OZ_ERR_CAPACITY
+
+
+def test_arena_vs_golden_and_oracle(oz, golden_arena):
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.agents import arena_batch
+    g = golden_arena
+    for name in g["names"]:
+        name = str(name)
+        n, sims, seed, game, sa, sb, qmode, k = (int(x) for x in g[f"{name}/meta"])
+        c = float(g[f"{name}/c"][0])
+        r = arena_batch(StubNetWrapper((n, n), sa, 0, max_batch=1), StubNetWrapper((n, n), sb, 0, max_batch=1), n, 1, sims, c,
+                        seed=seed, first_game_id=game, q_mode=qmode)
+        assert int(r["n_moves"][0]) == k, name
+        assert np.array_equal(r["actions"][0][:k], g[f"{name}/action"]) and np.array_equal(r["players"][0][:k], g[f"{name}/player"])
+        assert (int(r["final_black"][0]), int(r["final_white"][0])) == tuple(int(x) for x in g[f"{name}/final"])
+        assert (int(r["winner"][0]), int(r["points"][0])) == tuple(int(x) for x in g[f"{name}/result"]), name
+    # 32 concurrent deterministic games vs the oracle
+    G, n, sims = 32, 6, 120
+    r = arena_batch(StubNetWrapper((n, n), 41, 0, max_batch=G), StubNetWrapper((n, n), 42, 0, max_batch=G), n, G, sims, 1.0,
+                    seed=7, first_game_id=500, q_mode=0)
+    for gi in range(G):
+        o = oracle.arena(oracle.Mcts(n, 1.0, 0, salt=41), oracle.Mcts(n, 1.0, 0, salt=42), sims, 7, 500 + gi)
+        k = o["n_moves"]
+        assert int(r["n_moves"][gi]) == k and np.array_equal(r["actions"][gi][:k], o["action"]), gi
+        assert (int(r["winner"][gi]), int(r["points"][gi])) == (o["winner"], o["points"]), gi
+
+
+def test_agents_dropin_duel(oz, golden_arena, monkeypatch):
+    """duel_between_agents with two NeuralNetworkOthelloAgent (host-side nets) == the reference's trace"""
+    from othellozero_amd.Othello import OthelloGame
+    from othellozero_amd.agents import NeuralNetworkOthelloAgent, duel_between_agents
+    g = golden_arena
+    name = "ar6_200_f64"
+    n, sims, seed, game, sa, sb, qmode, k = (int(x) for x in g[f"{name}/meta"])
+    ply = [0]
+    log = []
+    orig_play = OthelloGame.play
+
+    def counting_play(self, row, col):
+        log.append((self.current_player.value, int(row) * 8 + int(col)))
+        orig_play(self, row, col)
+        ply[0] += 1
+    monkeypatch.setattr(OthelloGame, "play", counting_play)
+    _patch_rng(monkeypatch, seed, game, lambda: ply[0])
+    game_obj = OthelloGame(n)
+    a1 = NeuralNetworkOthelloAgent(game_obj, PyStubNet(n, sa, 0, True), sims, 1, q_mode=qmode)
+    a2 = NeuralNetworkOthelloAgent(game_obj, PyStubNet(n, sb, 0, True), sims, 1, q_mode=qmode)
+    winner, points = duel_between_agents(game_obj, a1, a2)
+    assert [x[1] for x in log] == list(g[f"{name}/action"]) and [x[0] for x in log] == list(g[f"{name}/player"])
+    assert (1 if winner is a1 else -1, points) == tuple(int(x) for x in g[f"{name}/result"])
+
+
+# ------------------------------------------------------------------ network
+def _boards(n, count, seed):
+    rs = np.random.RandomState(seed)
+    own, opp = [], []
+    for _ in range(count):
+        a = rs.rand(n, n) < 0.4
+        b = (rs.rand(n, n) < 0.4) & ~a
+        o, p = oracle.pack_board(np.stack([a, b], axis=2))
+        own.append(o); opp.append(p)
+    return np.array(own, np.uint64), np.array(opp, np.uint64)
+
+
+@pytest.mark.parametrize("n,channels,batch", [(8, 128, 37), (6, 128, 70), (8, 512, 9), (6, 512, 5)])
+def test_network_vs_float64_oracle(oz, n, channels, batch):
+    """pi and v within 1e-5 (absolute) of the float64 restatement of OthelloNN; every parameter kind random
+    (kernels, biases, BN gamma / beta / moving mean / moving variance); logits lifted away from uniform."""
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.weights import init_weights
+    w = init_weights(n, seed=11, channels=channels, randomize_all=True)
+    for i in (36, 38):
+        w[i] = w[i] * 4.0
+    net = NNetWrapper((n, n), num_channels_1=channels, max_batch=64, weights=w)
+    own, opp = _boards(n, batch, seed=n + channels)
+    pi, v = net.predict_batch(own, opp)                        # batch > max_batch exercises the chunking too
+    pi64, v64 = nn_numpy.forward(w, own, opp, n)
+    assert pi.dtype == np.float32 and v.dtype == np.float32 and pi.shape == (batch, n, n)
+    assert pi64.std() > 2e-3 and np.abs(v64).max() > 0.05       # the test is not vacuous
+    assert np.abs(pi.reshape(batch, -1) - pi64).max() <= 1e-5
+    assert np.abs(v - v64).max() <= 1e-5
+    assert np.abs(pi.reshape(batch, -1).sum(axis=1) - 1).max() < 1e-5
+    # a position's result does not depend on its place in the batch, nor on the batch size (bit-exact)
+    perm = np.random.RandomState(0).permutation(batch)
+    pi2, v2 = net.predict_batch(own[perm], opp[perm])
+    assert np.array_equal(pi2, pi[perm]) and np.array_equal(v2, v[perm])
+    p1, v1 = net.predict(oz.unpack_board(int(own[3]), int(opp[3]), n))
+    assert np.array_equal(p1, pi[3]) and v1 == v[3] and isinstance(v1, np.float32)
+    # get/set weights round trip and copy()
+    cp = net.copy()
+    assert all(np.array_equal(a, b) for a, b in zip(cp.get_weights(), w))
+    pc, vc = cp.predict_batch(own[:4], opp[:4])
+    assert np.array_equal(pc, pi[:4]) and np.array_equal(vc, v[:4])
+
+
+def test_search_with_real_network_vs_oracle(oz):
+    """end to end: batched engine + OthelloNN on the GPU == the oracle's search fed with the GPU network's
+    own (pi, v) per position (so float rounding in the net cannot excuse a divergent game)."""
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    from othellozero_amd.weights import init_weights
+    n, C_, G, sims = 6, 128, 16, 30
+    w = init_weights(n, seed=2, channels=C_, randomize_all=True)
+    for i in (36, 38):
+        w[i] = w[i] * 4.0
+    net = NNetWrapper((n, n), num_channels_1=C_, max_batch=G, weights=w)
+    eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=31, first_game_id=0, q_mode=1)
+    rec = eng.play_to_end()
+    cache = {}
+
+    def ev(own, opp, nn):
+        if (own, opp) not in cache:
+            p, v = net.predict_batch([own], [opp])
+            cache[(own, opp)] = (p[0].ravel(), float(v[0]))
+        return cache[(own, opp)]
+    for gi in range(G):
+        ep = oracle.Mcts(n, 1.0, 1, evaluator=ev).episode(sims, 1.0, 0.9, 31, gi)
+        r = rec[rec["game_id"] == gi]
+        assert np.array_equal(r["action"], ep["action"]) and np.array_equal(r["z"], ep["z"]), gi
+        assert np.array_equal(r["black"], ep["black"]) and np.array_equal(r["white"], ep["white"]), gi
+
+
+# ------------------------------------------------------------------ BASELINE config sizes (size-independent properties)
+def test_config2_size_properties(oz):
+    """4096 concurrent 8x8 games at 100 sims/move (BASELINE config 2) for a few move rounds with the device stub
+    net: every recorded transition is legal under the oracle's rules, disc counts grow by one per ply plus flips,
+    counters are consistent, and a second run reproduces the first bit for bit."""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.Othello import rules_legal_moves
+    from othellozero_amd.training import SelfPlayEngine
+    G, n, sims, rounds = 4096, 8, 100, 3
+    states = []
+    for rep in range(2):
+        eng = SelfPlayEngine(StubNetWrapper((n, n), 77, 0, max_batch=G), n, G, sims, seed=1234)
+        before = eng.state()
+        eng.run(rounds)
+        st, after = eng.stats(), eng.state()
+        assert st["simulations"] == G * sims * rounds and st["moves"] == G * rounds and st["live_games"] == G
+        assert st["expansions"] + st["terminal_hits"] <= st["simulations"] and st["overflow"] == 0
+        assert st["expansions"] > 0.8 * st["simulations"]
+        assert np.all(after["ply"] == rounds)
+        discs = np.array([bin(int(b)).count("1") + bin(int(w)).count("1") for b, w in zip(after["black"], after["white"])])
+        assert np.all(discs == 4 + rounds) and np.all((after["black"] & after["white"]) == 0)
+        counts = eng.last_counts()
+        assert np.all(counts.sum(axis=1) >= sims - 1)            # Ns of the root: this move's sims + reused visits
+        states.append((after["black"].copy(), after["white"].copy(), counts.copy(), st["expansions"]))
+        assert np.all(before["ply"] == 0)
+    assert np.array_equal(states[0][0], states[1][0]) and np.array_equal(states[0][1], states[1][1])
+    assert np.array_equal(states[0][2], states[1][2]) and states[0][3] == states[1][3]
+    # spot-check 64 slots against the oracle
+    for gi in range(0, G, 64):
+        ep = oracle.Mcts(n, 1.0, 1, salt=77).episode(sims, 1.0, 0.9, 1234, gi, max_moves=rounds)
+        b, w = C.c_uint64(int(ep["black"][-1])), C.c_uint64(int(ep["white"][-1]))
+        pl, fin = C.c_int(int(ep["player"][-1])), C.c_int(0)
+        oracle.lib().orc_game_play(C.byref(b), C.byref(w), n, C.byref(pl), C.byref(fin), int(ep["action"][-1]))
+        assert (b.value, w.value) == (int(states[0][0][gi]), int(states[0][1][gi])), gi

@@ -1,0 +1,191 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol (no compute), host-side
+logic, the oracle's NN legs agree with each other and with torch, and the multi-rank record pooling
+works over gloo with world_size 2."""
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import nn_numpy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from othellozero_amd import _lib
+    lib = _lib.load()                      # raises OzLibraryError if the .so is missing
+    hdr = open(os.path.join(ROOT, "include", "othellozero_amd.h")).read()
+    declared = set(re.findall(r"^\s*(?:const char\*|int)\s+(oz_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert len(declared) > 40
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    bound = set(_lib.SIGNATURES) | {"oz_last_error"}
+    assert declared == bound, (declared ^ bound)
+    assert lib.oz_version() >= 100
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from othellozero_amd import _lib
+    with pytest.raises(_lib.OzLibraryError):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_no_gpu_means_error_not_fallback():
+    from othellozero_amd import _lib
+    lib = _lib.load()
+    if lib.oz_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from othellozero_amd.NNet import NNetWrapper
+    with pytest.raises(_lib.OzLibraryError):
+        NNetWrapper((6, 6), num_channels_1=128)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "othellozero_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle", src, flags=re.M), f
+                assert "liboz_oracle" not in src, f
+
+
+def test_record_dtype_and_pack_roundtrip():
+    from othellozero_amd import _lib
+    assert _lib.RECORD_DTYPE.itemsize == 48
+    rs = np.random.RandomState(0)
+    for n in (4, 6, 8):
+        b = rs.rand(n, n, 2) < 0.3
+        b[:, :, 1] &= ~b[:, :, 0]
+        c0, c1 = _lib.pack_board(b)
+        assert (c0, c1) == oracle.pack_board(b)
+        assert np.array_equal(_lib.unpack_board(c0, c1, n), b)
+
+
+def test_shard_games():
+    from othellozero_amd.distributed import shard_games
+    for total, world in ((32768, 8), (10, 3), (5, 8)):
+        seen = []
+        for r in range(world):
+            first, cnt = shard_games(total, r, world)
+            seen += list(range(first, first + cnt))
+        assert seen == list(range(total))
+
+
+def test_weight_shapes_match_survey_parameter_counts():
+    from othellozero_amd.weights import init_weights, onn_shapes
+    assert sum(int(np.prod(s)) for s in onn_shapes(8)) == 16051265        # params incl. BN statistics
+    assert sum(int(np.prod(s)) for s in onn_shapes(6)) == 9745445
+    w = init_weights(6, seed=1, channels=128)
+    assert len(w) == 40 and w[0].shape == (3, 3, 2, 128) and w[24].shape == (4 * 128, 1024)
+
+
+def _torch_forward(weights, own, opp, n):
+    import torch
+    import torch.nn.functional as F
+    w = [torch.from_numpy(np.asarray(a, dtype=np.float64)) for a in weights]
+    x = torch.from_numpy(nn_numpy.planes(own, opp, n)).permute(0, 3, 1, 2)          # NCHW
+    for layer, pad in enumerate((1, 1, 0, 0)):
+        k, bias, g, b, mu, var = w[6 * layer:6 * layer + 6]
+        x = F.conv2d(x, k.permute(3, 2, 0, 1), bias, padding=pad)
+        x = F.batch_norm(x, mu, var, g, b, training=False, eps=1e-3).relu()
+    x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)                               # keras Flatten of NHWC
+    for layer in (4, 5):
+        k, bias, g, b, mu, var = w[6 * layer:6 * layer + 6]
+        x = F.batch_norm(x @ k + bias, mu, var, g, b, training=False, eps=1e-3).relu()
+    pi = torch.softmax(x @ w[36] + w[37], dim=1)
+    v = torch.tanh(x @ w[38] + w[39])[:, 0]
+    return pi.numpy(), v.numpy()
+
+
+def _random_boards(n, count, seed):
+    rs = np.random.RandomState(seed)
+    own, opp = [], []
+    for _ in range(count):
+        a = rs.rand(n, n) < 0.35
+        b = (rs.rand(n, n) < 0.35) & ~a
+        brd = np.stack([a, b], axis=2)
+        o, p = oracle.pack_board(brd)
+        own.append(o); opp.append(p)
+    return np.array(own, np.uint64), np.array(opp, np.uint64)
+
+
+@pytest.mark.parametrize("n", [6, 8])
+def test_oracle_nn_legs_agree(n):
+    """float64 NumPy restatement == torch-CPU float64 (independent conv/BN implementation) to 1e-12,
+    and the float32 C restatement is within 1e-5 of both."""
+    from othellozero_amd.weights import init_weights
+    C = 64
+    w = init_weights(n, seed=3, channels=C, randomize_all=True)
+    for i in (0, 6, 12, 18, 24, 30, 36, 38):
+        w[i] = w[i] * 3.0                      # lift the logits away from uniform
+    own, opp = _random_boards(n, 5, seed=n)
+    pi64, v64 = nn_numpy.forward(w, own, opp, n)
+    pit, vt = _torch_forward(w, own, opp, n)
+    assert np.abs(pi64 - pit).max() < 1e-12 and np.abs(v64 - vt).max() < 1e-12
+    assert pi64.std() > 1e-3
+    cnet = oracle.CNet(w, n, channels=C, nthreads=2)
+    pi32, v32 = cnet.forward(own, opp)
+    assert np.abs(pi32 - pi64).max() < 1e-5 and np.abs(v32 - v64).max() < 1e-5
+
+
+def test_oracle_episode_with_c_net_runs():
+    """the cpu_baseline path: oracle search driven by the float32 C net (batch-1 leaf evaluation)"""
+    from othellozero_amd.weights import init_weights
+    w = init_weights(6, seed=0, channels=64)
+    cnet = oracle.CNet(w, 6, channels=64, nthreads=2)
+    m = oracle.Mcts(6, 1.0, oracle.QMODE_F64, evaluator=cnet.evaluator())
+    ep = m.episode(8, 1.0, 0.9, 1234, 0, max_moves=3)
+    assert ep["n_moves"] == 3 and ep["stats"]["expansions"] > 10 and cnet.ctx.calls == ep["stats"]["expansions"]
+
+
+GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from othellozero_amd import _lib
+from othellozero_amd.distributed import gather_records, records_to_tensor, tensor_to_records, shard_games
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+first, cnt = shard_games(7, rank, world)           # ragged: 4 + 3 games
+rec = np.zeros(0, dtype=_lib.RECORD_DTYPE)
+rows = []
+for g in range(first, first + cnt):
+    k = 3 + g                                       # variable number of plies per game
+    r = np.zeros(k, dtype=_lib.RECORD_DTYPE)
+    r["game_id"] = g; r["ply"] = np.arange(k); r["black"] = 1000 * g + np.arange(k); r["z"] = 1 - 2 * (g & 1)
+    rows.append(r)
+rec = np.concatenate(rows) if rows else rec
+pooled = tensor_to_records(gather_records(records_to_tensor(rec)))
+pooled = pooled[np.lexsort((pooled["ply"], pooled["game_id"]))]
+exp = sum(3 + g for g in range(7))
+assert pooled.size == exp, (pooled.size, exp)
+assert np.array_equal(np.unique(pooled["game_id"]), np.arange(7))
+for g in range(7):
+    sel = pooled[pooled["game_id"] == g]
+    assert np.array_equal(sel["ply"], np.arange(3 + g)) and np.all(sel["black"] == 1000 * g + np.arange(3 + g))
+# an empty rank must not break the gather
+pooled2 = tensor_to_records(gather_records(records_to_tensor(rec if rank == 0 else rec[:0])))
+assert pooled2.size == (sum(3 + g for g in range(4)))
+dist.barrier()
+print("RANK_OK", rank)
+"""
+
+
+def test_gloo_world_size_2_record_pooling(tmp_path):
+    script = tmp_path / "gloo_worker.py"
+    script.write_text(GLOO_WORKER)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {rank}" in out, out
