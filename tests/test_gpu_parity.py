@@ -154,8 +154,9 @@ def test_symmetry_expansion(oz):
     rs = np.random.RandomState(1)
     n = 8
     rec = np.zeros(50, dtype=_lib.RECORD_DTYPE)
-    rec["black"] = rs.randint(0, 1 << 62, 50); rec["white"] = rs.randint(0, 1 << 62, 50) & ~rec["black"]
-    rec["final_black"] = rs.randint(0, 1 << 62, 50); rec["final_white"] = ~rec["final_black"]
+    r64 = lambda: rs.randint(0, 1 << 62, 50).astype(np.uint64) * np.uint64(4) + rs.randint(0, 4, 50).astype(np.uint64)
+    rec["black"] = r64(); rec["white"] = r64() & ~rec["black"]
+    rec["final_black"] = r64(); rec["final_white"] = ~rec["final_black"]
     rec["action"] = rs.randint(0, 64, 50); rec["z"] = rs.choice([-1, 1], 50)
     for alias in (False, True):
         boards, pol, z = expand_examples(rec, n, alias_final=alias)
