@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--board", type=int, default=8)
     ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x2"],
+                    help="conv arithmetic: exact fp32 matrix cores, or f32 via 2 x fp16 split (same 1e-5 parity tolerance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -92,7 +94,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n, G = args.board, args.games
-    net = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0)   # same weights on every rank
+    net = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0, precision=args.precision)   # same weights on every rank
     eng = SelfPlayEngine(net, n, G, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * G,
                          game_id_stride=world * G, q_mode=_lib.QMODE_F64, refill=True,
                          record_cap=G * (args.steps + args.warmup + 2))

@@ -72,6 +72,14 @@ int oz_net_num_weights(const oz_net* net);
 int oz_net_weight_size(const oz_net* net, int index, int64_t* nelem);
 int oz_net_set_weight(oz_net* net, int index, const float* data, int64_t nelem);
 int oz_net_get_weight(const oz_net* net, int index, float* data, int64_t nelem);
+/* arithmetic of the 3x3 convolutions: 0 = exact fp32 matrix cores (v_mfma_f32_32x32x2_f32);
+ * 1 = "f32 via 2 x fp16 split": x = h1 + h2, products a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_32x32x16_f16 with fp32
+ * accumulation (<= 2^-22 relative per product, the class of fp32 accumulation error; needs channels % 256 == 0 and
+ * post-ReLU activations < 65504 -- oz_net_check / predict / selfplay_sync report OZ_ERR_STATE otherwise).
+ * Takes effect at the next oz_net_commit. */
+int oz_net_set_precision(oz_net* net, int mode);
+int oz_net_get_precision(const oz_net* net);
+int oz_net_check(oz_net* net);
 /* fold BN (epsilon 1e-3, moving statistics) + re-layout for the kernels; call after the last set_weight */
 int oz_net_commit(oz_net* net);
 /* NNetWrapper.predict (Net/NNet.py:70-87) for `count` canonical boards: pi[count][n*n] float32, v[count] float32 */

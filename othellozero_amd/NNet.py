@@ -35,7 +35,7 @@ class _NetHandle:
 
 class NNetWrapper(_NetHandle):
     def __init__(self, board_size=(8, 8), batch_size=32, epochs=10, num_channels_1=512, num_channels_2=256,
-                 lr=0.001, dropout=0.3, network=NeuralNets.ONN, max_batch=1, seed=0, weights=None):
+                 lr=0.001, dropout=0.3, network=NeuralNets.ONN, max_batch=1, seed=0, weights=None, precision="f32"):
         super().__init__()
         self.board_size_x, self.board_size_y = board_size
         assert self.board_size_x == self.board_size_y, "square boards only"
@@ -48,6 +48,10 @@ class NNetWrapper(_NetHandle):
             raise NotImplementedError("only NeuralNets.ONN is implemented (BNN: SURVEY.md section 8(f) item 4)")
         lib = _lib.require_gpu()
         _lib.check(lib.oz_net_create(C.byref(self._h), self.board_size_x, self.num_channels, self.max_batch))
+        # precision: "f32" = exact fp32 matrix cores; "f16x2" = f32 via 2 x fp16 split on the 16-bit matrix cores
+        # (same <= 1e-5 tolerance, ~3-4x faster; needs channels % 256 == 0, raises if an activation leaves the fp16 range)
+        self.precision = precision
+        _lib.check(lib.oz_net_set_precision(self._h, {"f32": 0, "f16x2": 1}[precision]))
         self.set_weights(weights if weights is not None else init_weights(self.board_size_x, seed, self.num_channels))
 
     # ---- weights (model.get_weights / set_weights, Net/NNet.py:98-101)
@@ -112,7 +116,8 @@ class NNetWrapper(_NetHandle):
 
     def copy(self):
         return NNetWrapper((self.board_size_x, self.board_size_y), network=self.network_type,
-                           num_channels_1=self.num_channels, max_batch=self.max_batch, weights=self.get_weights())
+                           num_channels_1=self.num_channels, max_batch=self.max_batch, weights=self.get_weights(),
+                           precision=self.precision)
 
     # ---- profiling hooks used by bench.py
     def time_forward(self, count, iters=3):

@@ -18,6 +18,7 @@ struct oz_net {
     int n = 8, C = 512, max_batch = 0, device = 0;
     std::mutex mu;
     virtual ~oz_net() {}
+    virtual int check() { return 0; }      // sticky device-side validity flags (f16x2 range)
     virtual int forward_device(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count,
                                float* d_pi, float* d_v, hipStream_t s) = 0;
 };

@@ -190,6 +190,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
     }
 }
 
+#include "oz_net_h2.h"
+
 // ---------------------------------------------------------------- heads
 // one wave per position: logits[a] = f2 . Wpi[:,a] + bpi[a] -> softmax; v = tanh(f2 . Wv + bv)
 __global__ __launch_bounds__(64) void k_heads(const float* __restrict__ f2 /*[B][512]*/, const int* __restrict__ d_count,
@@ -264,7 +266,13 @@ struct OnnNet : oz_net {
     float *d_scale[6] = {}, *d_shift[6] = {};
     float *d_wpi = nullptr, *d_bpi = nullptr, *d_wv = nullptr, *d_bv = nullptr;
     float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *act4 = nullptr, *f1 = nullptr, *f2 = nullptr;
-    float *ones = nullptr, *zeros = nullptr;
+    // precision 1 ("f32 via 2 x fp16 split", oz_net_h2.h): conv2..4 weights in the h2 layout, pre-scaled by 2^kexp
+    int precision = 0;
+    uint4* d_wh[3] = {nullptr, nullptr, nullptr};
+    float* d_scale_h2[3] = {nullptr, nullptr, nullptr};
+    int* d_flag = nullptr;
+    uint4* d_zero = nullptr;
+    bool h2_attr_set = false;
     std::vector<void*> allocs;
     // profiling of the dominant launch (conv2)
     bool profile = false;
@@ -303,10 +311,60 @@ struct OnnNet : oz_net {
         return OZ_OK;
     }
 
+    int launch_gemm_h2(const void* in, int layer, void* out, int out_h2, const int* d_count, int max_count, int Hin,
+                       int Hout, int pad, hipStream_t s) {
+        H2Geom g;
+        g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = C; g.taps = 9; g.N = C; g.K = 9 * C; g.out_h2 = out_h2;
+        const long long Mmax = (long long)max_count * Hout * Hout;
+        const int num_mt = (int)((Mmax + H2_BM - 1) / H2_BM);
+        const int grid = ((num_mt + 7) / 8) * 8 * (C / H2_BN);
+        if (!h2_attr_set) {
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES));
+            h2_attr_set = true;
+        }
+        hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(512), H2_LDS_BYTES, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
+                           d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag);
+        OZ_HIP(hipGetLastError());
+        return OZ_OK;
+    }
+
+    int check() override {
+        if (!d_flag) return OZ_OK;
+        int f = 0;
+        OZ_HIP(hipMemcpy(&f, d_flag, sizeof(int), hipMemcpyDeviceToHost));
+        if (f) {
+            oz_set_error("an activation exceeded the fp16 range (65504) in precision mode f16x2: results are invalid; "
+                         "use precision f32 for this network");
+            return OZ_ERR_STATE;
+        }
+        return OZ_OK;
+    }
+
+    int forward_h2(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi, float* d_v,
+                   hipStream_t s) {
+        const int P = n * n;
+        const long long threads = (long long)max_count * P * (C / 8);
+        hipLaunchKernelGGL(k_conv1_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, C,
+                           d_w1, d_scale[0], d_shift[0], (uint4*)act1, d_flag);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile && pending.size() > 4096) { if (int rc = collect_profile()) return rc; }
+        if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); OZ_HIP(hipEventRecord(e0, s)); }
+        if (int rc = launch_gemm_h2(act1, 1, act2, 1, d_count, max_count, n, n, 1, s)) return rc;
+        if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
+        if (int rc = launch_gemm_h2(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, s)) return rc;
+        if (int rc = launch_gemm_h2(act3, 3, act4, 0, d_count, max_count, n - 2, n - 4, 0, s)) return rc;
+        if (int rc = launch_gemm(act4, d_wt[3], 4, f1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
+        if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
+        hipLaunchKernelGGL(k_heads, dim3(max_count), dim3(64), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        OZ_HIP(hipGetLastError());
+        return OZ_OK;
+    }
+
     int forward_device(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi,
                        float* d_v, hipStream_t s) override {
         if (!committed) { oz_set_error("network weights not committed (call oz_net_commit)"); return OZ_ERR_STATE; }
         if (max_count > max_batch) { oz_set_error("batch %d exceeds max_batch %d", max_count, max_batch); return OZ_ERR_ARG; }
+        if (precision == 1) return forward_h2(d_own, d_opp, d_count, max_count, d_pi, d_v, s);
         const int P = n * n;
         {
             const long long threads = (long long)max_count * P * (C / 4);
@@ -441,6 +499,35 @@ OZ_API int oz_net_commit(oz_net* net) {
             for (int c = 0; c < Ns[i]; ++c) t[(size_t)c * Ks[i] + k] = src[(size_t)k * Ns[i] + c];
         if (int rc = upload(o, &o->d_wt[i], t)) return rc;
     }
+    if (o->precision == 1) {
+        // conv2..4 in the h2 layout [Cout][K/8][h1 x8 | h2 x8], k = tap*Cin + ci, pre-scaled by an exact power of two
+        for (int i = 0; i < 3; ++i) {
+            const auto& src = o->w[gl[i]];
+            const int K = Ks[i], N = Ns[i];
+            float mx = 0.f;
+            for (float x : src) mx = fmaxf(mx, fabsf(x));
+            const int kexp = mx > 0.f ? (int)floorf(log2f(1000.0f / mx)) : 0;
+            std::vector<uint16_t> h((size_t)N * K * 2);
+            for (int c = 0; c < N; ++c)
+                for (int k = 0; k < K; ++k) {
+                    const float x = ldexpf(src[(size_t)k * N + c], kexp);
+                    const _Float16 h1 = (_Float16)x, h2 = (_Float16)(x - (float)h1);
+                    const size_t base = ((size_t)c * (K / 8) + (k >> 3)) * 16 + (k & 7);
+                    memcpy(&h[base], &h1, 2); memcpy(&h[base + 8], &h2, 2);
+                }
+            if (!o->d_wh[i]) { if (int rc = o->alloc(&o->d_wh[i], h.size() / 8)) return rc; }
+            OZ_HIP(hipMemcpy(o->d_wh[i], h.data(), h.size() * 2, hipMemcpyHostToDevice));
+            std::vector<float> sc(N);
+            std::vector<float> host_scale(N);
+            OZ_HIP(hipMemcpy(host_scale.data(), o->d_scale[i + 1], sizeof(float) * N, hipMemcpyDeviceToHost));
+            for (int c = 0; c < N; ++c) sc[c] = ldexpf(host_scale[c], -kexp);
+            if (int rc = upload(o, &o->d_scale_h2[i], sc)) return rc;
+        }
+        if (!o->d_flag) { if (int rc = o->alloc(&o->d_flag, 1)) return rc; }
+        OZ_HIP(hipMemset(o->d_flag, 0, sizeof(int)));
+        if (!o->d_zero) { if (int rc = o->alloc(&o->d_zero, 16)) return rc; }
+        OZ_HIP(hipMemset(o->d_zero, 0, 256));
+    }
     if (int rc = upload(o, &o->d_wpi, o->w[36])) return rc;
     if (int rc = upload(o, &o->d_bpi, o->w[37])) return rc;
     if (int rc = upload(o, &o->d_wv, o->w[38])) return rc;
@@ -486,6 +573,7 @@ OZ_API int oz_net_predict(oz_net* net, const uint64_t* own, const uint64_t* opp,
     if (!rc) {
         hipMemcpy(pi, d_pi, 4ull * count * n2, hipMemcpyDeviceToHost);
         hipMemcpy(v, d_v, 4ull * count, hipMemcpyDeviceToHost);
+        rc = net->check();
     }
     hipFree(d_own); hipFree(d_opp); hipFree(d_count); hipFree(d_pi); hipFree(d_v);
     return rc;
@@ -525,6 +613,29 @@ OZ_API int oz_net_time_forward(oz_net* net, int count, int iters, float* ms_avg)
     if (rc) return rc;
     OZ_HIP(e);
     return OZ_OK;
+}
+
+// precision: 0 = exact fp32 matrix cores (k_gemm_f32), 1 = f32 via 2 x fp16 split on the 16-bit matrix cores (oz_net_h2.h).
+// Takes effect at the next oz_net_commit.
+OZ_API int oz_net_set_precision(oz_net* net, int mode) {
+    OnnNet* o = as_onn(net);
+    OZ_REQUIRE(o, "not an OthelloNN network");
+    OZ_REQUIRE(mode == 0 || mode == 1, "precision must be 0 (f32) or 1 (f16x2)");
+    OZ_REQUIRE(mode == 0 || o->C % 256 == 0, "precision f16x2 needs channels %% 256 == 0 (got %d)", o->C);
+    std::lock_guard<std::mutex> lk(o->mu);
+    if (o->precision != mode) { o->precision = mode; o->committed = false; }
+    return OZ_OK;
+}
+OZ_API int oz_net_get_precision(const oz_net* net) {
+    const OnnNet* o = as_onn(const_cast<oz_net*>(net));
+    return o ? o->precision : 0;
+}
+// sticky range check of the f16x2 mode (OZ_ERR_STATE if an activation left the fp16 range since the last commit)
+OZ_API int oz_net_check(oz_net* net) {
+    OZ_REQUIRE(net, "null net");
+    std::lock_guard<std::mutex> lk(net->mu);
+    hipSetDevice(net->device);
+    return net->check();
 }
 
 // profiling of the dominant launch (conv2 implicit GEMM): HIP events on the launching stream

@@ -855,7 +855,9 @@ OZ_API int oz_selfplay_sync(oz_selfplay* sp) {
     std::lock_guard<std::mutex> lk(sp->mu);
     hipSetDevice(sp->m->device);
     if (int rc = check_error_flag(sp->m)) return rc;
-    return mcts_collect_eval_time(sp->m);
+    if (int rc = mcts_collect_eval_time(sp->m)) return rc;
+    std::lock_guard<std::mutex> lkn(sp->net->mu);
+    return sp->net->check();
 }
 
 OZ_API int oz_selfplay_get_stats(oz_selfplay* sp, oz_selfplay_stats* out) {

@@ -422,8 +422,10 @@ def _boards(n, count, seed):
     return np.array(own, np.uint64), np.array(opp, np.uint64)
 
 
-@pytest.mark.parametrize("n,channels,batch", [(8, 128, 37), (6, 128, 70), (8, 512, 9), (6, 512, 5)])
-def test_network_vs_float64_oracle(oz, n, channels, batch):
+@pytest.mark.parametrize("n,channels,batch,precision", [
+    (8, 128, 37, "f32"), (6, 128, 70, "f32"), (8, 512, 9, "f32"), (6, 512, 5, "f32"),
+    (8, 256, 37, "f16x2"), (6, 256, 70, "f16x2"), (8, 512, 9, "f16x2"), (6, 512, 5, "f16x2")])
+def test_network_vs_float64_oracle(oz, n, channels, batch, precision):
     """pi and v within 1e-5 (absolute) of the float64 restatement of OthelloNN; every parameter kind random
     (kernels, biases, BN gamma / beta / moving mean / moving variance); logits lifted away from uniform."""
     from othellozero_amd.NNet import NNetWrapper
@@ -431,7 +433,7 @@ def test_network_vs_float64_oracle(oz, n, channels, batch):
     w = init_weights(n, seed=11, channels=channels, randomize_all=True)
     for i in (36, 38):
         w[i] = w[i] * 4.0
-    net = NNetWrapper((n, n), num_channels_1=channels, max_batch=64, weights=w)
+    net = NNetWrapper((n, n), num_channels_1=channels, max_batch=64, weights=w, precision=precision)
     own, opp = _boards(n, batch, seed=n + channels)
     pi, v = net.predict_batch(own, opp)                        # batch > max_batch exercises the chunking too
     pi64, v64 = nn_numpy.forward(w, own, opp, n)
@@ -453,17 +455,36 @@ def test_network_vs_float64_oracle(oz, n, channels, batch):
     assert np.array_equal(pc, pi[:4]) and np.array_equal(vc, v[:4])
 
 
-def test_search_with_real_network_vs_oracle(oz):
+def test_f16x2_range_guard_fails_loudly(oz):
+    """precision f16x2 must refuse (not silently mis-compute) a net whose activations leave the fp16 range"""
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.weights import init_weights
+    w = init_weights(8, seed=4, channels=256, randomize_all=True)
+    w[6] = w[6] * 1.0e6                                   # conv2 kernel: activations far above 65504
+    own, opp = _boards(8, 4, seed=1)
+    net = NNetWrapper((8, 8), num_channels_1=256, max_batch=4, weights=w, precision="f16x2")
+    with pytest.raises(oz.OzError) as ei:
+        net.predict_batch(own, opp)
+    assert ei.value.code == oz.OZ_ERR_STATE and "fp16 range" in str(ei.value)
+    ref = NNetWrapper((8, 8), num_channels_1=256, max_batch=4, weights=w, precision="f32")
+    pi, v = ref.predict_batch(own, opp)                   # the exact-fp32 mode handles the same net
+    assert np.isfinite(pi).all() and np.isfinite(v).all()
+    with pytest.raises(oz.OzError):
+        NNetWrapper((8, 8), num_channels_1=128, precision="f16x2")       # needs channels % 256 == 0
+
+
+@pytest.mark.parametrize("precision,C_", [("f32", 128), ("f16x2", 256)])
+def test_search_with_real_network_vs_oracle(oz, precision, C_):
     """end to end: batched engine + OthelloNN on the GPU == the oracle's search fed with the GPU network's
     own (pi, v) per position (so float rounding in the net cannot excuse a divergent game)."""
     from othellozero_amd.NNet import NNetWrapper
     from othellozero_amd.training import SelfPlayEngine
     from othellozero_amd.weights import init_weights
-    n, C_, G, sims = 6, 128, 16, 30
+    n, G, sims = 6, 16, 30
     w = init_weights(n, seed=2, channels=C_, randomize_all=True)
     for i in (36, 38):
         w[i] = w[i] * 4.0
-    net = NNetWrapper((n, n), num_channels_1=C_, max_batch=G, weights=w)
+    net = NNetWrapper((n, n), num_channels_1=C_, max_batch=G, weights=w, precision=precision)
     eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=31, first_game_id=0, q_mode=1)
     rec = eng.play_to_end()
     cache = {}
