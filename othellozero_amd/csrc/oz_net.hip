@@ -193,31 +193,49 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
 #include "oz_net_h2.h"
 
 // ---------------------------------------------------------------- heads
-// one wave per position: logits[a] = f2 . Wpi[:,a] + bpi[a] -> softmax; v = tanh(f2 . Wv + bv)
+// one wave per HEADS_P positions: logits[a] = f2 . Wpi[:,a] + bpi[a] -> softmax; v = tanh(f2 . Wv + bv).
+// Each Wpi row load (coalesced, one column per lane) feeds HEADS_P positions; the f2 reads are wave-uniform.
+#define HEADS_P 8
 __global__ __launch_bounds__(64) void k_heads(const float* __restrict__ f2 /*[B][512]*/, const int* __restrict__ d_count,
                                               int A, const float* __restrict__ Wpi /*[512][A]*/, const float* __restrict__ bpi,
                                               const float* __restrict__ Wv /*[512]*/, const float* __restrict__ bv,
                                               float* __restrict__ pi, float* __restrict__ v) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= *d_count) return;
-    const float* x = f2 + (size_t)b * 512;
-    float logit = 0.f, vpart = 0.f;
+    const int b0 = blockIdx.x * HEADS_P, lane = threadIdx.x, count = *d_count;
+    if (b0 >= count) return;
     const bool act = lane < A;
+    const float* x[HEADS_P];
+#pragma unroll
+    for (int p = 0; p < HEADS_P; ++p) x[p] = f2 + (size_t)(b0 + p < count ? b0 + p : count - 1) * 512;
+    float logit[HEADS_P], vpart[HEADS_P];
+#pragma unroll
+    for (int p = 0; p < HEADS_P; ++p) { logit[p] = 0.f; vpart[p] = 0.f; }
     for (int i = 0; i < 512; ++i) {
-        const float xi = x[i];
-        if (act) logit = fmaf(xi, Wpi[(size_t)i * A + lane], logit);
+        const float w = act ? Wpi[(size_t)i * A + lane] : 0.f;
+#pragma unroll
+        for (int p = 0; p < HEADS_P; ++p) logit[p] = fmaf(x[p][i], w, logit[p]);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) vpart = fmaf(x[lane * 8 + i], Wv[lane * 8 + i], vpart);
-    logit = act ? logit + bpi[lane] : -INFINITY;
-    float mx = logit;
+    for (int i = 0; i < 8; ++i) {
+        const float wv = Wv[lane * 8 + i];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    float e = act ? expf(logit - mx) : 0.f, s = e;
+        for (int p = 0; p < HEADS_P; ++p) vpart[p] = fmaf(x[p][lane * 8 + i], wv, vpart[p]);
+    }
+    const float bl = act ? bpi[lane] : 0.f, bvv = bv[0];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); vpart += __shfl_xor(vpart, off, 64); }
-    if (act) pi[(size_t)b * A + lane] = e / s;
-    if (lane == 0) v[b] = tanhf(vpart + bv[0]);
+    for (int p = 0; p < HEADS_P; ++p) {
+        const float lg = act ? logit[p] + bl : -INFINITY;
+        float mx = lg, vp = vpart[p];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float e = act ? expf(lg - mx) : 0.f;
+        float s = e;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); vp += __shfl_xor(vp, off, 64); }
+        if (b0 + p < count) {
+            if (act) pi[(size_t)(b0 + p) * A + lane] = e / s;
+            if (lane == 0) v[b0 + p] = tanhf(vp + bvv);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- stub evaluator (test nets)
@@ -268,8 +286,8 @@ struct OnnNet : oz_net {
     float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *act4 = nullptr, *f1 = nullptr, *f2 = nullptr;
     // precision 1 ("f32 via 2 x fp16 split", oz_net_h2.h): conv2..4 weights in the h2 layout, pre-scaled by 2^kexp
     int precision = 0;
-    uint4* d_wh[3] = {nullptr, nullptr, nullptr};
-    float* d_scale_h2[3] = {nullptr, nullptr, nullptr};
+    uint4* d_wh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // conv2..4, fc1, fc2
+    float* d_scale_h2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int* d_flag = nullptr;
     uint4* d_zero = nullptr;
     bool h2_attr_set = false;
@@ -311,18 +329,21 @@ struct OnnNet : oz_net {
         return OZ_OK;
     }
 
+    // layer: 1..3 = conv2..4 (3x3, Cin = N = C), 4 = fc1, 5 = fc2 (taps 1)
+    template <typename CF>
     int launch_gemm_h2(const void* in, int layer, void* out, int out_h2, const int* d_count, int max_count, int Hin,
-                       int Hout, int pad, hipStream_t s) {
+                       int Hout, int pad, int Cin, int taps, int N, hipStream_t s) {
         H2Geom g;
-        g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = C; g.taps = 9; g.N = C; g.K = 9 * C; g.out_h2 = out_h2;
+        g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.out_h2 = out_h2; g.relu = 1;
         const long long Mmax = (long long)max_count * Hout * Hout;
-        const int num_mt = (int)((Mmax + H2_BM - 1) / H2_BM);
-        const int grid = ((num_mt + 7) / 8) * 8 * (C / H2_BN);
+        const int num_mt = (int)((Mmax + CF::BM - 1) / CF::BM);
+        const int grid = ((num_mt + 7) / 8) * 8 * (N / CF::BN);
         if (!h2_attr_set) {
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Big>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Big::LDS));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
             h2_attr_set = true;
         }
-        hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(512), H2_LDS_BYTES, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
+        hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
                            d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
@@ -342,20 +363,19 @@ struct OnnNet : oz_net {
 
     int forward_h2(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi, float* d_v,
                    hipStream_t s) {
-        const int P = n * n;
-        const long long threads = (long long)max_count * P * (C / 8);
+        const long long threads = (long long)max_count * n * (C / 8);       // one thread per (board row, 8 channels)
         hipLaunchKernelGGL(k_conv1_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, C,
                            d_w1, d_scale[0], d_shift[0], (uint4*)act1, d_flag);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && pending.size() > 4096) { if (int rc = collect_profile()) return rc; }
         if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); OZ_HIP(hipEventRecord(e0, s)); }
-        if (int rc = launch_gemm_h2(act1, 1, act2, 1, d_count, max_count, n, n, 1, s)) return rc;
+        if (int rc = launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
         if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
-        if (int rc = launch_gemm_h2(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, s)) return rc;
-        if (int rc = launch_gemm_h2(act3, 3, act4, 0, d_count, max_count, n - 2, n - 4, 0, s)) return rc;
-        if (int rc = launch_gemm(act4, d_wt[3], 4, f1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
-        if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
-        hipLaunchKernelGGL(k_heads, dim3(max_count), dim3(64), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        if (int rc = launch_gemm_h2<H2Big>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
+        if (int rc = launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
+        if (int rc = launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
+        if (int rc = launch_gemm_h2<H2Small>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
+        hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(64), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
     }
@@ -380,7 +400,7 @@ struct OnnNet : oz_net {
         if (int rc = launch_gemm(act3, d_wt[2], 3, act4, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
         if (int rc = launch_gemm(act4, d_wt[3], 4, f1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
         if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
-        hipLaunchKernelGGL(k_heads, dim3(max_count), dim3(64), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(64), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
     }
@@ -501,7 +521,7 @@ OZ_API int oz_net_commit(oz_net* net) {
     }
     if (o->precision == 1) {
         // conv2..4 in the h2 layout [Cout][K/8][h1 x8 | h2 x8], k = tap*Cin + ci, pre-scaled by an exact power of two
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 5; ++i) {
             const auto& src = o->w[gl[i]];
             const int K = Ks[i], N = Ns[i];
             float mx = 0.f;

@@ -1,4 +1,4 @@
-// oz_net_h2.h -- "f32 via 2 x fp16 split" convolution kernels (included by oz_net.hip).
+// oz_net_h2.h -- "f32 via 2 x fp16 split" convolution / dense kernels (included by oz_net.hip).
 //
 // Why: OthelloNN is fp32 and the fp32 matrix cores peak at 157 TFLOP/s (1/16 of the 16-bit MFMA rate).
 // Every fp32 value x is carried as two fp16 planes  x = h1 + h2,  h1 = fp16(x), h2 = fp16(x - h1)
@@ -15,29 +15,39 @@
 // group  [h1 x 8][h2 x 8]; a row of K values is K/8 groups = 4*K bytes (same footprint as fp32).
 // A lane of a 32x32x16 MFMA needs 8 consecutive k of one plane = one aligned 16-byte read.
 //
-// Kernel: implicit GEMM, block tile 256 x 256 x 32, 512 threads = 8 waves (2 x 4), wave tile 128 x 64
-// = 4 x 2 MFMA tiles (128 accumulator registers).  Both operand tiles (256 rows x 128 B) go global -> LDS
-// with 16-byte LDS-DMA (global_load_lds_dwordx4, no staging registers, no ds_write pass): the LDS image is
-// lane-linear per wave instruction (8 rows of 8 chunks), made bank-conflict-free by XOR-swizzling the
-// 16-byte chunk index with (row>>1)&7 on the SOURCE address and on the read address; A rows are gathered
-// per 3x3 tap, out-of-image taps read a zero line.  Two LDS buffers, one barrier per k-tile.
-// Epilogue = BN scale/shift + ReLU, then fp32 rows or the h2 layout for the next layer (transposed through
-// LDS so that global stores are 16-byte chunks of whole pixel rows).
+// Kernel: implicit GEMM, k-tile 32.  Both operand tiles (rows x 128 B) go global -> LDS with 16-byte
+// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass); the LDS image is
+// lane-linear per wave instruction (8 rows of 8 chunks) and made bank-conflict-free by XOR-swizzling the
+// 16-byte chunk index with (row>>1)&7 on the SOURCE address and on the read address (measured
+// SQ_LDS_BANK_CONFLICT = 0); A rows are gathered per 3x3 tap, out-of-image taps read a zero line.
+// Two LDS buffers, one barrier per k-tile.  Epilogue = BN scale/shift + ReLU, then fp32 rows or the h2
+// layout for the next layer (transposed through LDS so that global stores are 16-byte chunks of whole rows).
 #pragma once
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-#define H2_BM 256
-#define H2_BN 256
 #define H2_BK 32
-#define H2_TILEB (H2_BM * 128)            // one operand tile: 256 rows x 128 B = 32 768 B
-#define H2_LDS_BYTES (4 * H2_TILEB)       // [buf][A|B] = 131 072 B
 #define H2_F16_MAX 65504.0f
+
+// tile configurations: NWM x NWN waves, each wave NTI x NTJ MFMA tiles of 32 x 32
+//   H2Big   (3x3 convolutions): 2 x 4 waves, wave tile 128 x 64 -> block 256 x 256, 512 threads, 128 KB LDS
+//   H2Small (dense layers):     2 x 2 waves, wave tile  64 x 64 -> block 128 x 128, 256 threads,  64 KB LDS
+template <int NWM, int NWN, int NTI, int NTJ> struct H2Cfg {
+    static constexpr int WM = NWM, WN = NWN, TI = NTI, TJ = NTJ;
+    static constexpr int BM = NWM * NTI * 32, BN = NWN * NTJ * 32, NW = NWM * NWN, NT = NW * 64;
+    static constexpr int TILEA = BM * 128, TILEB = BN * 128, BUF = TILEA + TILEB, LDS = 2 * BUF;
+    static constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW);     // LDS-DMA instructions per wave per operand tile
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NTI % 2 == 0, "tile shape");
+    static_assert(NW * 16384 <= LDS, "epilogue slices must fit in the staging buffers");
+};
+typedef H2Cfg<2, 4, 4, 2> H2Big;
+typedef H2Cfg<2, 2, 2, 2> H2Small;
 
 struct H2Geom {
     int Hin, Hout, pad, Cin, taps;        // taps 9 (3x3 conv) or 1 (dense, Hin = Hout = 1)
     int N, K;                             // output channels, taps * Cin
     int out_h2;                           // 1: write the h2 layout, 0: write fp32 rows
+    int relu;
 };
 
 __device__ __forceinline__ void h2_split(float x, _Float16& h1, _Float16& h2) {
@@ -48,83 +58,109 @@ __device__ __forceinline__ void h2_split(float x, _Float16& h1, _Float16& h2) {
 typedef const __attribute__((address_space(1))) void* h2_gptr;
 typedef __attribute__((address_space(3))) void* h2_lptr;
 
-// conv1 + plane unpack, output in the h2 layout: one thread per (row m, group of 8 channels)
+// conv1 + plane unpack, output in the h2 layout.  One thread = one board row (n pixels) x 8 channels: the 18
+// weight vectors are loaded once per thread and applied to the row's pixels (input bits tested in registers).
 __global__ __launch_bounds__(256) void k_conv1_h2(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
                                                   const int* __restrict__ d_count, int n, int C,
                                                   const float* __restrict__ W /*[9][2][C]*/, const float* __restrict__ scale,
                                                   const float* __restrict__ shift, uint4* __restrict__ out, int* __restrict__ flag) {
-    const int P = n * n, cg = C >> 3;
-    const long long M = (long long)(*d_count) * P;
+    const int cg = C >> 3;
+    const long long R = (long long)(*d_count) * n;                  // board rows
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long m = idx / cg;
-    if (m >= M) return;
+    const long long br = idx / cg;
+    if (br >= R) return;
     const int c8 = (int)(idx % cg) * 8;
-    const int b = (int)(m / P), pix = (int)(m % P), y = pix / n, x = pix % n;
+    const int b = (int)(br / n), y = (int)(br % n);
     const uint64_t o = own[b], p = opp[b];
-    float acc[8];
+    float acc[8][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int x = 0; x < 8; ++x)
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+        for (int j = 0; j < 8; ++j) acc[x][j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y + ky - 1;
+        if (iy < 0 || iy >= n) continue;
+        const unsigned ro = (unsigned)((o >> (iy * 8)) & 0xFF), rp = (unsigned)((p >> (iy * 8)) & 0xFF);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int iy = y + ky - 1, ix = x + kx - 1;
-            if (iy < 0 || iy >= n || ix < 0 || ix >= n) continue;
-            const int sq = iy * 8 + ix;
-            const float a0 = (float)((o >> sq) & 1), a1 = (float)((p >> sq) & 1);
-            const float* w0 = W + (size_t)((ky * 3 + kx) * 2 + 0) * C + c8;
-            const float* w1 = W + (size_t)((ky * 3 + kx) * 2 + 1) * C + c8;
+            const f32x4 w0a = *reinterpret_cast<const f32x4*>(W + (size_t)((ky * 3 + kx) * 2 + 0) * C + c8);
+            const f32x4 w0b = *reinterpret_cast<const f32x4*>(W + (size_t)((ky * 3 + kx) * 2 + 0) * C + c8 + 4);
+            const f32x4 w1a = *reinterpret_cast<const f32x4*>(W + (size_t)((ky * 3 + kx) * 2 + 1) * C + c8);
+            const f32x4 w1b = *reinterpret_cast<const f32x4*>(W + (size_t)((ky * 3 + kx) * 2 + 1) * C + c8 + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(a0, w0[j], acc[j]);
+            for (int x = 0; x < 8; ++x) {
+                const int ix = x + kx - 1;
+                if (ix < 0 || ix >= 8) continue;                    // columns >= n are never occupied
+                const float a0 = (float)((ro >> ix) & 1), a1 = (float)((rp >> ix) & 1);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(a1, w1[j], acc[j]);
+                for (int j = 0; j < 4; ++j) {
+                    acc[x][j] = fmaf(a0, w0a[j], acc[x][j]);
+                    acc[x][j + 4] = fmaf(a0, w0b[j], acc[x][j + 4]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[x][j] = fmaf(a1, w1a[j], acc[x][j]);
+                    acc[x][j + 4] = fmaf(a1, w1b[j], acc[x][j + 4]);
+                }
+            }
         }
-    f16x8 h1, h2;
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale[c8 + j]; sh[j] = shift[c8 + j]; }
     bool over = false;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float v = fmaxf(fmaf(acc[j], scale[c8 + j], shift[c8 + j]), 0.f);
-        over |= v > H2_F16_MAX;
-        _Float16 a, bb;
-        h2_split(v, a, bb);
-        h1[j] = a; h2[j] = bb;
+    for (int x = 0; x < 8; ++x) {
+        if (x >= n) continue;
+        f16x8 h1, h2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = fmaxf(fmaf(acc[x][j], sc[j], sh[j]), 0.f);
+            over |= v > H2_F16_MAX;
+            _Float16 a, bb;
+            h2_split(v, a, bb);
+            h1[j] = a; h2[j] = bb;
+        }
+        uint4* dst = out + ((size_t)(br * n + x) * cg + (c8 >> 3)) * 2;
+        dst[0] = *reinterpret_cast<uint4*>(&h1);
+        dst[1] = *reinterpret_cast<uint4*>(&h2);
     }
     if (over) atomicOr(flag, 1);
-    uint4* dst = out + ((size_t)m * cg + (c8 >> 3)) * 2;
-    dst[0] = *reinterpret_cast<uint4*>(&h1);
-    dst[1] = *reinterpret_cast<uint4*>(&h2);
 }
 
-// out[M][N] = relu((A[M][K] . W[N][K]^T) * scale + shift); A and W in the h2 layout; M = *d_count * Hout^2.
+// out[M][N] = act((A[M][K] . W[N][K]^T) * scale + shift); A and W in the h2 layout; M = *d_count * Hout^2.
 // zero_line: >= 128 B of zeros in global memory (source of out-of-image taps and of rows beyond M).
-__global__ __launch_bounds__(512, 2) void k_gemm_h2(const uint4* __restrict__ in, const uint4* __restrict__ Wh,
-                                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    void* __restrict__ out, const int* __restrict__ d_count, H2Geom g,
-                                                    int num_mt, const uint4* __restrict__ zero_line, int* __restrict__ flag) {
+template <typename CF>
+__global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__ in, const uint4* __restrict__ Wh,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       void* __restrict__ out, const int* __restrict__ d_count, H2Geom g,
+                                                       int num_mt, const uint4* __restrict__ zero_line, int* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nnt = g.N / H2_BN;
+    constexpr int BM = CF::BM, BN = CF::BN, TI = CF::TI, TJ = CF::TJ, IA = CF::IA, IB = CF::IB;
+    const int nnt = g.N / BN;
     const int id = blockIdx.x, xcd = id & 7, jb = id >> 3;
     const int mt = (jb / nnt) * 8 + xcd, nt = jb % nnt;
     const int P = g.Hout * g.Hout;
     const long long M = (long long)(*d_count) * P;
-    if (mt >= num_mt || (long long)mt * H2_BM >= M) return;
+    if (mt >= num_mt || (long long)mt * BM >= M) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves, wave tile 128 rows x 64 cols
+    const int wm = wave / CF::WN, wn = wave % CF::WN;
     const int rowq = g.Cin >> 2;                             // uint4 (16 B) units per input pixel row: Cin/8 groups * 2
     const int wrowq = g.K >> 2;                              // uint4 units per weight row
 
-    // staging map: wave w, DMA instruction i (0..3) fills LDS rows (w*4+i)*8 .. +7; lane l -> row +(l>>3), physical
-    // chunk l&7, which holds logical chunk (l&7) ^ ((row>>1)&7) of that row's 128-byte k-slice
-    long long aidx[4];       // uint4 index of (row's input pixel at tap (0,0), logical chunk), or -1
-    unsigned amask[4];
-    unsigned bidx[4];
+    // staging map: wave w, DMA instruction i fills LDS rows (w*I + i)*8 .. +7 of the operand tile; lane l -> row
+    // +(l>>3), physical chunk l&7, which holds logical chunk (l&7) ^ ((row>>1)&7) of that row's 128-byte k-slice
+    long long aidx[IA];      // uint4 index of (row's input pixel at tap (0,0), logical chunk)
+    unsigned amask[IA];
+    unsigned bidx[IB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < IA; ++i) {
+        const int row = (wave * IA + i) * 8 + (lane >> 3);
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        const long long m = (long long)mt * H2_BM + row;
+        const long long m = (long long)mt * BM + row;
         aidx[i] = 0; amask[i] = 0;
         if (m < M) {
             const int b = (int)(m / P), pix = (int)(m % P), oy = pix / g.Hout, ox = pix % g.Hout;
@@ -136,28 +172,37 @@ __global__ __launch_bounds__(512, 2) void k_gemm_h2(const uint4* __restrict__ in
             }
             amask[i] = mk;
         }
-        bidx[i] = (unsigned)(nt * H2_BN + row) * (unsigned)wrowq + (unsigned)lc;
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        const int row = (wave * IB + i) * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        bidx[i] = (unsigned)(nt * BN + row) * (unsigned)wrowq + (unsigned)lc;
     }
     const uint4* zsrc = zero_line + (lane & 7);
 
     auto stage = [&](int kt, int buf) {
         const int k0 = kt * H2_BK, tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin;
         const long long toff = ((long long)(tap / 3) * g.Hin + (tap % 3)) * rowq + (ci0 >> 2);   // 32 ch = 8 uint4
-        unsigned char* la = smem + (size_t)buf * 2 * H2_TILEB + wave * 4096;
+        unsigned char* la = smem + (size_t)buf * CF::BUF + wave * IA * 1024;
+        unsigned char* lb = smem + (size_t)buf * CF::BUF + CF::TILEA + wave * IB * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < IA; ++i) {
             const uint4* ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + toff) : zsrc;
-            const uint4* gb = Wh + bidx[i] + (k0 >> 2);
             __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((h2_gptr)gb, (h2_lptr)(la + H2_TILEB + i * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const uint4* gb = Wh + bidx[i] + (k0 >> 2);
+            __builtin_amdgcn_global_load_lds((h2_gptr)gb, (h2_lptr)(lb + i * 1024), 16, 0, 0);
         }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -173,23 +218,23 @@ __global__ __launch_bounds__(512, 2) void k_gemm_h2(const uint4* __restrict__ in
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const unsigned char* At = smem + (size_t)buf * 2 * H2_TILEB + (wm * 128 + r32) * 128;
-        const unsigned char* Bt = smem + (size_t)buf * 2 * H2_TILEB + H2_TILEB + (wn * 64 + r32) * 128;
+        const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * TI * 32 + r32) * 128;
+        const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * TJ * 32 + r32) * 128;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int oh1 = s ? o10 : o00, oh2 = s ? o11 : o01;
-            f16x8 b1[2], b2[2];
+            f16x8 b1[TJ], b2[TJ];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TJ; ++j) {
                 b1[j] = *reinterpret_cast<const f16x8*>(Bt + j * 32 * 128 + oh1);
                 b2[j] = *reinterpret_cast<const f16x8*>(Bt + j * 32 * 128 + oh2);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < TI; ++i) {
                 const f16x8 a1 = *reinterpret_cast<const f16x8*>(At + i * 32 * 128 + oh1);
                 const f16x8 a2 = *reinterpret_cast<const f16x8*>(At + i * 32 * 128 + oh2);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < TJ; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[j], acc[i][j], 0, 0, 0);
@@ -203,40 +248,44 @@ __global__ __launch_bounds__(512, 2) void k_gemm_h2(const uint4* __restrict__ in
     if (!g.out_h2) {
         float* o = reinterpret_cast<float*>(out);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = nt * H2_BN + wn * 64 + j * 32 + r32;
+        for (int j = 0; j < TJ; ++j) {
+            const int col = nt * BN + wn * TJ * 32 + j * 32 + r32;
             const float sc = scale[col], sh = shift[col];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long long m = (long long)mt * H2_BM + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (m < M) o[(size_t)m * g.N + col] = fmaxf(fmaf(acc[i][j][r], sc, sh), 0.f);
+                    const long long m = (long long)mt * BM + wm * TI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = fmaf(acc[i][j][r], sc, sh);
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (m < M) o[(size_t)m * g.N + col] = v;
                 }
         }
         return;
     }
-    // h2 output: each wave transposes its 128 x 64 tile through its own 16 KB LDS slice in two halves of 64 rows:
-    // slice[row][group(8)][plane(2)][8 halfs] = 256 B per row; then 16-byte chunks go out, 16 lanes per pixel row.
+    // h2 output: each wave transposes its tile through its own 16 KB LDS slice, 64 rows x (TJ*32 = 64 channels) at a
+    // time: slice[row][group(8)][plane(2)][8 halfs] = 256 B per row; then 16-byte chunks go out, 16 lanes per row.
+    static_assert(TJ == 2, "the h2 epilogue assumes a 64-channel wave tile");
     bool over = false;
     _Float16* slice = reinterpret_cast<_Float16*>(smem + wave * 16384);
     uint4* o = reinterpret_cast<uint4*>(out);
-    const int nq = g.N >> 2;                                // uint4 units per output pixel row (N/8 groups * 2)
+    const int nq = g.N >> 2;                                // uint4 units per output row (N/8 groups * 2)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < TI / 2; ++hh) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const int i = hh * 2 + ii;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TJ; ++j) {
                 const int lc = j * 32 + r32;                 // column inside the wave tile
-                const int col = nt * H2_BN + wn * 64 + lc;
+                const int col = nt * BN + wn * TJ * 32 + lc;
                 const float sc = scale[col], sh = shift[col];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int lr = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // row inside the 64-row half
-                    const float v = fmaxf(fmaf(acc[i][j][r], sc, sh), 0.f);
-                    over |= v > H2_F16_MAX;
+                    const int lr = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // row inside the 64-row pass
+                    float v = fmaf(acc[i][j][r], sc, sh);
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    over |= fabsf(v) > H2_F16_MAX;
                     _Float16 h1, h2;
                     h2_split(v, h1, h2);
                     _Float16* p = slice + lr * 128 + (lc >> 3) * 16 + (lc & 7);
@@ -250,9 +299,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_h2(const uint4* __restrict__ in
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int q = c * 64 + lane, lr = q >> 4, cq = q & 15;
-            const long long m = (long long)mt * H2_BM + wm * 128 + hh * 64 + lr;
+            const long long m = (long long)mt * BM + wm * TI * 32 + hh * 64 + lr;
             const uint4 val = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(slice) + lr * 256 + cq * 16);
-            if (m < M) o[(size_t)m * nq + ((nt * H2_BN + wn * 64) >> 2) + cq] = val;
+            if (m < M) o[(size_t)m * nq + ((nt * BN + wn * TJ * 32) >> 2) + cq] = val;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
