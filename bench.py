@@ -32,6 +32,34 @@ def conv2_flop_per_leaf(n, C):
     return 2 * (n * n) * (9 * C) * C                       # 8x8: 301 989 888 FLOP
 
 
+PEAK_F16_MATRIX_TFLOPS = 2500.0                            # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16 MFMA
+
+
+def roofline(precision, achieved, conv2_ms, launches, expansions, n, channels):
+    """Dominant kernel = the conv2 launch (53 % of the network's FLOPs).  `achieved` is ALGORITHMIC fp32 TFLOP/s
+    (2*M*K*N per launch / HIP-event time on the launch stream).  precision f32: v_mfma_f32_32x32x2_f32, peak 157.3.
+    precision f16x2: every fp32 product costs 3 fp16 MFMA products, so the matrix pipe executes 3x `achieved`;
+    both fractions are reported against the 2.5 PFLOP/s dense fp16 peak."""
+    hbm = None
+    try:      # HBM-side bytes per leaf from the committed PMC profile of this kernel (profiles/), scaled per launch
+        tj = json.load(open(os.path.join(ROOT, "profiles", f"conv2_traffic_{precision}.json")))
+        hbm = tj["hbm_bytes_per_leaf"] * expansions / max(launches, 1)
+    except Exception:
+        pass
+    r = {"bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "traffic": hbm, "launches": int(launches),
+         "avg_launch_ms": conv2_ms / max(launches, 1), "flop_per_leaf": conv2_flop_per_leaf(n, channels)}
+    if precision == "f32":
+        r.update(kernel="k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                 peak=PEAK_F32_MATRIX_TFLOPS, frac=achieved / PEAK_F32_MATRIX_TFLOPS)
+    else:
+        r.update(kernel="k_gemm_h2_s16 (conv2: 3x3 same, 512->512, implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16)",
+                 peak=PEAK_F16_MATRIX_TFLOPS, frac=achieved / PEAK_F16_MATRIX_TFLOPS,
+                 mfma_products_per_fp32_product=3, matrix_pipe_tflops=3 * achieved,
+                 matrix_pipe_frac=3 * achieved / PEAK_F16_MATRIX_TFLOPS,
+                 vs_fp32_matrix_peak=achieved / PEAK_F32_MATRIX_TFLOPS)
+    return r
+
+
 def cpu_baseline(n, channels, sims, budget_s=15.0):
     """The oracle port of the reference path (sequential simulations, one game, batch-1 leaf evaluation by the
     float32 C restatement of OthelloNN on all host cores), timed on a bounded sample: the first plies of one game."""
@@ -151,14 +179,9 @@ def main():
             "pooled_records": int(pooled.shape[0]),
             "nn_forward_ms_total_rank0": nn_ms, "nn_fraction_of_wall_rank0": nn_ms * 1e-3 / dt,
             "whole_net_tflops_rank0": d["expansions"] * FLOP_PER_EXPANSION.get(n, 0) / max(nn_ms * 1e-3, 1e-9) / 1e12,
-            "roofline": {
-                "kernel": "k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
-                "launches": int(conv2_launches), "avg_launch_ms": conv2_ms / max(conv2_launches, 1),
-                "flop_per_leaf": conv2_flop_per_leaf(n, args.channels),
-            },
+            "roofline": roofline(args.precision, achieved, conv2_ms, conv2_launches, d["expansions"], n, args.channels),
         }
+        out["dtype"] = "f32" if args.precision == "f32" else "f32 as 2xfp16 split (3 fp16 MFMA products per fp32 product, f32 accumulate)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.channels, args.sims)
         print(json.dumps(out), flush=True)

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libothellozero_amd.so")
+LIB_PATH = os.environ.get("OZ_LIB_PATH") or os.path.join(_HERE, "lib", "libothellozero_amd.so")
 
 OZ_OK, OZ_ERR_HIP, OZ_ERR_ARG, OZ_ERR_CAPACITY, OZ_ERR_KEY, OZ_ERR_STATE = range(6)
 QMODE_NEP50, QMODE_F64 = 0, 1

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libothellozero_amd.so")
 SOURCES = ["oz_rules.hip", "oz_search.hip", "oz_net.hip"]
-HEADERS = ["oz_common.h", "oz_internal.h", os.path.join("..", "..", "include", "othellozero_amd.h")]
+HEADERS = ["oz_common.h", "oz_internal.h", "oz_net_h2.h", os.path.join("..", "..", "include", "othellozero_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
@@ -44,7 +44,7 @@ def build(force=False, verbose=False):
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([_hipcc()] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([_hipcc()] + FLAGS + os.environ.get("OZ_EXTRA_FLAGS", "").split() + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
