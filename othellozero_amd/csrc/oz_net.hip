@@ -191,7 +191,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
 }
 
 #include "oz_net_h2.h"
-#include "oz_net_h2w4.h"
 
 // ---------------------------------------------------------------- heads
 // one wave per HEADS_P positions: logits[a] = f2 . Wpi[:,a] + bpi[a] -> softmax; v = tanh(f2 . Wv + bv).
@@ -292,7 +291,6 @@ struct OnnNet : oz_net {
     int* d_flag = nullptr;
     uint4* d_zero = nullptr;
     bool h2_attr_set = false;
-    int h2_kernel = 3;       // default: 8-wave two-stage kernel on the 16x16x32 shape (fastest measured; OZ_H2_KERNEL switches)
     std::vector<void*> allocs;
     // profiling of the dominant launch (conv2)
     bool profile = false;
@@ -343,31 +341,10 @@ struct OnnNet : oz_net {
         if (!h2_attr_set) {
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Big>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Big::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2_ring<H2Big>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Big::LDS));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2_ring<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
             h2_attr_set = true;
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2_w4, hipFuncAttributeMaxDynamicSharedMemorySize, H2W4::LDS));
-            const char* e = getenv("OZ_H2_KERNEL");          // kernel A/B switch: 0 = 8-wave 2-stage, 1 = 4-stage ring, 2 = 4-wave pipelined
-            if (e) h2_kernel = atoi(e);
         }
-        if (h2_kernel == 3) {     // 16x16x32 MFMA shape
-            static bool attr16 = false;
-            if (!attr16) {
-                OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2_s16<H2Big>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Big::LDS));
-                OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2_s16<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
-                attr16 = true;
-            }
-            hipLaunchKernelGGL(k_gemm_h2_s16<CF>, dim3(grid), dim3(CF::NT), CF::LDS, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
-                               d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag);
-        } else if (h2_kernel == 2 && CF::BM == 256 && CF::BN == 256)
-            hipLaunchKernelGGL(k_gemm_h2_w4, dim3(grid), dim3(H2W4::NT), H2W4::LDS, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
-                               d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag);
-        else if (h2_kernel == 1)      // 4-stage LDS ring, k-tile 16, counted vmcnt (same LDS footprint: 4 x (BM+BN) x 64 B)
-            hipLaunchKernelGGL(k_gemm_h2_ring<CF>, dim3(grid), dim3(CF::NT), CF::LDS, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
-                               d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag);
-        else
-            hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
-                               d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag);
+        hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
+                           d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
     }
@@ -551,11 +528,15 @@ OZ_API int oz_net_commit(oz_net* net) {
             for (float x : src) mx = fmaxf(mx, fabsf(x));
             const int kexp = mx > 0.f ? (int)floorf(log2f(1000.0f / mx)) : 0;
             std::vector<uint16_t> h((size_t)N * K * 2);
+            // kernel k order (oz_net_h2.h): k' = (slice*taps + tap)*32 + c32  <->  keras k = tap*Cin + slice*32 + c32
+            const int taps = i < 3 ? 9 : 1, Cin = K / taps;
             for (int c = 0; c < N; ++c)
-                for (int k = 0; k < K; ++k) {
+                for (int kp = 0; kp < K; ++kp) {
+                    const int tile = kp >> 5, c32 = kp & 31, slice = tile / taps, tap = tile - slice * taps;
+                    const int k = tap * Cin + slice * 32 + c32;
                     const float x = ldexpf(src[(size_t)k * N + c], kexp);
                     const _Float16 h1 = (_Float16)x, h2 = (_Float16)(x - (float)h1);
-                    const size_t base = ((size_t)c * (K / 8) + (k >> 3)) * 16 + (k & 7);
+                    const size_t base = ((size_t)c * (K / 8) + (kp >> 3)) * 16 + (kp & 7);
                     memcpy(&h[base], &h1, 2); memcpy(&h[base + 8], &h2, 2);
                 }
             if (!o->d_wh[i]) { if (int rc = o->alloc(&o->d_wh[i], h.size() / 8)) return rc; }

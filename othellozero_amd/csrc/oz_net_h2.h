@@ -2,10 +2,10 @@
 //
 // Why: OthelloNN is fp32 and the fp32 matrix cores peak at 157 TFLOP/s (1/16 of the 16-bit MFMA rate).
 // Every fp32 value x is carried as two fp16 planes  x = h1 + h2,  h1 = fp16(x), h2 = fp16(x - h1)
-// (22 significand bits), and a product is evaluated as  a1*b1 + a1*b2 + a2*b1  on
-// v_mfma_f32_32x32x16_f16 with fp32 accumulation: the dropped a2*b2 term and the split residuals are
-// <= 2^-22 relative -- the same class as fp32 accumulation error over K = 4608 (measured: |d pi|, |d v|
-// <= 1e-5 vs float64 in tests/test_gpu_parity.py, like the fp32 path).  3 MFMAs at 16x the fp32 rate.
+// (22 significand bits), and a product is evaluated as  a1*b1 + a1*b2 + a2*b1  on the fp16 matrix cores
+// with fp32 accumulation: the dropped a2*b2 term and the split residuals are <= 2^-22 relative -- the same
+// class as fp32 accumulation error over K = 4608 (measured: |d pi|, |d v| <= 1e-5 vs float64 in
+// tests/test_gpu_parity.py, like the fp32 path).  3 MFMAs at 16x the fp32 rate.
 // Range: weights are pre-scaled per layer by an exact power of two so max|w| ~ 2^9..2^10 (the inverse
 // goes into the BN scale); activations (post-ReLU) must stay below 65504 -- the epilogue raises a
 // sticky device flag otherwise and the host reports it (use precision f32 for such a net), never a
@@ -13,23 +13,35 @@
 //
 // Storage ("h2 layout"): for a row (pixel or output channel) every 8 consecutive k are one 32-byte
 // group  [h1 x 8][h2 x 8]; a row of K values is K/8 groups = 4*K bytes (same footprint as fp32).
-// A lane of a 32x32x16 MFMA needs 8 consecutive k of one plane = one aligned 16-byte read.
+// Weight rows are stored in the kernel's k-tile order: k' = (slice*taps + tap)*32 + c  for channel 32*slice + c,
+// i.e. the 9 taps of one 32-channel slice are consecutive k-tiles, so the 9 shifted re-reads of the same
+// activation rows happen back to back (L1/L2 hits instead of re-fetching past L2).
 //
-// Kernel: implicit GEMM, k-tile 32.  Both operand tiles (rows x 128 B) go global -> LDS with 16-byte
-// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass); the LDS image is
-// lane-linear per wave instruction (8 rows of 8 chunks) and made bank-conflict-free by XOR-swizzling the
-// 16-byte chunk index with (row>>1)&7 on the SOURCE address and on the read address (measured
-// SQ_LDS_BANK_CONFLICT = 0); A rows are gathered per 3x3 tap, out-of-image taps read a zero line.
-// Two LDS buffers, one barrier per k-tile.  Epilogue = BN scale/shift + ReLU, then fp32 rows or the h2
-// layout for the next layer (transposed through LDS so that global stores are 16-byte chunks of whole rows).
+// Kernel k_gemm_h2: implicit GEMM, k-tile 32, on v_mfma_f32_16x16x32_f16 (one MFMA consumes the whole k-tile;
+// lane l holds row/column l&15 and k-group l>>4 = one aligned 16-byte LDS read per plane).  Both operand tiles
+// (rows x 128 B) go global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write pass); the LDS image is lane-linear per wave instruction (8 rows of 8 chunks) and made
+// bank-conflict-free by XOR-swizzling the 16-byte chunk index with (row>>1)&7 on the SOURCE address and on the
+// read address (measured SQ_LDS_BANK_CONFLICT = 0); A rows are gathered per 3x3 tap, out-of-image taps read a
+// zero line.  Two LDS stages, one barrier per k-tile, the next tile's DMA instructions interleaved with the
+// MFMA stream (sched_group_barrier).  Epilogue = BN scale/shift + ReLU, then fp32 rows or the h2 layout for the
+// next layer (transposed through LDS so that global stores are 16-byte chunks of whole rows).
+//
+// What was measured on the way (conv2 size, 4096 leaves; kept here so nobody re-discovers it):
+//   32x32x16 shape, 8 waves, 2 stages ................ 2.75 ms   (no DMA: 2.20 ms, no MFMA: 1.67 ms)
+//   4-stage ring, k-tile 16, counted vmcnt ........... 3.11 ms   (twice the barriers / exposed LDS latency)
+//   4 waves (one per SIMD), 128x128 wave tile, register double-buffered fragments, barrier mid-k-step ... 2.78 ms
+//   all three: 1.77-1.89 GHz, 66-70 % matrix-pipe busy -> clock/power bound, not issue bound
+//   16x16x32 shape (this kernel) ..................... 2.53 ms   (higher sustained clock on this shape)
 #pragma once
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define H2_BK 32
 #define H2_F16_MAX 65504.0f
 
-// tile configurations: NWM x NWN waves, each wave NTI x NTJ MFMA tiles of 32 x 32
+// tile configurations: NWM x NWN waves, each wave NTI x NTJ blocks of 32 x 32 (= 2 x 2 MFMA tiles of 16 x 16)
 //   H2Big   (3x3 convolutions): 2 x 4 waves, wave tile 128 x 64 -> block 256 x 256, 512 threads, 128 KB LDS
 //   H2Small (dense layers):     2 x 2 waves, wave tile  64 x 64 -> block 128 x 128, 256 threads,  64 KB LDS
 template <int NWM, int NWN, int NTI, int NTJ> struct H2Cfg {
@@ -137,7 +149,9 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                                                        void* __restrict__ out, const int* __restrict__ d_count, H2Geom g,
                                                        int num_mt, const uint4* __restrict__ zero_line, int* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BM = CF::BM, BN = CF::BN, TI = CF::TI, TJ = CF::TJ, IA = CF::IA, IB = CF::IB;
+    constexpr int BM = CF::BM, BN = CF::BN, IA = CF::IA, IB = CF::IB;
+    constexpr int RI = CF::TI * 2, RJ = CF::TJ * 2;           // 16-row / 16-column MFMA tiles per wave
+    // XCD-aware tile order: the N/BN column tiles of one row tile run on the same XCD (ids b, b+8 share an L2)
     const int nnt = g.N / BN;
     const int id = blockIdx.x, xcd = id & 7, jb = id >> 3;
     const int mt = (jb / nnt) * 8 + xcd, nt = jb % nnt;
@@ -180,10 +194,12 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         bidx[i] = (unsigned)(nt * BN + row) * (unsigned)wrowq + (unsigned)lc;
     }
     const uint4* zsrc = zero_line + (lane & 7);
+    const int nk = g.K / H2_BK;
 
-    auto stage = [&](int kt, int buf) {
-        const int k0 = kt * H2_BK, tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin;
-        const long long toff = ((long long)(tap / 3) * g.Hin + (tap % 3)) * rowq + (ci0 >> 2);   // 32 ch = 8 uint4
+    auto stage = [&](int kt_raw, int buf) {
+        const int kt = kt_raw < nk ? kt_raw : nk - 1;        // past the end: re-stage the last tile (branch-free loop body)
+        const int slice = kt / g.taps, tap = kt - slice * g.taps;         // tap-inner k order
+        const long long toff = ((long long)(tap / 3) * g.Hin + (tap % 3)) * rowq + slice * 8;    // 32 ch = 8 uint4
         unsigned char* la = smem + (size_t)buf * CF::BUF + wave * IA * 1024;
         unsigned char* lb = smem + (size_t)buf * CF::BUF + CF::TILEA + wave * IB * 1024;
 #pragma unroll
@@ -193,68 +209,49 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
-            const uint4* gb = Wh + bidx[i] + (k0 >> 2);
+            const uint4* gb = Wh + bidx[i] + kt * 8;
             __builtin_amdgcn_global_load_lds((h2_gptr)gb, (h2_lptr)(lb + i * 1024), 16, 0, 0);
         }
     };
 
-    f32x16 acc[TI][TJ];
+    f32x4v acc[RI][RJ];
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j)
+        for (int j = 0; j < RJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = g.K / H2_BK;
-    const int r32 = lane & 31, half = lane >> 5;
-    const int swz = (r32 >> 1) & 7;                          // (row>>1)&7 of every row this lane reads (tile bases are multiples of 16)
-    // byte offsets inside a 128-byte row of logical chunks c = 4s + 2*half + plane
-    const int o00 = ((2 * half) ^ swz) * 16, o01 = ((2 * half + 1) ^ swz) * 16;
-    const int o10 = ((4 + 2 * half) ^ swz) * 16, o11 = ((4 + 2 * half + 1) ^ swz) * 16;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int swz = (r16 >> 1) & 7;                          // (row>>1)&7 of every row this lane reads (tile bases are multiples of 16)
+    const int oh1 = ((2 * kg) ^ swz) * 16, oh2 = ((2 * kg + 1) ^ swz) * 16;
 
     stage(0, 0);
     __syncthreads();                                         // drains the DMA (vmcnt(0)) and publishes the tile
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * TI * 32 + r32) * 128;
-        const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * TJ * 32 + r32) * 128;
+        stage(kt + 1, buf ^ 1);
+        const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * RI * 16 + r16) * 128;
+        const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+        f16x8 b1[RJ], b2[RJ];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            // the next tile's LDS-DMA is issued in the middle of the MFMA stream (between the two k-steps) and
-            // interleaved with the second k-step's MFMAs below, so the matrix pipe never waits for DMA issue.
-            // (the last iteration re-stages the last tile into the idle buffer: keeps the loop body branch-free)
-#if !defined(H2_EXP) || H2_EXP != 1      // H2_EXP=1 (timing experiment only): no DMA in the loop
-            if (s == 1) stage(kt + 1 < nk ? kt + 1 : nk - 1, buf ^ 1);
-#endif
-            const int oh1 = s ? o10 : o00, oh2 = s ? o11 : o01;
-            f16x8 b1[TJ], b2[TJ];
+        for (int j = 0; j < RJ; ++j) {
+            b1[j] = *reinterpret_cast<const f16x8*>(Bt + j * 16 * 128 + oh1);
+            b2[j] = *reinterpret_cast<const f16x8*>(Bt + j * 16 * 128 + oh2);
+        }
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                b1[j] = *reinterpret_cast<const f16x8*>(Bt + j * 32 * 128 + oh1);
-                b2[j] = *reinterpret_cast<const f16x8*>(Bt + j * 32 * 128 + oh2);
-            }
+        for (int i = 0; i < RI; ++i) {
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(At + i * 16 * 128 + oh1);
+            const f16x8 a2 = *reinterpret_cast<const f16x8*>(At + i * 16 * 128 + oh2);
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const f16x8 a1 = *reinterpret_cast<const f16x8*>(At + i * 32 * 128 + oh1);
-                const f16x8 a2 = *reinterpret_cast<const f16x8*>(At + i * 32 * 128 + oh2);
-#if defined(H2_EXP) && H2_EXP == 2        // timing experiment only: LDS reads kept alive, no MFMA
-                asm volatile("" ::"v"(a1), "v"(a2));
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) asm volatile("" ::"v"(b1[j]), "v"(b2[j]));
-#else
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[j], acc[i][j], 0, 0, 0);
-                }
-#endif
+            for (int j = 0; j < RJ; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[j], acc[i][j], 0, 0, 0);
             }
         }
-        // second half of the body: one DMA after every MFMAs_per_DMA matrix instructions
-        {
-            constexpr int NDMA = IA + IB, NMF = TI * TJ * 3, PER = NMF / NDMA;
+        {   // the next tile's DMA instructions are spread over the first half of the MFMA stream
+            constexpr int NDMA = IA + IB, NMF = RI * RJ * 3, PER = NMF / (2 * NDMA);
 #pragma unroll
             for (int q = 0; q < NDMA; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);      // MFMA
@@ -264,18 +261,18 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         __syncthreads();
     }
 
-    // ---- epilogue.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
     if (!g.out_h2) {
         float* o = reinterpret_cast<float*>(out);
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int col = nt * BN + wn * TJ * 32 + j * 32 + r32;
+        for (int j = 0; j < RJ; ++j) {
+            const int col = nt * BN + wn * RJ * 16 + j * 16 + r16;
             const float sc = scale[col], sh = shift[col];
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+            for (int i = 0; i < RI; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long m = (long long)mt * BM + wm * TI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                for (int r = 0; r < 4; ++r) {
+                    const long long m = (long long)mt * BM + wm * RI * 16 + i * 16 + kg * 4 + r;
                     float v = fmaf(acc[i][j][r], sc, sh);
                     if (g.relu) v = fmaxf(v, 0.f);
                     if (m < M) o[(size_t)m * g.N + col] = v;
@@ -283,26 +280,26 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         }
         return;
     }
-    // h2 output: each wave transposes its tile through its own 16 KB LDS slice, 64 rows x (TJ*32 = 64 channels) at a
-    // time: slice[row][group(8)][plane(2)][8 halfs] = 256 B per row; then 16-byte chunks go out, 16 lanes per row.
-    static_assert(TJ == 2, "the h2 epilogue assumes a 64-channel wave tile");
+    // h2 output: each wave transposes its tile through its own 16 KB LDS slice, 64 rows x 64 channels at a time:
+    // slice[row][group(8)][plane(2)][8 halfs] = 256 B per row; then 16-byte chunks go out, 16 lanes per row.
+    static_assert(RJ == 4, "the h2 epilogue assumes a 64-channel wave tile");
     bool over = false;
     _Float16* slice = reinterpret_cast<_Float16*>(smem + wave * 16384);
     uint4* o = reinterpret_cast<uint4*>(out);
     const int nq = g.N >> 2;                                // uint4 units per output row (N/8 groups * 2)
 #pragma unroll
-    for (int hh = 0; hh < TI / 2; ++hh) {
+    for (int hh = 0; hh < RI / 4; ++hh) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int i = hh * 2 + ii;
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = hh * 4 + ii;
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int lc = j * 32 + r32;                 // column inside the wave tile
-                const int col = nt * BN + wn * TJ * 32 + lc;
+            for (int j = 0; j < RJ; ++j) {
+                const int lc = j * 16 + r16;                 // column inside the wave tile
+                const int col = nt * BN + wn * RJ * 16 + lc;
                 const float sc = scale[col], sh = shift[col];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lr = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // row inside the 64-row pass
+                for (int r = 0; r < 4; ++r) {
+                    const int lr = ii * 16 + kg * 4 + r;     // row inside the 64-row pass
                     float v = fmaf(acc[i][j][r], sc, sh);
                     if (g.relu) v = fmaxf(v, 0.f);
                     over |= fabsf(v) > H2_F16_MAX;
@@ -319,195 +316,9 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int q = c * 64 + lane, lr = q >> 4, cq = q & 15;
-            const long long m = (long long)mt * BM + wm * TI * 32 + hh * 64 + lr;
+            const long long m = (long long)mt * BM + wm * RI * 16 + hh * 64 + lr;
             const uint4 val = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(slice) + lr * 256 + cq * 16);
-            if (m < M) o[(size_t)m * nq + ((nt * BN + wn * TJ * 32) >> 2) + cq] = val;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (over) atomicOr(flag, 1);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// k_gemm_h2_ring: the same computation with a deeper operand pipeline.  k-tile 16 (64-byte rows), a ring of
-// 4 LDS stages, the LDS-DMA of tile kt+3 is issued during tile kt; a wave waits only for ITS OWN DMA of tile kt
-// with a counted s_waitcnt vmcnt(N) (N = DMA instructions of the two younger tiles) and the block meets at one raw
-// s_barrier per k-tile (no vmcnt(0) drain), so ~2 tiles of DMA latency are hidden behind the matrix pipe.
-// Ablation of the 2-stage kernel above at conv2 size: 2.75 ms full, 2.20 ms without DMA, 1.67 ms without MFMA.
-// Swizzle for 64-byte rows: physical chunk = logical chunk ^ ((row >> 2) & 3)  (16 consecutive rows x one logical
-// chunk -> 16 distinct 16-byte bank slots).
-template <typename CF>
-__global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2_ring(const uint4* __restrict__ in, const uint4* __restrict__ Wh,
-                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            void* __restrict__ out, const int* __restrict__ d_count, H2Geom g,
-                                                            int num_mt, const uint4* __restrict__ zero_line, int* __restrict__ flag) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BM = CF::BM, BN = CF::BN, TI = CF::TI, TJ = CF::TJ;
-    constexpr int KT = 16, NST = 4;
-    constexpr int TA = BM * 64, TB = BN * 64, STG = TA + TB;           // bytes per stage
-    constexpr int IA = BM / (16 * CF::NW), IB = BN / (16 * CF::NW);    // DMA instructions per wave per tile (16 rows each)
-    constexpr int DPW = IA + IB;
-    static_assert(BM % (16 * CF::NW) == 0 && BN % (16 * CF::NW) == 0, "tile shape");
-    static_assert(NST * STG >= CF::NW * 16384, "epilogue slices must fit");
-    const int nnt = g.N / BN;
-    const int id = blockIdx.x, xcd = id & 7, jb = id >> 3;
-    const int mt = (jb / nnt) * 8 + xcd, nt = jb % nnt;
-    const int P = g.Hout * g.Hout;
-    const long long M = (long long)(*d_count) * P;
-    if (mt >= num_mt || (long long)mt * BM >= M) return;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / CF::WN, wn = wave % CF::WN;
-    const int rowq = g.Cin >> 2, wrowq = g.K >> 2;
-
-    // staging map: DMA instruction i of wave w fills rows (w*I + i)*16 .. +15; lane l -> row +(l>>2), physical chunk l&3
-    long long aidx[IA];
-    unsigned amask[IA];
-    unsigned bidx[IB];
-#pragma unroll
-    for (int i = 0; i < IA; ++i) {
-        const int row = (wave * IA + i) * 16 + (lane >> 2);
-        const int lc = (lane & 3) ^ ((row >> 2) & 3);
-        const long long m = (long long)mt * BM + row;
-        aidx[i] = 0; amask[i] = 0;
-        if (m < M) {
-            const int b = (int)(m / P), pix = (int)(m % P), oy = pix / g.Hout, ox = pix % g.Hout;
-            aidx[i] = (((long long)b * g.Hin + (oy - g.pad)) * g.Hin + (ox - g.pad)) * rowq + lc;
-            unsigned mk = 0;
-            for (int t = 0; t < g.taps; ++t) {
-                const int iy = oy - g.pad + t / 3, ix = ox - g.pad + t % 3;
-                if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Hin) mk |= 1u << t;
-            }
-            amask[i] = mk;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-        const int row = (wave * IB + i) * 16 + (lane >> 2);
-        const int lc = (lane & 3) ^ ((row >> 2) & 3);
-        bidx[i] = (unsigned)(nt * BN + row) * (unsigned)wrowq + (unsigned)lc;
-    }
-    const uint4* zsrc = zero_line + (lane & 3);
-    const int nk = g.K / KT;
-
-    auto stage = [&](int kt_raw) {
-        const int kt = kt_raw < nk ? kt_raw : nk - 1;        // past the end: re-stage the last tile (keeps DMA counts uniform)
-        const int st = kt_raw & (NST - 1);
-        const int k0 = kt * KT, tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin;
-        const long long toff = ((long long)(tap / 3) * g.Hin + (tap % 3)) * rowq + (ci0 >> 2);   // 16 ch = 4 uint4
-        unsigned char* la = smem + st * STG + wave * IA * 1024;
-        unsigned char* lb = smem + st * STG + TA + wave * IB * 1024;
-#pragma unroll
-        for (int i = 0; i < IA; ++i) {
-            const uint4* ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + toff) : zsrc;
-            __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la + i * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < IB; ++i) {
-            const uint4* gb = Wh + bidx[i] + (k0 >> 2);
-            __builtin_amdgcn_global_load_lds((h2_gptr)gb, (h2_lptr)(lb + i * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int r32 = lane & 31, half = lane >> 5;
-    const int key = (r32 >> 2) & 3;
-    const int oh1 = ((2 * half) ^ key) * 16, oh2 = ((2 * half + 1) ^ key) * 16;
-
-    stage(0); stage(1); stage(2);
-    static_assert(DPW * 2 <= 63, "vmcnt immediate");
-    for (int kt = 0; kt < nk; ++kt) {
-        // own DMA of tile kt has landed once at most the 2*DPW younger DMA instructions are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");
-        __builtin_amdgcn_s_barrier();                        // everyone's part of tile kt is in LDS; stage (kt-1)&3 is free
-        stage(kt + 3);
-        const unsigned char* At = smem + (kt & (NST - 1)) * STG + (wm * TI * 32 + r32) * 64;
-        const unsigned char* Bt = smem + (kt & (NST - 1)) * STG + TA + (wn * TJ * 32 + r32) * 64;
-        f16x8 b1[TJ], b2[TJ];
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            b1[j] = *reinterpret_cast<const f16x8*>(Bt + j * 32 * 64 + oh1);
-            b2[j] = *reinterpret_cast<const f16x8*>(Bt + j * 32 * 64 + oh2);
-        }
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const f16x8 a1 = *reinterpret_cast<const f16x8*>(At + i * 32 * 64 + oh1);
-            const f16x8 a2 = *reinterpret_cast<const f16x8*>(At + i * 32 * 64 + oh2);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[j], acc[i][j], 0, 0, 0);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped tail DMAs must land before LDS is reused
-    __syncthreads();
-
-    const int BMv = BM;
-    if (!g.out_h2) {
-        float* o = reinterpret_cast<float*>(out);
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int col = nt * BN + wn * TJ * 32 + j * 32 + r32;
-            const float sc = scale[col], sh = shift[col];
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long m = (long long)mt * BMv + wm * TI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    float v = fmaf(acc[i][j][r], sc, sh);
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    if (m < M) o[(size_t)m * g.N + col] = v;
-                }
-        }
-        return;
-    }
-    static_assert(TJ == 2, "the h2 epilogue assumes a 64-channel wave tile");
-    bool over = false;
-    _Float16* slice = reinterpret_cast<_Float16*>(smem + wave * 16384);
-    uint4* o = reinterpret_cast<uint4*>(out);
-    const int nq = g.N >> 2;
-#pragma unroll
-    for (int hh = 0; hh < TI / 2; ++hh) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int i = hh * 2 + ii;
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int lc = j * 32 + r32;
-                const int col = nt * BN + wn * TJ * 32 + lc;
-                const float sc = scale[col], sh = shift[col];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lr = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    float v = fmaf(acc[i][j][r], sc, sh);
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    over |= fabsf(v) > H2_F16_MAX;
-                    _Float16 h1, h2;
-                    h2_split(v, h1, h2);
-                    _Float16* p = slice + lr * 128 + (lc >> 3) * 16 + (lc & 7);
-                    p[0] = h1; p[8] = h2;
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int q = c * 64 + lane, lr = q >> 4, cq = q & 15;
-            const long long m = (long long)mt * BMv + wm * TI * 32 + hh * 64 + lr;
-            const uint4 val = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(slice) + lr * 256 + cq * 16);
-            if (m < M) o[(size_t)m * nq + ((nt * BN + wn * TJ * 32) >> 2) + cq] = val;
+            if (m < M) o[(size_t)m * nq + ((nt * BN + wn * RJ * 16) >> 2) + cq] = val;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
