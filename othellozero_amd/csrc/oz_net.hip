@@ -193,47 +193,61 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
 #include "oz_net_h2.h"
 
 // ---------------------------------------------------------------- heads
-// one wave per HEADS_P positions: logits[a] = f2 . Wpi[:,a] + bpi[a] -> softmax; v = tanh(f2 . Wv + bv).
-// Each Wpi row load (coalesced, one column per lane) feeds HEADS_P positions; the f2 reads are wave-uniform.
+// one 256-thread block per HEADS_P positions: wave w accumulates k in [128w, 128w+128) of logits[a] = f2 . Wpi[:,a]
+// (one policy column per lane, every coalesced Wpi row load feeds HEADS_P positions) and of v = f2 . Wv; the four
+// partial sums are combined in a fixed order through LDS, then wave w finishes positions 2w, 2w+1 (softmax, tanh).
 #define HEADS_P 8
-__global__ __launch_bounds__(64) void k_heads(const float* __restrict__ f2 /*[B][512]*/, const int* __restrict__ d_count,
-                                              int A, const float* __restrict__ Wpi /*[512][A]*/, const float* __restrict__ bpi,
-                                              const float* __restrict__ Wv /*[512]*/, const float* __restrict__ bv,
-                                              float* __restrict__ pi, float* __restrict__ v) {
-    const int b0 = blockIdx.x * HEADS_P, lane = threadIdx.x, count = *d_count;
+__global__ __launch_bounds__(256) void k_heads(const float* __restrict__ f2 /*[B][512]*/, const int* __restrict__ d_count,
+                                               int A, const float* __restrict__ Wpi /*[512][A]*/, const float* __restrict__ bpi,
+                                               const float* __restrict__ Wv /*[512]*/, const float* __restrict__ bv,
+                                               float* __restrict__ pi, float* __restrict__ v) {
+    __shared__ float part[4][HEADS_P][64];
+    __shared__ float vpart_s[4][HEADS_P];
+    const int b0 = blockIdx.x * HEADS_P, lane = threadIdx.x & 63, w = threadIdx.x >> 6, count = *d_count;
     if (b0 >= count) return;
     const bool act = lane < A;
     const float* x[HEADS_P];
 #pragma unroll
-    for (int p = 0; p < HEADS_P; ++p) x[p] = f2 + (size_t)(b0 + p < count ? b0 + p : count - 1) * 512;
-    float logit[HEADS_P], vpart[HEADS_P];
+    for (int p = 0; p < HEADS_P; ++p) x[p] = f2 + (size_t)(b0 + p < count ? b0 + p : count - 1) * 512 + w * 128;
+    float logit[HEADS_P], vp[HEADS_P];
 #pragma unroll
-    for (int p = 0; p < HEADS_P; ++p) { logit[p] = 0.f; vpart[p] = 0.f; }
-    for (int i = 0; i < 512; ++i) {
-        const float w = act ? Wpi[(size_t)i * A + lane] : 0.f;
+    for (int p = 0; p < HEADS_P; ++p) { logit[p] = 0.f; vp[p] = 0.f; }
+#pragma unroll 8
+    for (int i = 0; i < 128; ++i) {
+        const float wgt = act ? Wpi[(size_t)(w * 128 + i) * A + lane] : 0.f;
 #pragma unroll
-        for (int p = 0; p < HEADS_P; ++p) logit[p] = fmaf(x[p][i], w, logit[p]);
+        for (int p = 0; p < HEADS_P; ++p) logit[p] = fmaf(x[p][i], wgt, logit[p]);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float wv = Wv[lane * 8 + i];
+    for (int i = 0; i < 2; ++i) {
+        const float wv = Wv[w * 128 + lane * 2 + i];
 #pragma unroll
-        for (int p = 0; p < HEADS_P; ++p) vpart[p] = fmaf(x[p][lane * 8 + i], wv, vpart[p]);
+        for (int p = 0; p < HEADS_P; ++p) vp[p] = fmaf(x[p][lane * 2 + i], wv, vp[p]);
     }
-    const float bl = act ? bpi[lane] : 0.f, bvv = bv[0];
 #pragma unroll
     for (int p = 0; p < HEADS_P; ++p) {
-        const float lg = act ? logit[p] + bl : -INFINITY;
-        float mx = lg, vp = vpart[p];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vp[p] += __shfl_xor(vp[p], off, 64);
+        part[w][p][lane] = logit[p];
+        if (lane == 0) vpart_s[w][p] = vp[p];
+    }
+    __syncthreads();
+    const float bl = act ? bpi[lane] : 0.f, bvv = bv[0];
+#pragma unroll
+    for (int q = 0; q < HEADS_P / 4; ++q) {
+        const int p = w * (HEADS_P / 4) + q;
+        const float sum = ((part[0][p][lane] + part[1][p][lane]) + part[2][p][lane]) + part[3][p][lane];
+        const float lg = act ? sum + bl : -INFINITY;
+        float mx = lg;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
         const float e = act ? expf(lg - mx) : 0.f;
         float s = e;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); vp += __shfl_xor(vp, off, 64); }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
         if (b0 + p < count) {
             if (act) pi[(size_t)(b0 + p) * A + lane] = e / s;
-            if (lane == 0) v[b0 + p] = tanhf(vp + bvv);
+            if (lane == 0) v[b0 + p] = tanhf(((vpart_s[0][p] + vpart_s[1][p]) + vpart_s[2][p]) + vpart_s[3][p] + bvv);
         }
     }
 }
@@ -340,7 +354,9 @@ struct OnnNet : oz_net {
         const int grid = ((num_mt + 7) / 8) * 8 * (N / CF::BN);
         if (!h2_attr_set) {
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Big>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Big::LDS));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Mid>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Mid::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Thin>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Thin::LDS));
             h2_attr_set = true;
         }
         hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
@@ -371,11 +387,11 @@ struct OnnNet : oz_net {
         if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); OZ_HIP(hipEventRecord(e0, s)); }
         if (int rc = launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
         if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
-        if (int rc = launch_gemm_h2<H2Big>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
+        if (int rc = launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
         if (int rc = launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
-        if (int rc = launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
-        if (int rc = launch_gemm_h2<H2Small>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
-        hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(64), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        if (int rc = launch_gemm_h2<H2Thin>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
+        if (int rc = launch_gemm_h2<H2Thin>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
+        hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
     }
@@ -400,7 +416,7 @@ struct OnnNet : oz_net {
         if (int rc = launch_gemm(act3, d_wt[2], 3, act4, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
         if (int rc = launch_gemm(act4, d_wt[3], 4, f1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
         if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
-        hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(64), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
     }

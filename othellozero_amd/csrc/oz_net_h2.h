@@ -49,11 +49,15 @@ template <int NWM, int NWN, int NTI, int NTJ> struct H2Cfg {
     static constexpr int BM = NWM * NTI * 32, BN = NWN * NTJ * 32, NW = NWM * NWN, NT = NW * 64;
     static constexpr int TILEA = BM * 128, TILEB = BN * 128, BUF = TILEA + TILEB, LDS = 2 * BUF;
     static constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW);     // LDS-DMA instructions per wave per operand tile
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NTI % 2 == 0, "tile shape");
-    static_assert(NW * 16384 <= LDS, "epilogue slices must fit in the staging buffers");
+    // h2 epilogue: each wave transposes PB 16-row blocks (x 64 channels) per pass through a private LDS slice
+    static constexpr int PB = (NTI % 2 == 0) ? 4 : 2, SLICE = PB * 16 * 256;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
+    static_assert(NW * SLICE <= LDS, "epilogue slices must fit in the staging buffers");
 };
-typedef H2Cfg<2, 4, 4, 2> H2Big;
-typedef H2Cfg<2, 2, 2, 2> H2Small;
+typedef H2Cfg<2, 4, 4, 2> H2Big;      // conv2, conv4: 256 x 256
+typedef H2Cfg<2, 4, 3, 2> H2Mid;      // conv3 (M = B*36): 192 x 256 -> 1536 blocks = 6.0 rounds of 256 CUs (256 x 256: 4.5)
+typedef H2Cfg<2, 2, 2, 2> H2Small;    // 128 x 128
+typedef H2Cfg<1, 2, 2, 2> H2Thin;     // dense layers (M = batch): 64 x 128, 2 waves -> 512 / 256 blocks at B = 4096
 
 struct H2Geom {
     int Hin, Hout, pad, Cin, taps;        // taps 9 (3x3 conv) or 1 (dense, Hin = Hout = 1)
@@ -284,14 +288,15 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     // slice[row][group(8)][plane(2)][8 halfs] = 256 B per row; then 16-byte chunks go out, 16 lanes per row.
     static_assert(RJ == 4, "the h2 epilogue assumes a 64-channel wave tile");
     bool over = false;
-    _Float16* slice = reinterpret_cast<_Float16*>(smem + wave * 16384);
+    constexpr int PB = CF::PB;
+    _Float16* slice = reinterpret_cast<_Float16*>(smem + wave * CF::SLICE);
     uint4* o = reinterpret_cast<uint4*>(out);
     const int nq = g.N >> 2;                                // uint4 units per output row (N/8 groups * 2)
 #pragma unroll
-    for (int hh = 0; hh < RI / 4; ++hh) {
+    for (int hh = 0; hh < RI / PB; ++hh) {
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = hh * 4 + ii;
+        for (int ii = 0; ii < PB; ++ii) {
+            const int i = hh * PB + ii;
 #pragma unroll
             for (int j = 0; j < RJ; ++j) {
                 const int lc = j * 16 + r16;                 // column inside the wave tile
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                 const float sc = scale[col], sh = shift[col];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int lr = ii * 16 + kg * 4 + r;     // row inside the 64-row pass
+                    const int lr = ii * 16 + kg * 4 + r;     // row inside the pass
                     float v = fmaf(acc[i][j][r], sc, sh);
                     if (g.relu) v = fmaxf(v, 0.f);
                     over |= fabsf(v) > H2_F16_MAX;
@@ -312,11 +317,11 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's LDS writes have landed
         __builtin_amdgcn_wave_barrier();
-        // 64 rows x 256 B = 1024 chunks of 16 B; lane l takes chunks l, l+64, ...: 16 consecutive lanes = one row
+        // PB*16 rows x 256 B in chunks of 16 B; lane l takes chunks l, l+64, ...: 16 consecutive lanes = one row
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int c = 0; c < PB * 4; ++c) {
             const int q = c * 64 + lane, lr = q >> 4, cq = q & 15;
-            const long long m = (long long)mt * BM + wm * RI * 16 + hh * 64 + lr;
+            const long long m = (long long)mt * BM + wm * RI * 16 + hh * PB * 16 + lr;
             const uint4 val = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(slice) + lr * 256 + cq * 16);
             if (m < M) o[(size_t)m * nq + ((nt * BN + wn * RJ * 16) >> 2) + cq] = val;
         }
