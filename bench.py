@@ -11,8 +11,8 @@ stay busy for the whole timed region and completed games are counted exactly.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
 Prints ONE JSON line on rank 0: value = node expansions per second over all GPUs (the BASELINE metric; the
-same line carries games/s and sims/s), `roofline` for the dominant kernel (conv2 implicit GEMM on the fp32
-matrix cores, HIP events on its launch stream) and `cpu_baseline` (the CPU oracle -- the reference algorithm
+same line carries games/s and sims/s), `roofline` for the dominant kernel (the conv2 implicit-GEMM launch, HIP
+events on its launch stream) and `cpu_baseline` (the CPU oracle -- the reference algorithm
 with batch-1 leaf evaluation -- timed on this host's cores on a bounded sample).
 """
 import argparse
@@ -66,7 +66,7 @@ def cpu_baseline(n, channels, sims, budget_s=15.0):
     import oracle
     from othellozero_amd.weights import init_weights
     w = init_weights(n, seed=0, channels=channels)
-    threads = oracle.lib().orc_nn_max_threads()
+    threads = min(oracle.lib().orc_nn_max_threads(), 16)        # the box's CPU share for one GPU
     net = oracle.CNet(w, n, channels=channels, nthreads=threads)
 
     def run(max_moves):
@@ -90,7 +90,7 @@ def cpu_baseline(n, channels, sims, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=100)
@@ -99,11 +99,15 @@ def main():
     ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x2"],
                     help="conv arithmetic: exact fp32 matrix cores, or f32 via 2 x fp16 split (same 1e-5 parity tolerance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_device:
+        local_rank = 0
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import torch
@@ -119,7 +123,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     n, G = args.board, args.games
     net = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0, precision=args.precision)   # same weights on every rank

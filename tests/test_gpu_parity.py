@@ -535,3 +535,49 @@ def test_config2_size_properties(oz):
         pl, fin = C.c_int(int(ep["player"][-1])), C.c_int(0)
         oracle.lib().orc_game_play(C.byref(b), C.byref(w), n, C.byref(pl), C.byref(fin), int(ep["action"][-1]))
         assert (b.value, w.value) == (int(states[0][0][gi]), int(states[0][1][gi])), gi
+
+
+def test_config4_size_properties_6x6(oz):
+    """BASELINE config 4: 4096 concurrent 6x6 games, 100 sims/move, device stub net: counters, legality of the
+    position after 3 move rounds (vs the oracle for a sample), bit reproducibility."""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    G, n, sims, rounds = 4096, 6, 100, 3
+    res = []
+    for rep in range(2):
+        eng = SelfPlayEngine(StubNetWrapper((n, n), 55, 0, max_batch=G), n, G, sims, seed=4321, q_mode=0)
+        eng.run(rounds)
+        st, after = eng.stats(), eng.state()
+        assert st["simulations"] == G * sims * rounds and st["moves"] == G * rounds and st["overflow"] == 0
+        valid = sum(1 << (r * 8 + c) for r in range(n) for c in range(n))
+        assert np.all(((after["black"] | after["white"]) & ~np.uint64(valid)) == 0)
+        res.append((after["black"].copy(), after["white"].copy(), eng.last_counts().copy()))
+    assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
+    for gi in range(0, G, 128):
+        ep = oracle.Mcts(n, 1.0, 0, salt=55).episode(sims, 1.0, 0.9, 4321, gi, max_moves=rounds)
+        b, w = C.c_uint64(int(ep["black"][-1])), C.c_uint64(int(ep["white"][-1]))
+        pl, fin = C.c_int(int(ep["player"][-1])), C.c_int(0)
+        oracle.lib().orc_game_play(C.byref(b), C.byref(w), n, C.byref(pl), C.byref(fin), int(ep["action"][-1]))
+        assert (b.value, w.value) == (int(res[0][0][gi]), int(res[0][1][gi])), gi
+        assert np.array_equal(res[0][2][gi], ep["counts"][-1]), gi
+
+
+def test_config5_arena_800_sims_512_games(oz):
+    """BASELINE config 5: 512 parallel deterministic arena games at 800 sims/move (net A = BLACK vs net B = WHITE,
+    temperature 0, tie stream): move lists, winners and points bit-exact against the oracle for a sample of games,
+    result invariants for all of them, and the whole batch reproducible."""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.agents import arena_batch
+    G, n, sims = 512, 8, 800
+    r = arena_batch(StubNetWrapper((n, n), 301, 0, max_batch=G), StubNetWrapper((n, n), 302, 0, max_batch=G), n, G, sims, 1.0,
+                    seed=11, first_game_id=0, q_mode=1)
+    assert np.all(r["n_moves"] > 40) and np.all(r["n_moves"] <= 60)
+    discs = np.array([bin(int(b)).count("1") + bin(int(w)).count("1") for b, w in zip(r["final_black"], r["final_white"])])
+    assert np.all(discs == 4 + r["n_moves"]) and np.all(np.abs(r["winner"]) == 1)
+    for gi in (0, 1, 255, 511):
+        o = oracle.arena(oracle.Mcts(n, 1.0, 1, salt=301), oracle.Mcts(n, 1.0, 1, salt=302), sims, 11, gi)
+        k = o["n_moves"]
+        assert int(r["n_moves"][gi]) == k and np.array_equal(r["actions"][gi][:k], o["action"]), gi
+        assert np.array_equal(r["players"][gi][:k], o["player"]), gi
+        assert (int(r["winner"][gi]), int(r["points"][gi])) == (o["winner"], o["points"]), gi
+        assert (int(r["final_black"][gi]), int(r["final_white"][gi])) == (o["final_black"], o["final_white"]), gi
