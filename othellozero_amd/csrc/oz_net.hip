@@ -303,6 +303,7 @@ struct OnnNet : oz_net {
     uint4* d_wh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // conv2..4, fc1, fc2
     float* d_scale_h2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int* d_flag = nullptr;
+    float* d_partial = nullptr;      // split-K slabs [4][max_batch][1024]
     uint4* d_zero = nullptr;
     bool h2_attr_set = false;
     std::vector<void*> allocs;
@@ -346,12 +347,15 @@ struct OnnNet : oz_net {
     // layer: 1..3 = conv2..4 (3x3, Cin = N = C), 4 = fc1, 5 = fc2 (taps 1)
     template <typename CF>
     int launch_gemm_h2(const void* in, int layer, void* out, int out_h2, const int* d_count, int max_count, int Hin,
-                       int Hout, int pad, int Cin, int taps, int N, hipStream_t s) {
+                       int Hout, int pad, int Cin, int taps, int N, hipStream_t s, int ksplit = 1) {
         H2Geom g;
         g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.out_h2 = out_h2; g.relu = 1;
+        g.ksplit = ksplit; g.slab = (long long)max_batch * N;
         const long long Mmax = (long long)max_count * Hout * Hout;
         const int num_mt = (int)((Mmax + CF::BM - 1) / CF::BM);
-        const int grid = ((num_mt + 7) / 8) * 8 * (N / CF::BN);
+        const int grid = ((num_mt + 7) / 8) * 8 * (N / CF::BN) * ksplit;
+        void* out_final = out;
+        if (ksplit > 1) out = d_partial;          // raw k-slice sums; k_splitk_reduce_h2 below writes out_final (h2 layout)
         if (!h2_attr_set) {
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Big>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Big::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Mid>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Mid::LDS));
@@ -361,6 +365,11 @@ struct OnnNet : oz_net {
         }
         hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
                            d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag);
+        if (ksplit > 1) {
+            const long long threads = (long long)max_count * (N / 8);
+            hipLaunchKernelGGL(k_splitk_reduce_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)d_partial,
+                               g.slab, ksplit, N, d_count, d_scale_h2[layer - 1], d_shift[layer], 1, (uint4*)out_final, d_flag);
+        }
         OZ_HIP(hipGetLastError());
         return OZ_OK;
     }
@@ -389,7 +398,8 @@ struct OnnNet : oz_net {
         if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
         if (int rc = launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
         if (int rc = launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
-        if (int rc = launch_gemm_h2<H2Thin>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
+        // fc1: K = 8192 but only batch x 1024 outputs -> 4-way split-K (fixed-order reduce) to fill the chip
+        if (int rc = launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
         if (int rc = launch_gemm_h2<H2Thin>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
         hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
         OZ_HIP(hipGetLastError());
@@ -565,6 +575,7 @@ OZ_API int oz_net_commit(oz_net* net) {
         }
         if (!o->d_flag) { if (int rc = o->alloc(&o->d_flag, 1)) return rc; }
         OZ_HIP(hipMemset(o->d_flag, 0, sizeof(int)));
+        if (!o->d_partial) { if (int rc = o->alloc(&o->d_partial, (size_t)4 * o->max_batch * 1024)) return rc; }
         if (!o->d_zero) { if (int rc = o->alloc(&o->d_zero, 16)) return rc; }
         OZ_HIP(hipMemset(o->d_zero, 0, 256));
     }

@@ -64,7 +64,46 @@ struct H2Geom {
     int N, K;                             // output channels, taps * Cin
     int out_h2;                           // 1: write the h2 layout, 0: write fp32 rows
     int relu;
+    int ksplit;                           // > 1: split-K, raw partial sums to slab[ks] (no scale/shift), see k_splitk_reduce_h2
+    long long slab;                       // elements between two partial slabs
 };
+
+// finishes a split-K layer: out[m][n] = act((sum_s slab[s][m][n]) * scale[n] + shift[n]) with the slices added in a
+// FIXED order (bit-reproducible), written in the h2 layout.  One thread per (row, 8 channels).
+__global__ __launch_bounds__(256) void k_splitk_reduce_h2(const float* __restrict__ part, long long slab, int ksplit, int N,
+                                                          const int* __restrict__ d_count, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int relu, uint4* __restrict__ out,
+                                                          int* __restrict__ flag) {
+    const int ng = N >> 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long m = idx / ng;
+    if (m >= *d_count) return;
+    const int c8 = (int)(idx % ng) * 8;
+    float acc[8];
+    const float* p = part + (size_t)m * N + c8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = p[j];
+    for (int s = 1; s < ksplit; ++s) {
+        const float* q = p + (size_t)s * slab;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += q[j];
+    }
+    f16x8 h1, h2;
+    bool over = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = fmaf(acc[j], scale[c8 + j], shift[c8 + j]);
+        if (relu) v = fmaxf(v, 0.f);
+        over |= fabsf(v) > H2_F16_MAX;
+        const _Float16 a = (_Float16)v;
+        h1[j] = a;
+        h2[j] = (_Float16)(v - (float)a);
+    }
+    if (over) atomicOr(flag, 1);
+    uint4* dst = out + ((size_t)m * ng + (c8 >> 3)) * 2;
+    dst[0] = *reinterpret_cast<uint4*>(&h1);
+    dst[1] = *reinterpret_cast<uint4*>(&h2);
+}
 
 __device__ __forceinline__ void h2_split(float x, _Float16& h1, _Float16& h2) {
     h1 = (_Float16)x;
@@ -164,9 +203,10 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     constexpr int BM = CF::BM, BN = CF::BN, IA = CF::IA, IB = CF::IB;
     constexpr int RI = CF::TI * 2, RJ = CF::TJ * 2;           // 16-row / 16-column MFMA tiles per wave
     // XCD-aware tile order: the N/BN column tiles of one row tile run on the same XCD (ids b, b+8 share an L2)
-    const int nnt = g.N / BN;
+    // split-K (g.ksplit > 1): the ksplit slices of one output tile are consecutive block ids of the same XCD
+    const int nnt = g.N / BN, per_mt = nnt * g.ksplit;
     const int id = blockIdx.x, xcd = id & 7, jb = id >> 3;
-    const int mt = (jb / nnt) * 8 + xcd, nt = jb % nnt;
+    const int mt = (jb / per_mt) * 8 + xcd, rem = jb % per_mt, nt = rem / g.ksplit, ks = rem - nt * g.ksplit;
     const int P = g.Hout * g.Hout;
     const long long M = (long long)(*d_count) * P;
     if (mt >= num_mt || (long long)mt * BM >= M) return;
@@ -206,7 +246,7 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         bidx[i] = (unsigned)(nt * BN + row) * (unsigned)wrowq + (unsigned)lc;
     }
     const uint4* zsrc = zero_line + (lane & 7);
-    const int nk = g.K / H2_BK;
+    const int nk_all = g.K / H2_BK, kbeg = (int)((long long)nk_all * ks / g.ksplit), nk = (int)((long long)nk_all * (ks + 1) / g.ksplit);
 
     auto stage = [&](int kt_raw, int buf) {
         const int kt = kt_raw < nk ? kt_raw : nk - 1;        // past the end: re-stage the last tile (branch-free loop body)
@@ -238,10 +278,10 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     const int swz = h2_swz(r16);                             // tile bases are multiples of 16 rows
     const int oh1 = ((2 * kg) ^ swz) * 16, oh2 = ((2 * kg + 1) ^ swz) * 16;
 
-    stage(0, 0);
+    stage(kbeg, 0);
     __syncthreads();                                         // drains the DMA (vmcnt(0)) and publishes the tile
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kbeg; kt < nk; ++kt) {
+        const int buf = (kt - kbeg) & 1;
         stage(kt + 1, buf ^ 1);
         const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * RI * 16 + r16) * 128;
         const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
@@ -274,6 +314,21 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     }
 
     // ---- epilogue.  C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
+    if (g.ksplit > 1) {      // raw fp32 partial sums of this k-slice into slab ks; k_splitk_reduce_h2 finishes the layer
+        float* o = reinterpret_cast<float*>(out) + (size_t)ks * g.slab;
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) {
+            const int col = nt * BN + wn * RJ * 16 + j * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < RI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long m = (long long)mt * BM + wm * RI * 16 + i * 16 + kg * 4 + r;
+                    if (m < M) o[(size_t)m * g.N + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     if (!g.out_h2) {
         float* o = reinterpret_cast<float*>(out);
 #pragma unroll
