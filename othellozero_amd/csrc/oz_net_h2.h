@@ -33,6 +33,11 @@
 //   4 waves (one per SIMD), 128x128 wave tile, register double-buffered fragments, barrier mid-k-step ... 2.78 ms
 //   all three: 1.77-1.89 GHz, 66-70 % matrix-pipe busy -> clock/power bound, not issue bound
 //   16x16x32 shape (this kernel) ..................... 2.53 ms   (higher sustained clock on this shape)
+//   + swizzle key for the 16x16x32 operand map ....... 2.40 ms   (LDS conflict cycles 50 % -> 3 %)
+//   ablation of THIS kernel (tools/build_variant.sh -DH2_EXP_NODMA [-DH2_EXP_NOBARRIER]): 2.47 ms full, 2.06 ms with
+//   no DMA in the loop, 2.00 ms with no DMA and no barrier; A staged for 1 tap of 9 only: 2.36 ms.  So the floor of
+//   this structure is LDS reads + MFMA at the power-limited clock (~620 TFLOP/s fp32-equivalent); LDS-DMA issue/wait
+//   costs 16 %, barriers 3 %, and tap reuse for A alone would buy <= 4.5 %.
 #pragma once
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -254,6 +259,9 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         const long long toff = ((long long)(tap / 3) * g.Hin + (tap % 3)) * rowq + slice * 8;    // 32 ch = 8 uint4
         unsigned char* la = smem + (size_t)buf * CF::BUF + wave * IA * 1024;
         unsigned char* lb = smem + (size_t)buf * CF::BUF + CF::TILEA + wave * IB * 1024;
+#ifdef H2_EXP_TAP0                        // timing experiment only (wrong results): A staged for tap 0 only = upper bound of tap reuse
+        if (tap == 0)
+#endif
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             const uint4* ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + toff) : zsrc;
@@ -282,7 +290,9 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     __syncthreads();                                         // drains the DMA (vmcnt(0)) and publishes the tile
     for (int kt = kbeg; kt < nk; ++kt) {
         const int buf = (kt - kbeg) & 1;
+#ifndef H2_EXP_NODMA                      // H2_EXP_* : timing experiments only (wrong results), see tools/build_variant.sh
         stage(kt + 1, buf ^ 1);
+#endif
         const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * RI * 16 + r16) * 128;
         const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
         f16x8 b1[RJ], b2[RJ];
@@ -310,7 +320,9 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read (global_load_lds)
             }
         }
+#ifndef H2_EXP_NOBARRIER
         __syncthreads();
+#endif
     }
 
     // ---- epilogue.  C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
