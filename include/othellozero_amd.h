@@ -64,6 +64,8 @@ int oz_rules_play(const uint64_t* black, const uint64_t* white, const int8_t* pl
 typedef struct oz_net oz_net;
 /* ONN with `channels` conv filters (reference: 512), for boards n x n, batches up to max_batch */
 int oz_net_create(oz_net** out, int n, int channels, int max_batch);
+/* BaseNN (Net/BaseNN.py:41-56): same trunk on ONE input plane (+1 mover, -1 opponent); 40 weight arrays, conv1 kernel (3,3,1,C) */
+int oz_net_create_bnn(oz_net** out, int n, int channels, int max_batch);
 /* deterministic integer-hash stand-in for predict() (test nets; formula in oracle/oz_oracle.c orc_stub_predict) */
 int oz_net_create_stub(oz_net** out, int n, uint64_t salt, uint64_t keep_mask, int max_batch);
 int oz_net_destroy(oz_net* net);
@@ -73,7 +75,7 @@ int oz_net_weight_size(const oz_net* net, int index, int64_t* nelem);
 int oz_net_set_weight(oz_net* net, int index, const float* data, int64_t nelem);
 int oz_net_get_weight(const oz_net* net, int index, float* data, int64_t nelem);
 /* arithmetic of the 3x3 convolutions: 0 = exact fp32 matrix cores (v_mfma_f32_32x32x2_f32);
- * 1 = "f32 via 2 x fp16 split": x = h1 + h2, products a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_32x32x16_f16 with fp32
+ * 1 = "f32 via 2 x fp16 split": x = h1 + h2, products a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_16x16x32_f16 with fp32
  * accumulation (<= 2^-22 relative per product, the class of fp32 accumulation error; needs channels % 256 == 0 and
  * post-ReLU activations < 65504 -- oz_net_check / predict / selfplay_sync report OZ_ERR_STATE otherwise).
  * Takes effect at the next oz_net_commit. */

@@ -50,6 +50,8 @@ def _conv3x3(x, k, bias, same):
 def forward(weights, own, opp, n, dtype=np.float64, return_activations=False):
     w = [np.asarray(a, dtype=dtype) for a in weights]
     x = planes(own, opp, n, dtype)
+    if w[0].shape[2] == 1:                         # BaseNN (Net/BaseNN.py:41-44): one plane, +1 mover / -1 opponent
+        x = x[..., 0:1] - x[..., 1:2]
     acts = []
     for layer, same in enumerate((True, True, False, False)):
         k, bias, g, b, mu, var = w[6 * layer:6 * layer + 6]

@@ -44,20 +44,24 @@ class NNetWrapper(_NetHandle):
         self.network_type = network
         self.num_channels = num_channels_1          # num_channels_2 is accepted but unused (OthelloNN.py:39)
         self.max_batch = int(max_batch)
-        if network is not NeuralNets.ONN:
-            raise NotImplementedError("only NeuralNets.ONN is implemented (BNN: SURVEY.md section 8(f) item 4)")
+        if network not in (NeuralNets.ONN, NeuralNets.BNN):
+            raise Exception('Invalid Network Type.')
+        # BNN (Net/BaseNN.py): the same trunk on the one-channel board (+1 BLACK / -1 WHITE, mover-canonical in the search)
+        self.in_channels = 2 if network is NeuralNets.ONN else 1
         lib = _lib.require_gpu()
-        _lib.check(lib.oz_net_create(C.byref(self._h), self.board_size_x, self.num_channels, self.max_batch))
+        create = lib.oz_net_create if network is NeuralNets.ONN else lib.oz_net_create_bnn
+        _lib.check(create(C.byref(self._h), self.board_size_x, self.num_channels, self.max_batch))
         # precision: "f32" = exact fp32 matrix cores; "f16x2" = f32 via 2 x fp16 split on the 16-bit matrix cores
         # (same <= 1e-5 tolerance, ~3-4x faster; needs channels % 256 == 0, raises if an activation leaves the fp16 range)
         self.precision = precision
         _lib.check(lib.oz_net_set_precision(self._h, {"f32": 0, "f16x2": 1}[precision]))
-        self.set_weights(weights if weights is not None else init_weights(self.board_size_x, seed, self.num_channels))
+        self.set_weights(weights if weights is not None else
+                         init_weights(self.board_size_x, seed, self.num_channels, in_channels=self.in_channels))
 
     # ---- weights (model.get_weights / set_weights, Net/NNet.py:98-101)
     def set_weights(self, weights):
         lib = _lib.load()
-        shapes = onn_shapes(self.board_size_x, self.num_channels)
+        shapes = onn_shapes(self.board_size_x, self.num_channels, self.in_channels)
         assert len(weights) == len(shapes), f"expected {len(shapes)} arrays"
         for i, (w, shp) in enumerate(zip(weights, shapes)):
             a = np.ascontiguousarray(w, dtype=np.float32)
@@ -68,7 +72,7 @@ class NNetWrapper(_NetHandle):
     def get_weights(self):
         lib = _lib.load()
         out = []
-        for i, shp in enumerate(onn_shapes(self.board_size_x, self.num_channels)):
+        for i, shp in enumerate(onn_shapes(self.board_size_x, self.num_channels, self.in_channels)):
             a = np.zeros(shp, dtype=np.float32)
             _lib.check(lib.oz_net_get_weight(self._h, i, _lib.p_f32(a), a.size))
             out.append(a)
@@ -90,7 +94,10 @@ class NNetWrapper(_NetHandle):
         return pi, v
 
     def predict(self, board):
-        """Net/NNet.py:70-87: board (n,n,2) -> (pi.reshape(n,n), v[0][0])"""
+        """Net/NNet.py:70-87: board (n,n,2) [ONN] or one-channel (n,n) with +1 / -1 [BNN] -> (pi.reshape(n,n), v[0][0])"""
+        if self.in_channels == 1:
+            b = np.asarray(board)
+            board = np.stack([b == 1, b == -1], axis=2)
         own, opp = _lib.pack_board(board)
         pi, v = self.predict_batch(np.array([own], np.uint64), np.array([opp], np.uint64))
         return pi[0], v[0]

@@ -64,6 +64,7 @@ SIGNATURES = {
     "oz_rules_status": [_u64p, _u64p, C.c_int, C.c_int, _u8p, _i32p, _i32p, _i8p],
     "oz_rules_play": [_u64p, _u64p, _i8p, _u8p, C.c_int, C.c_int, _u64p, _u64p, _i8p, _u8p],
     "oz_net_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int],
+    "oz_net_create_bnn": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int],
     "oz_net_create_stub": [C.POINTER(_vp), C.c_int, C.c_uint64, C.c_uint64, C.c_int],
     "oz_net_destroy": [_vp], "oz_net_num_weights": [_vp],
     "oz_net_weight_size": [_vp, C.c_int, _i64p],

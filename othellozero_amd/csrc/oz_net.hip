@@ -291,6 +291,7 @@ struct StubNet : oz_net {
 
 struct OnnNet : oz_net {
     int F = 0, A = 0;
+    int cin = 2;             // input planes: 2 = OthelloNN (own, opp), 1 = BaseNN (own - opp, Net/BaseNN.py:41-44)
     std::vector<std::vector<float>> w;      // 40 arrays, keras get_weights() order
     bool committed = false;
     // device
@@ -319,7 +320,7 @@ struct OnnNet : oz_net {
     }
     std::vector<int64_t> sizes() const {
         std::vector<int64_t> s;
-        const int cins[4] = {2, C, C, C};
+        const int cins[4] = {cin, C, C, C};
         for (int l = 0; l < 4; ++l) { s.push_back(9ll * cins[l] * C); for (int k = 0; k < 5; ++k) s.push_back(C); }
         s.push_back((int64_t)F * 1024); for (int k = 0; k < 5; ++k) s.push_back(1024);
         s.push_back(1024ll * 512); for (int k = 0; k < 5; ++k) s.push_back(512);
@@ -448,13 +449,18 @@ int oz_net_forward_device(oz_net* net, const uint64_t* d_own, const uint64_t* d_
     return net->forward_device(d_own, d_opp, d_count, max_count, d_pi, d_v, s);
 }
 
-OZ_API int oz_net_create(oz_net** out, int n, int channels, int max_batch) {
+static int net_create(oz_net** out, int n, int channels, int max_batch, int cin);
+OZ_API int oz_net_create(oz_net** out, int n, int channels, int max_batch) { return net_create(out, n, channels, max_batch, 2); }
+// BaseNN (Net/BaseNN.py:41-56): the same trunk on ONE input plane holding +1 (mover) / -1 (opponent) / 0
+OZ_API int oz_net_create_bnn(oz_net** out, int n, int channels, int max_batch) { return net_create(out, n, channels, max_batch, 1); }
+static int net_create(oz_net** out, int n, int channels, int max_batch, int cin) {
     OZ_REQUIRE(out, "null out pointer");
     OZ_REQUIRE(n == 6 || n == 8, "OthelloNN needs board size 6 or 8 (two 'valid' 3x3 convolutions); got %d", n);
     OZ_REQUIRE(channels >= 128 && channels % 128 == 0, "channels must be a positive multiple of 128 (got %d)", channels);
     OZ_REQUIRE(max_batch > 0, "max_batch must be positive");
     OnnNet* net = new OnnNet();
     net->kind = 0; net->n = n; net->C = channels; net->max_batch = max_batch; net->device = oz_current_device();
+    net->cin = cin;
     net->F = (n - 4) * (n - 4) * channels; net->A = n * n;
     auto sz = net->sizes();
     net->w.resize(sz.size());
@@ -534,7 +540,15 @@ OZ_API int oz_net_commit(oz_net* net) {
         if (int rc = upload(o, &o->d_scale[l], sc)) return rc;
         if (int rc = upload(o, &o->d_shift[l], sh)) return rc;
     }
-    if (int rc = upload(o, &o->d_w1, o->w[0])) return rc;                       // [9][2][C] as stored
+    if (o->cin == 2) {
+        if (int rc = upload(o, &o->d_w1, o->w[0])) return rc;                   // [9][2][C] as stored
+    } else {
+        // one plane x in {+1, 0, -1} = own - opp:  x*w == own*w + opp*(-w) exactly, so the two-plane kernels serve BaseNN
+        std::vector<float> w2((size_t)9 * 2 * C);
+        for (int t = 0; t < 9; ++t)
+            for (int c = 0; c < C; ++c) { w2[(size_t)(t * 2) * C + c] = o->w[0][(size_t)t * C + c]; w2[(size_t)(t * 2 + 1) * C + c] = -o->w[0][(size_t)t * C + c]; }
+        if (int rc = upload(o, &o->d_w1, w2)) return rc;
+    }
     // conv2..4 kernels (3,3,Cin,Cout) -> [Cout][K], k = tap*Cin + ci ; dense (in,out) -> [out][in]
     const int gl[5] = {6, 12, 18, 24, 30};
     const int Ks[5] = {9 * C, 9 * C, 9 * C, o->F, 1024}, Ns[5] = {C, C, C, 1024, 512};

@@ -23,8 +23,8 @@ class OthelloMCTS:
         OZ_QMODE_NEP50 = what NumPy >= 2 computes (SURVEY.md R-FP)."""
         self._board_size = board_size
         self._neural_network = neural_network
-        if neural_network.network_type is not NeuralNets.ONN and getattr(neural_network.network_type, "name", "") != "ONN":
-            raise NotImplementedError("only the two-channel (ONN) board view is implemented")
+        # othelo_mcts.py:15-18: ONN nets see the two-channel board, BNN nets the one-channel (+1 / -1) view
+        self._one_channel = getattr(neural_network.network_type, "name", "") == "BNN"
         self.degree_explorarion = degree_exploration
         self._q_mode = q_mode
         self._node_cap = node_cap
@@ -83,7 +83,10 @@ class OthelloMCTS:
             _lib.check(lib.oz_mcts_select(self._h))
             _lib.check(lib.oz_mcts_leaves(self._h, _lib.p_i32(status), _lib.p_u64(lo), _lib.p_u64(lp)))
             if status[0] == _lib.LEAF_EVAL:
-                p, val = self._neural_network.predict(_lib.unpack_board(int(lo[0]), int(lp[0]), n))
+                leaf = _lib.unpack_board(int(lo[0]), int(lp[0]), n)
+                if self._one_channel:                      # othelo_mcts.py:85-86
+                    leaf = OthelloGame.convert_to_one_channel_board(leaf)
+                p, val = self._neural_network.predict(leaf)
                 pi[0] = np.asarray(p, dtype=np.float32).reshape(-1)
                 v[0] = val
             _lib.check(lib.oz_mcts_backup(self._h, _lib.p_f32(pi), _lib.p_f32(v)))

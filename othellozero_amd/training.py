@@ -41,9 +41,8 @@ def execute_episode(board_size, neural_network, degree_exploration, num_simulati
     game = OthelloGame(board_size)
     mcts = OthelloMCTS(board_size, neural_network, degree_exploration, q_mode=q_mode,
                        node_cap=num_simulations * (board_size * board_size - 3) + 64)
-    if neural_network.network_type is not NeuralNets.ONN and getattr(neural_network.network_type, "name", "") != "ONN":
-        raise NotImplementedError("only NeuralNets.ONN is implemented")
-    board_view_type = BoardView.TWO_CHANNELS
+    # training.py:34-37 (BNN examples are one-channel boards, a fresh array per round: no aliasing for them)
+    board_view_type = BoardView.ONE_CHANNEL if getattr(neural_network.network_type, "name", "") == "BNN" else BoardView.TWO_CHANNELS
 
     while not game.has_finished():
         state = game.board(BoardView.TWO_CHANNELS)

@@ -10,10 +10,11 @@ index  array
 import numpy as np
 
 
-def onn_shapes(n, channels=512):
+def onn_shapes(n, channels=512, in_channels=2):
+    """in_channels = 2: OthelloNN (Net/OthelloNN.py), 1: BaseNN (Net/BaseNN.py) -- same trunk, one input plane"""
     C = channels
     shapes = []
-    for cin in (2, C, C, C):
+    for cin in (in_channels, C, C, C):
         shapes += [(3, 3, cin, C), (C,), (C,), (C,), (C,), (C,)]
     shapes += [((n - 4) * (n - 4) * C, 1024)] + [(1024,)] * 5
     shapes += [(1024, 512)] + [(512,)] * 5
@@ -31,12 +32,12 @@ def _glorot_uniform(rs, shape):
     return rs.uniform(-lim, lim, size=shape).astype(np.float32)
 
 
-def init_weights(n, seed=0, channels=512, randomize_all=False):
+def init_weights(n, seed=0, channels=512, randomize_all=False, in_channels=2):
     """Keras defaults (glorot_uniform kernels, zero bias, BN gamma=1 beta=0 mean=0 var=1).
     randomize_all=True also draws biases and BN statistics (numerics tests)."""
     rs = np.random.RandomState(seed)
     out = []
-    for i, shp in enumerate(onn_shapes(n, channels)):
+    for i, shp in enumerate(onn_shapes(n, channels, in_channels)):
         if len(shp) >= 2:
             out.append(_glorot_uniform(rs, shp))
             continue

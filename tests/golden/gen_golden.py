@@ -22,6 +22,7 @@ Fixtures:
   mcts.npz       search traces: expanded boards in order + full (Ns, Nsa, Qsa, Psa) tables, simulate() returns
   episodes.npz   execute_episode traces (moves, snapshots, root counts, returned examples, z)
   arena.npz      duel_between_agents traces
+  episodes_bnn.npz  execute_episode through the one-channel (BaseNN) board view
 """
 import enum
 import os
@@ -500,7 +501,56 @@ def arena_fixture():
     np.savez_compressed(os.path.join(OUT, "arena.npz"), **out)
 
 
+
+
+# ---------------------------------------------------------------- BaseNN (one-channel view) episode
+class StubNetBNN(StubNet):
+    """same integer-hash net, reached through the one-channel board view (othelo_mcts.py:17-18,85-86)"""
+    network_type = NeuralNets.BNN
+
+    def predict(self, board):
+        b = np.asarray(board)
+        assert b.ndim == 2
+        return StubNet.predict(self, np.stack([b == 1, b == -1], axis=2))
+
+
+def bnn_fixture():
+    specs = [("ep6_bnn", 6, 40, 1, 1, 0.9, 1234, 9, 111, 0, "nep50"), ("ep8_bnn_f64", 8, 25, 1, 1, 0.9, 1234, 10, 112, 0, "f64")]
+    out, names = {}, []
+    saved = patched_rng()
+    training.OthelloGame = CountingGame
+    try:
+        for name, n, sims, c, T, eg, seed, game, salt, keep, regime in specs:
+            Ctx.seed, Ctx.game, Ctx.ply, Ctx.counts = seed, game, 0, []
+            CountingGame.log = []
+            net = StubNetBNN(n, salt, keep, regime)
+            ex = training.execute_episode(n, net, c, sims, T, eg)
+            log = CountingGame.log
+            k = len(log)
+            assert len(ex) == 8 * k
+            out[f"{name}/meta"] = np.array([n, sims, seed, game, salt, keep, 0 if regime == "nep50" else 1, k], dtype=np.int64)
+            out[f"{name}/params"] = np.array([float(c), float(T), float(eg)])
+            out[f"{name}/action"] = np.array([x[3] for x in log], dtype=np.uint8)
+            out[f"{name}/player"] = np.array([x[2] for x in log], dtype=np.int8)
+            eb = np.zeros((8 * k, 2), np.uint64); ep = np.zeros(8 * k, np.int32); ez = np.zeros(8 * k, np.int8)
+            for i, (b, p, z) in enumerate(ex):
+                assert b.ndim == 2 and p.dtype == np.float64 and isinstance(z, int)
+                eb[i] = pack(np.stack([b == 1, b == -1], axis=2))
+                nz = np.argwhere(p == 1.0)
+                ep[i] = nz[0][0] * n + nz[0][1]
+                ez[i] = z
+            out[f"{name}/ex_board"] = eb; out[f"{name}/ex_policy"] = ep; out[f"{name}/ex_z"] = ez
+            out[f"{name}/dtype"] = np.array([str(ex[0][0].dtype)])
+            names.append(name)
+            print("bnn episode", name, "moves", k, "board dtype", ex[0][0].dtype)
+    finally:
+        restore_rng(saved)
+        training.OthelloGame = OthelloGame
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "episodes_bnn.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rules", "pairwise", "symmetries", "mcts", "episodes", "arena"]
+    which = sys.argv[1:] or ["rules", "pairwise", "symmetries", "mcts", "episodes", "arena", "bnn"]
     for w in which:
         globals()[w + "_fixture"]()

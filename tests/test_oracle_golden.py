@@ -213,3 +213,22 @@ def test_stub_net_python_callback_equals_builtin():
     assert len(da) == len(db)
     for x, y in zip(da, db):
         assert x["k0"] == y["k0"] and np.array_equal(x["Q"], y["Q"]) and np.array_equal(x["P"], y["P"])
+
+
+def test_episodes_one_channel_view():
+    """BaseNN path (training.py:34-37,61-65): same search, examples are per-move one-channel snapshots (no aliasing)"""
+    g = load_golden("episodes_bnn.npz")
+    for name in g["names"]:
+        name = str(name)
+        n, sims, seed, game, salt, keep, qmode, k = (int(x) for x in g[f"{name}/meta"])
+        c, T, eg = (float(x) for x in g[f"{name}/params"])
+        ep = oracle.Mcts(n, c, qmode, salt=salt, keep_mask=keep).episode(sims, T, eg, seed, game)
+        assert ep["n_moves"] == k and np.array_equal(ep["action"], g[f"{name}/action"]), name
+        perms = oracle.symmetry_perms(n)
+        for i in range(k):
+            snap = oracle.unpack_board(ep["black"][i], ep["white"][i], n).reshape(n * n, 2)
+            a = int(ep["action"][i]); a = (a >> 3) * n + (a & 7)
+            for t in range(8):
+                assert oracle.pack_board(snap[perms[t]].reshape(n, n, 2)) == tuple(int(x) for x in g[f"{name}/ex_board"][8 * i + t])
+                assert int(np.nonzero(perms[t] == a)[0][0]) == int(g[f"{name}/ex_policy"][8 * i + t])
+                assert int(ep["z"][i]) == int(g[f"{name}/ex_z"][8 * i + t])
