@@ -60,30 +60,30 @@ def roofline(precision, achieved, conv2_ms, launches, expansions, n, channels):
     return r
 
 
-def cpu_baseline(n, channels, sims, budget_s=15.0):
+def cpu_baseline(n, channels, sims, budget_s=12.0):
     """The oracle port of the reference path (sequential simulations, one game, batch-1 leaf evaluation by the
-    float32 C restatement of OthelloNN on all host cores), timed on a bounded sample: the first plies of one game."""
+    float32 C restatement of OthelloNN on all host cores), timed on a bounded sample of about budget_s seconds."""
     import oracle
     from othellozero_amd.weights import init_weights
     w = init_weights(n, seed=0, channels=channels)
     threads = min(oracle.lib().orc_nn_max_threads(), 16)        # the box's CPU share for one GPU
     net = oracle.CNet(w, n, channels=channels, nthreads=threads)
 
-    def run(max_moves):
-        m = oracle.Mcts(n, 1.0, oracle.QMODE_F64, evaluator=net.evaluator())
+    def run(game_id, max_moves):
+        m = oracle.Mcts(n, 1.0, oracle.QMODE_F64, evaluator=net.evaluator())        # a fresh tree per episode (training.py:29)
         t0 = time.perf_counter()
-        ep = m.episode(sims, 1.0, 0.9, 1234, 0, max_moves=max_moves)
+        ep = m.episode(sims, 1.0, 0.9, 1234, game_id, max_moves=max_moves)
         return time.perf_counter() - t0, ep
-    t1, ep1 = run(1)
-    moves = max(1, min(n * n - 4, int(budget_s / max(t1, 1e-3))))
-    if moves > 1:
-        t1, ep1 = run(moves)
-    exp = ep1["stats"]["expansions"]
+    run(0, 1)                                                                        # untimed: thread pool / cache warm-up
+    t, exp, plies, games = 0.0, 0, 0, 0
+    while t < budget_s and games < 64:                                               # whole games until the budget is used
+        dt, ep = run(games, n * n)
+        t, exp, plies, games = t + dt, exp + ep["stats"]["expansions"], plies + ep["n_moves"], games + 1
     return {
-        "value": exp / t1, "unit": "node-expansions/s", "cores": threads, "kind": "port",
-        "sample": f"first {ep1['n_moves']} plies of one {n}x{n} game at {sims} sims/move "
-                  f"({exp} expansions, {ep1['n_moves'] * sims} sims, {t1:.1f} s), batch-1 leaf eval, OpenMP x{threads}",
-        "sims_per_s": ep1["n_moves"] * sims / t1,
+        "value": exp / t, "unit": "node-expansions/s", "cores": threads, "kind": "port",
+        "sample": f"{plies} plies of {games} sequential {n}x{n} game(s) at {sims} sims/move "
+                  f"({exp} expansions, {plies * sims} sims, {t:.1f} s), batch-1 leaf eval, OpenMP x{threads}",
+        "sims_per_s": plies * sims / t,
     }
 
 

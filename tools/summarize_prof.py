@@ -1,0 +1,122 @@
+"""Turn rocprofv3 output directories into the summaries kept under profiles/.
+
+  python tools/summarize_prof.py trace  <rocprof_dir> <out_csv>  "<header comment>"
+  python tools/summarize_prof.py pmc    <out_csv> "<header comment>" <rocprof_dir> [<rocprof_dir> ...]
+  python tools/summarize_prof.py traffic <pmc_by_shape_csv> <out_json> <precision> <conv2 kernel substring> <grid_threads>
+
+`trace`   : per (kernel, grid) averages from *_kernel_trace.csv; the OthelloNN layers are recognised by grid size
+            (4096 leaves per launch) and get their algorithmic fp32 TFLOP/s.
+`pmc`     : per (kernel, grid, counter) per-launch averages from one or more *_counter_collection.csv (separate passes).
+`traffic` : conv2's HBM bytes per launch -> the json bench.py reads for roofline.traffic
+            (gfx950: FETCH_SIZE is in KB and counts half of wide coalesced reads -> x2; WRITE_SIZE in KB).
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+LEAVES = 4096
+# layer -> (fp32 FLOP per leaf); K, N of the implicit GEMM x output pixels per leaf x 2
+FLOP = {"conv2": 2 * 64 * 4608 * 512, "conv3": 2 * 36 * 4608 * 512, "conv4": 2 * 16 * 4608 * 512,
+        "fc1": 2 * 8192 * 1024, "fc2": 2 * 1024 * 512}
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name)
+
+
+def find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return hits[-1]
+
+
+def trace(d, out, header):
+    rows = defaultdict(list)
+    with open(find(d, "_kernel_trace.csv")) as f:
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            if k.startswith("__amd") or "at::" in k or "elementwise" in k:
+                continue
+            grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+            wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+            rows[(k, grid, wg, int(r["LDS_Block_Size"]), int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"]),
+                  int(r["Scratch_Size"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    # name the GEMM launches: order the gemm shapes by total time -> conv2 > conv3 > conv4 > fc1 > fc2 holds for this net
+    gemm = sorted((k for k in rows if "k_gemm" in k[0] and len(rows[k]) >= 50), key=lambda k: -sum(rows[k]))
+    names = {}
+    for k, lay in zip(gemm, ("conv2", "conv3", "conv4", "fc1", "fc2")):
+        names[k] = lay
+    with open(out, "w") as f:
+        f.write(f"# {header}\n")
+        f.write("# per (kernel, grid) averages from the kernel trace; 4096 leaves per launch; TFLOP_per_s = ALGORITHMIC fp32 FLOP "
+                "(precision f16x2 executes 3x that on the matrix pipe)\n")
+        f.write("kernel,grid_threads,wg,lds_bytes,vgpr,agpr,scratch,calls,avg_us,min_us,max_us,total_ms,layer,algorithmic_TFLOP_per_s\n")
+        for k in sorted(rows, key=lambda k: -sum(rows[k])):
+            t = rows[k]
+            avg = sum(t) / len(t)
+            lay = names.get(k, "")
+            tf = f"{FLOP[lay] * LEAVES / (avg * 1e-9) / 1e12:.1f}" if lay else ""
+            f.write(f"\"{k[0]}\",{k[1]},{k[2]},{k[3]},{k[4]},{k[5]},{k[6]},{len(t)},{avg / 1e3:.1f},{min(t) / 1e3:.1f},"
+                    f"{max(t) / 1e3:.1f},{sum(t) / 1e6:.1f},{lay},{tf}\n")
+
+
+def pmc(out, header, dirs):
+    acc = defaultdict(lambda: [0.0, 0])
+    for d in dirs:
+        with open(find(d, "_counter_collection.csv")) as f:
+            for r in csv.DictReader(f):
+                k = short(r["Kernel_Name"])
+                if k.startswith("__amd") or "at::" in k or "elementwise" in k:
+                    continue
+                a = acc[(k, int(r["Grid_Size"]), r["Counter_Name"])]
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+    with open(out, "w") as f:
+        f.write(f"# {header}\n")
+        f.write("# per-launch averages; FETCH_SIZE/WRITE_SIZE in KB as reported (gfx950: FETCH_SIZE counts 1/2 of wide coalesced "
+                "reads -> x2 when converted to bytes)\n")
+        f.write("kernel,grid_threads,counter,avg_per_launch,launches\n")
+        for (k, g, c), (s, n) in sorted(acc.items()):
+            f.write(f"\"{k}\",{g},{c},{s / n:.6g},{n}\n")
+
+
+def traffic(src, out, precision, kernel_sub, grid):
+    vals = {}
+    with open(src) as f:
+        for r in csv.DictReader(l for l in f if not l.startswith("#")):
+            if kernel_sub in r["kernel"] and int(r["grid_threads"]) == int(grid):
+                vals[r["counter"]] = float(r["avg_per_launch"])
+    fetch = vals["FETCH_SIZE"] * 1024 * 2
+    write = vals["WRITE_SIZE"] * 1024
+    j = {"round": 1, "precision": precision, "kernel": f"{kernel_sub} conv2", "leaves_per_launch": LEAVES,
+         "fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+         "hbm_bytes_per_leaf": (fetch + write) / LEAVES,
+         "algorithmic_bytes_per_leaf": 264448.0 if precision == "f16x2" else 262144.0 + 18 * 512 * 512 * 4 / LEAVES,
+         "source": src}
+    if "GRBM_GUI_ACTIVE" in vals:                  # summed over the 8 XCDs
+        j["gpu_cycles_per_launch"] = vals["GRBM_GUI_ACTIVE"] / 8
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in vals:     # summed over 256 CUs x 4 SIMDs
+            j["mfma_busy_frac"] = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (vals["GRBM_GUI_ACTIVE"] / 8 * 1024)
+    if "SQ_LDS_BANK_CONFLICT" in vals:
+        j["lds_bank_conflict_cycles"] = vals["SQ_LDS_BANK_CONFLICT"]
+    with open(out, "w") as f:
+        json.dump(j, f, indent=1)
+    print(json.dumps(j))
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    if mode == "trace":
+        trace(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif mode == "pmc":
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4:])
+    elif mode == "traffic":
+        traffic(*sys.argv[2:7])
+    else:
+        raise SystemExit(__doc__)
