@@ -3,15 +3,15 @@
 Same constructor arguments, `.network_type`, `.predict(board) -> (pi (n,n) float32, v float32)`,
 `.copy()`, `.save_checkpoint(path)`, `.load_checkpoint(path)`.  Added: `.predict_batch`,
 `.get_weights()/.set_weights()` (keras Model.get_weights() order), `StubNetWrapper`.
-Training (`.train`, Net/NNet.py:53-68) and Keras HDF5 files are out of this round's scope
-(SURVEY.md section 8(f)); they raise NotImplementedError instead of silently doing something else.
+Checkpoints are Keras HDF5 weight files (keras_h5.py).  Training (`.train`, Net/NNet.py:53-68) is out of this
+round's scope and raises NotImplementedError instead of silently doing something else.
 """
 import ctypes as C
 from enum import Enum, auto
 
 import numpy as np
 
-from . import _lib
+from . import _lib, keras_h5
 from .weights import init_weights, onn_shapes
 
 
@@ -34,9 +34,13 @@ class _NetHandle:
 
 
 class NNetWrapper(_NetHandle):
+    _models_built = 0          # Keras numbers layer names per process (conv2d, ..., conv2d_4, ...); checkpoints keep that
+
     def __init__(self, board_size=(8, 8), batch_size=32, epochs=10, num_channels_1=512, num_channels_2=256,
                  lr=0.001, dropout=0.3, network=NeuralNets.ONN, max_batch=1, seed=0, weights=None, precision="f32"):
         super().__init__()
+        self._model_index = NNetWrapper._models_built
+        NNetWrapper._models_built += 1
         self.board_size_x, self.board_size_y = board_size
         assert self.board_size_x == self.board_size_y, "square boards only"
         self.action_size = self.board_size_x * self.board_size_y
@@ -106,20 +110,36 @@ class NNetWrapper(_NetHandle):
         raise NotImplementedError("NNetWrapper.train (Net/NNet.py:53-68) is outside the self-play hot path "
                                   "(SURVEY.md section 8(f) item 2)")
 
-    # ---- checkpoints: the reference writes Keras HDF5 (Net/NNet.py:90-96); h5py is not available here, so
-    # checkpoints are .npz files holding the same 40 arrays in get_weights() order.
+    # ---- checkpoints (Net/NNet.py:90-96): Keras HDF5 weight files, read and written by keras_h5.py (no h5py needed);
+    # files saved by the reference load here and the other way round.  A path ending in .npz selects a plain
+    # NumPy archive of the same 40 arrays instead (an extension of this build).
     def save_checkpoint(self, filepath):
-        if filepath.endswith(".h5"):
-            raise NotImplementedError("Keras HDF5 checkpoints need an HDF5 writer (SURVEY.md section 8(f) item 1); "
-                                      "use a .npz path")
-        np.savez(filepath, *self.get_weights())
+        """model.save_weights(filepath, save_format='h5')"""
+        if filepath.endswith(".npz"):
+            np.savez(filepath, *self.get_weights())
+            return
+        layers = keras_h5.keras_layer_table(self.get_weights(), self._model_index, self.network_type.name)
+        keras_h5.save_keras_weights(filepath, layers)
 
     def load_checkpoint(self, filepath):
-        if filepath.endswith(".h5"):
-            raise NotImplementedError("Keras HDF5 checkpoints need an HDF5 reader (SURVEY.md section 8(f) item 1); "
-                                      "use a .npz path")
-        with np.load(filepath if filepath.endswith(".npz") else filepath + ".npz") as z:
-            self.set_weights([z[f"arr_{i}"] for i in range(len(z.files))])
+        """model.load_weights(filepath): layers with weights are matched BY ORDER, as Keras does; a file whose
+        weighted-layer count or shapes differ from this network raises ValueError."""
+        if filepath.endswith(".npz"):
+            with np.load(filepath) as z:
+                self.set_weights([z[f"arr_{i}"] for i in range(len(z.files))])
+            return
+        assert filepath.endswith('.h5'), 'Expecting a file with .h5 as extension'
+        layers = [(name, ws) for name, ws in keras_h5.load_keras_weights(filepath) if ws]
+        if len(layers) != 14:
+            raise ValueError(f"You are trying to load a weight file containing {len(layers)} layers into a model with 14 layers.")
+        flat = keras_h5.flat_weights(layers)
+        shapes = onn_shapes(self.board_size_x, self.num_channels, self.in_channels)
+        if len(flat) != len(shapes):
+            raise ValueError(f"the file holds {len(flat)} weight arrays, this network has {len(shapes)}")
+        for i, (a, shp) in enumerate(zip(flat, shapes)):
+            if tuple(a.shape) != tuple(shp):
+                raise ValueError(f"weight {i} of the file has shape {tuple(a.shape)}, this network expects {tuple(shp)}")
+        self.set_weights(flat)
 
     def copy(self):
         return NNetWrapper((self.board_size_x, self.board_size_y), network=self.network_type,
