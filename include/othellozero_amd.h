@@ -199,6 +199,33 @@ int oz_examples_expand(const oz_record* records, int64_t count, int n, int alias
                        int32_t* policy_index, int8_t* z);
 int oz_symmetry_table(int n, int32_t* perm /* [8][n*n] source index of every output cell */);
 
+/* ------------------------------------------------------------------ training step
+ * NNetWrapper.train (Net/NNet.py:53-68) = keras Model.fit on Net/OthelloNN.py:42-56 / Net/BaseNN.py:41-57:
+ * losses categorical_crossentropy (on the (n, n)-reshaped policy: per-row renormalisation, see oz_train.hip) +
+ * mean_squared_error, Adam(lr, clipvalue) in tf.keras' formulation, BatchNormalization in training mode
+ * (momentum bn_momentum, eps 1e-3), inverted Dropout with a counter-based mask keyed (seed, step, layer, element).
+ * Weights use the same 40-array get_weights() indexing as oz_net_set_weight.  One optimiser step =
+ * oz_trainer_forward_backward (gradients of the batch-mean loss into the gradient arena) + oz_trainer_apply; a
+ * data-parallel job all-reduces (averages) the arena between the two calls.  `external_grads` may point to a caller-
+ * owned device buffer of oz_trainer_arena_size floats (e.g. a torch tensor handed to RCCL); NULL = library-owned. */
+typedef struct oz_trainer oz_trainer;
+int oz_trainer_arena_size(int n, int channels, int in_channels, int64_t* nelem);
+int oz_trainer_create(oz_trainer** out, int n, int channels, int in_channels, int max_batch, float lr, float clipvalue /* <= 0: none */,
+                      float dropout, float bn_momentum, uint64_t seed, float* external_grads);
+int oz_trainer_destroy(oz_trainer* t);
+int oz_trainer_set_weight(oz_trainer* t, int index, const float* data, int64_t nelem);
+int oz_trainer_get_weight(oz_trainer* t, int index, float* data, int64_t nelem);
+int oz_trainer_get_grad(oz_trainer* t, int index, float* data, int64_t nelem);      /* trainable arrays only */
+int oz_trainer_grad_arena(oz_trainer* t, void** device_ptr, int64_t* nelem);
+/* boards as bitboards: own = channel 0, opp = channel 1 of the example board (BaseNN: +1 / -1 squares);
+ * pi_target [B][n*n], z_target [B]; losses3 = {total, policy, value} batch means.  Synchronous. */
+int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const uint64_t* opp, const float* pi_target,
+                                const float* z_target, int B, float* losses3);
+int oz_trainer_apply(oz_trainer* t);                         /* Adam step + BN moving-statistics commit (stream-ordered) */
+int oz_trainer_outputs(oz_trainer* t, int B, float* p /* [B][n*n] */, float* v /* [B] */);   /* of the last forward pass */
+int oz_trainer_sync(oz_trainer* t);
+int oz_trainer_step_count(oz_trainer* t, int64_t* step);
+
 /* ------------------------------------------------------------------ diagnostics
  * device arithmetic behind the PUCT / backup formulas (MCTS/__init__.py:68,168-170), for bit-exact
  * comparison with the host: sqrt(a), a/b in float64; a/b and (a*b+a)/b in float32 (no FMA contraction). */

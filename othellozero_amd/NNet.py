@@ -106,9 +106,28 @@ class NNetWrapper(_NetHandle):
         pi, v = self.predict_batch(np.array([own], np.uint64), np.array([opp], np.uint64))
         return pi[0], v[0]
 
-    def train(self, examples, verbose=None):
-        raise NotImplementedError("NNetWrapper.train (Net/NNet.py:53-68) is outside the self-play hot path "
-                                  "(SURVEY.md section 8(f) item 2)")
+    def train(self, examples, verbose=None, seed=None, allreduce=None):
+        """Net/NNet.py:53-68: model.fit(x=boards, y=[pis, vs], batch_size=self.batch_size, epochs=self.epochs) on the GPU
+        (oz_trainer_*: fp32 MFMA forward / backward, Adam lr=self.lr with clipvalue 0.5 for ONN / none for BNN, Dropout
+        self.dropout, BN momentum 0.99).  Returns a History-like object (`.history['loss']`, ...).  The TensorBoard
+        callback of the reference is not reproduced.  Optimiser state persists across calls like the compiled Keras model's."""
+        from . import trainer as T
+        if not examples:
+            return T.History()
+        own, opp, pi, z = T.pack_examples(examples, self.board_size_x, self.in_channels)
+        if getattr(self, "_trainer", None) is None:
+            assert self.num_channels % 128 == 0, "the training kernels need num_channels % 128 == 0"
+            self._trainer = T.Trainer(self.board_size_x, self.num_channels, self.in_channels, max_batch=self.batch_size, lr=self.lr,
+                                      clipvalue=0.5 if self.network_type is NeuralNets.ONN else 0.0, dropout=self.dropout,
+                                      seed=self._model_index if seed is None else seed)
+            self._fit_calls = 0
+        self._trainer.set_weights(self.get_weights())
+        hist = T.fit(self._trainer, own, opp, pi, z, batch_size=self.batch_size, epochs=self.epochs,
+                     shuffle_seed=1000003 * self._fit_calls + (self._model_index if seed is None else seed), allreduce=allreduce,
+                     verbose=verbose)
+        self._fit_calls += 1
+        self.set_weights(self._trainer.get_weights())
+        return hist
 
     # ---- checkpoints (Net/NNet.py:90-96): Keras HDF5 weight files, read and written by keras_h5.py (no h5py needed);
     # files saved by the reference load here and the other way round.  A path ending in .npz selects a plain

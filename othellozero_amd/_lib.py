@@ -100,6 +100,19 @@ SIGNATURES = {
     "oz_examples_expand": [_vp, C.c_int64, C.c_int, C.c_int, _u8p, _i32p, _i8p],
     "oz_symmetry_table": [C.c_int, _i32p],
     "oz_selftest_arith": [_f64p, _f64p, C.c_int, _f64p, _f64p, _f32p, _f32p],
+    "oz_trainer_arena_size": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)],
+    "oz_trainer_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                          C.c_uint64, _vp],
+    "oz_trainer_destroy": [_vp],
+    "oz_trainer_set_weight": [_vp, C.c_int, _f32p, C.c_int64],
+    "oz_trainer_get_weight": [_vp, C.c_int, _f32p, C.c_int64],
+    "oz_trainer_get_grad": [_vp, C.c_int, _f32p, C.c_int64],
+    "oz_trainer_grad_arena": [_vp, C.POINTER(_vp), C.POINTER(C.c_int64)],
+    "oz_trainer_forward_backward": [_vp, _u64p, _u64p, _f32p, _f32p, C.c_int, _f32p],
+    "oz_trainer_apply": [_vp],
+    "oz_trainer_outputs": [_vp, C.c_int, _f32p, _f32p],
+    "oz_trainer_sync": [_vp],
+    "oz_trainer_step_count": [_vp, C.POINTER(C.c_int64)],
 }
 
 _LIB = None

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libothellozero_amd.so")
-SOURCES = ["oz_rules.hip", "oz_search.hip", "oz_net.hip"]
+SOURCES = ["oz_rules.hip", "oz_search.hip", "oz_net.hip", "oz_train.hip"]
 HEADERS = ["oz_common.h", "oz_internal.h", "oz_net_h2.h", os.path.join("..", "..", "include", "othellozero_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         return r.stderr
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=3) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
         for warn in ex.map(run, jobs):
             if verbose and warn:
                 print(warn)

@@ -25,3 +25,14 @@ struct oz_net {
 
 int oz_net_forward_device(oz_net* net, const uint64_t* d_own, const uint64_t* d_opp, const int* d_count,
                           int max_count, float* d_pi, float* d_v, hipStream_t s);
+
+// implicit-GEMM geometry of k_gemm_f32 (oz_net.hip): out[M][N] = act((A[M][K] . Wt[N][K]^T) * scale + shift),
+// M = *d_count * Hout^2 rows (b, oy, ox); A rows are gathered per 3x3 tap with zero fill
+struct GemmGeom {
+    int Hin, Hout, pad, Cin, taps;   // taps = 9 (3x3 conv) or 1 (dense: Hin = Hout = 1, pad = 0)
+    int N, K;                        // output channels, taps*Cin
+    int relu;
+};
+int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
+                       const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
+                       hipStream_t s);

@@ -69,11 +69,6 @@ __global__ __launch_bounds__(256) void k_conv1(const uint64_t* __restrict__ own,
 #define GM_BK 32
 #define GM_LDS_STRIDE 36   // floats per staged row: 32 + 4 pad -> conflict-free ds_read_b128 / ds_write_b128
 
-struct GemmGeom {
-    int Hin, Hout, pad, Cin, taps;   // taps = 9 (3x3 conv) or 1 (dense: Hin = Hout = 1, pad = 0)
-    int N, K;                        // output channels, taps*Cin
-    int relu;
-};
 
 // out[M][N] = act((A[M][K] . Wt[N][K]^T) * scale + shift), M = *d_count * Hout^2, rows (b, oy, ox)
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ in, const float* __restrict__ Wt,
@@ -188,6 +183,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
                 }
             }
     }
+}
+
+// shared launcher (inference f32 path and the training step, oz_train.hip)
+int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
+                       const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
+                       hipStream_t s) {
+    OZ_REQUIRE(N % GM_BN == 0 && Cin % GM_BK == 0, "gemm_f32: N %% 128 and Cin %% 32 must be 0 (N=%d Cin=%d)", N, Cin);
+    GemmGeom g;
+    g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.relu = relu;
+    const long long Mmax = (long long)max_count * Hout * Hout;
+    const int num_mt = (int)((Mmax + GM_BM - 1) / GM_BM);
+    const int grid = ((num_mt + 7) / 8) * 8 * (N / GM_BN);
+    hipLaunchKernelGGL(k_gemm_f32, dim3(grid), dim3(256), 0, s, in, Wt, scale, shift, out, d_count, g, num_mt);
+    OZ_HIP(hipGetLastError());
+    return OZ_OK;
 }
 
 #include "oz_net_h2.h"
@@ -335,14 +345,7 @@ struct OnnNet : oz_net {
 
     int launch_gemm(const float* in, const float* Wt, int layer, float* out, const int* d_count, int max_count, int Hin,
                     int Hout, int pad, int Cin, int taps, int N, hipStream_t s) {
-        GemmGeom g;
-        g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.relu = 1;
-        const long long Mmax = (long long)max_count * Hout * Hout;
-        const int num_mt = (int)((Mmax + GM_BM - 1) / GM_BM);
-        const int grid = ((num_mt + 7) / 8) * 8 * (N / GM_BN);
-        hipLaunchKernelGGL(k_gemm_f32, dim3(grid), dim3(256), 0, s, in, Wt, d_scale[layer], d_shift[layer], out, d_count, g, num_mt);
-        OZ_HIP(hipGetLastError());
-        return OZ_OK;
+        return oz_gemm_f32_launch(in, Wt, d_scale[layer], d_shift[layer], out, d_count, max_count, Hin, Hout, pad, Cin, taps, N, 1, s);
     }
 
     // layer: 1..3 = conv2..4 (3x3, Cin = N = C), 4 = fc1, 5 = fc2 (taps 1)

@@ -1,0 +1,713 @@
+// oz_train.hip -- one optimiser step of OthelloNN / BaseNN on gfx950.
+//
+// Replaces NNetWrapper.train (Net/NNet.py:53-68) = keras Model.fit on the graph of Net/OthelloNN.py:42-56 compiled
+// with loss=['categorical_crossentropy','mean_squared_error'], Adam(lr, clipvalue=0.5) (BaseNN.py:57: no clipvalue).
+// Semantics (restated in oracle/train_ref.py, which is what the parity tests compare with):
+//   * BatchNormalization in training mode: batch mean / BIASED batch variance, eps 1e-3, momentum 0.99; the 4-D conv BNs
+//     run Keras' fused kernel whose moving-variance update uses the UNBIASED variance, the dense BNs the biased one.
+//   * the policy loss is Keras' probability-path categorical cross-entropy applied to the RESHAPED (B, n, n) output:
+//     every board row is renormalised, clipped to [1e-7, 1-1e-7], -sum(t log q) per row, mean over batch x rows.
+//   * value loss: mean squared error; total = pi + v.   * Dropout: inverted, counter-based keep mask.
+//   * Adam as tf.keras: lr_t = lr sqrt(1-b2^t)/(1-b1^t); var -= lr_t m / (sqrt(v) + 1e-7); clipvalue clips g first.
+//
+// All contractions run on the fp32 matrix cores: forward and data-gradient passes reuse k_gemm_f32 (oz_net.hip; the
+// data gradient of a 3x3 convolution is a 3x3 convolution with the taps reversed and the channel roles swapped, 'valid'
+// layers through a zero-bordered buffer), the weight gradient is k_wgrad_f32 below (a "TN" implicit GEMM whose k
+// index is the batch x pixel row).  Column reductions (BN statistics, BN backward sums, bias gradients) use a
+// fixed-order two-stage reduction, so a step is deterministic.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "oz_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BN_EPS 1e-3f
+#define RED_S 32          // row splits of the column reductions
+
+// ---------------------------------------------------------------- dropout hash (same formula in oracle/train_ref.py)
+OZ_HD bool oz_dropout_keep(uint64_t seed, uint64_t step, uint64_t layer, uint64_t idx, float rate) {
+    const uint64_t a = oz_sm64(seed + 0x632BE59BD9B4E019ULL * step);
+    const uint64_t h = oz_sm64(a ^ ((layer + 1) * 0xD1B54A32D192ED03ULL) ^ (idx * 0x9E3779B97F4A7C15ULL));
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+    return u >= rate;
+}
+
+// ---------------------------------------------------------------- conv1 forward (raw, + bias) and its weight gradient
+// x[b][iy][ix][ch]: cin = 2 -> (own bit, opp bit); cin = 1 -> own bit - opp bit (Net/BaseNN.py:41-44)
+__device__ __forceinline__ float t_plane(uint64_t o, uint64_t p, int sq, int ch, int cin) {
+    const float a = (float)((o >> sq) & 1), b = (float)((p >> sq) & 1);
+    return cin == 2 ? (ch == 0 ? a : b) : a - b;
+}
+
+__global__ __launch_bounds__(256) void k_t_conv1_fwd(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
+                                                     const int* __restrict__ d_count, int n, int C, int cin,
+                                                     const float* __restrict__ W /*[9][cin][C]*/, const float* __restrict__ bias,
+                                                     float* __restrict__ z /*[B][n*n][C]*/) {
+    const int P = n * n;
+    const long long M = (long long)(*d_count) * P;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long m = idx / C;
+    if (m >= M) return;
+    const int co = (int)(idx % C);
+    const int b = (int)(m / P), pix = (int)(m % P), y = pix / n, x = pix % n;
+    const uint64_t o = own[b], p = opp[b];
+    float acc = 0.f;
+    for (int t = 0; t < 9; ++t) {
+        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+        if (iy < 0 || iy >= n || ix < 0 || ix >= n) continue;
+        for (int ch = 0; ch < cin; ++ch) acc = fmaf(t_plane(o, p, iy * 8 + ix, ch, cin), W[(size_t)(t * cin + ch) * C + co], acc);
+    }
+    z[(size_t)m * C + co] = acc + bias[co];
+}
+
+// dW1[t][ch][co] = sum_m x[m shifted by t][ch] * dz[m][co]; block = (t*cin + ch, 256 output channels), rows split in RED_S
+__global__ __launch_bounds__(256) void k_t_conv1_wgrad(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
+                                                       const int* __restrict__ d_count, int n, int C, int cin,
+                                                       const float* __restrict__ dz, float* __restrict__ partial /*[RED_S][9*cin][C]*/) {
+    const int P = n * n, tc = blockIdx.x, t = tc / cin, ch = tc % cin;
+    const int co = blockIdx.y * 256 + threadIdx.x, sp = blockIdx.z;
+    if (co >= C) return;
+    const long long M = (long long)(*d_count) * P;
+    float acc = 0.f;
+    for (long long m = sp; m < M; m += RED_S) {
+        const int b = (int)(m / P), pix = (int)(m % P), y = pix / n + t / 3 - 1, x = pix % n + t % 3 - 1;
+        if (y < 0 || y >= n || x < 0 || x >= n) continue;
+        const float xv = t_plane(own[b], opp[b], y * 8 + x, ch, cin);
+        if (xv != 0.f) acc = fmaf(xv, dz[(size_t)m * C + co], acc);
+    }
+    partial[((size_t)sp * 9 * cin + tc) * C + co] = acc;
+}
+
+// out[i] = sum_s partial[s][i] in fixed order
+__global__ void k_t_sum_partials(const float* __restrict__ partial, int S, long long count, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += partial[(size_t)s * count + i];
+    out[i] = a;
+}
+
+// ---------------------------------------------------------------- column reductions over the rows of [M][C] matrices
+// MODE 0: sum x            MODE 1: sum (x - mean)^2
+// MODE 2: BN backward sums: dy = (a > 0 ? dA * post_scale : 0); s0 = sum dy, s1 = sum dy * xhat, xhat = (z - mean) * rstd
+// MODE 3: sum x with x stored in a zero-bordered buffer (rows (b, oy, ox) of an Hout^2 block at offset zoff in Hz^2)
+struct RedArgs {
+    const float *x, *a, *z, *mean, *rstd;
+    float post_scale;
+    int P, C, Hout, Hz, zoff;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void k_t_colreduce(RedArgs r, const int* __restrict__ d_count, float* __restrict__ partial /*[RED_S][2][C]*/) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane4 = threadIdx.x >> 6, sp = blockIdx.y;
+    const long long M = (long long)(*d_count) * r.P;
+    float s0 = 0.f, s1 = 0.f;
+    const float mu = (MODE == 1 || MODE == 2) ? r.mean[c] : 0.f, rs = MODE == 2 ? r.rstd[c] : 0.f;
+    for (long long m = sp * 4 + lane4; m < M; m += RED_S * 4) {
+        if (MODE == 0) s0 += r.x[(size_t)m * r.C + c];
+        if (MODE == 1) { const float d = r.x[(size_t)m * r.C + c] - mu; s0 = fmaf(d, d, s0); }
+        if (MODE == 2) {
+            const size_t o = (size_t)m * r.C + c;
+            const float dy = r.a[o] > 0.f ? r.x[o] * r.post_scale : 0.f;
+            s0 += dy;
+            s1 = fmaf(dy, (r.z[o] - mu) * rs, s1);
+        }
+        if (MODE == 3) {
+            const int HH = r.Hout * r.Hout, b = (int)(m / HH), pix = (int)(m % HH);
+            s0 += r.x[(((size_t)b * r.Hz + pix / r.Hout + r.zoff) * r.Hz + pix % r.Hout + r.zoff) * r.C + c];
+        }
+    }
+    __shared__ float sh[2][4][64];
+    sh[0][lane4][threadIdx.x & 63] = s0;
+    sh[1][lane4][threadIdx.x & 63] = s1;
+    __syncthreads();
+    if (lane4 == 0) {
+        const int l = threadIdx.x;
+        partial[((size_t)sp * 2 + 0) * r.C + c] = (sh[0][0][l] + sh[0][1][l]) + (sh[0][2][l] + sh[0][3][l]);
+        partial[((size_t)sp * 2 + 1) * r.C + c] = (sh[1][0][l] + sh[1][1][l]) + (sh[1][2][l] + sh[1][3][l]);
+    }
+}
+
+__device__ __forceinline__ float t_sum_s(const float* partial, int which, int C, int c) {
+    float a = 0.f;
+    for (int s = 0; s < RED_S; ++s) a += partial[((size_t)s * 2 + which) * C + c];
+    return a;
+}
+// mean[c] = sum / M
+__global__ void k_t_fin_mean(const float* __restrict__ partial, const int* __restrict__ d_count, int P, int C, float* __restrict__ mean) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) mean[c] = t_sum_s(partial, 0, C, c) / (float)((long long)(*d_count) * P);
+}
+// rstd[c] = 1/sqrt(var + eps); staged moving statistics: new = old * mom + batch * (1 - mom) (var unbiased when fused)
+__global__ void k_t_fin_var(const float* __restrict__ partial, const int* __restrict__ d_count, int P, int C, const float* __restrict__ mean,
+                            float* __restrict__ rstd, const float* __restrict__ mm, const float* __restrict__ mv,
+                            float* __restrict__ mm_new, float* __restrict__ mv_new, float mom, int fused) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long long M = (long long)(*d_count) * P;
+    const float var = t_sum_s(partial, 0, C, c) / (float)M;
+    rstd[c] = 1.0f / sqrtf(var + BN_EPS);
+    const float uv = fused ? var * ((float)M / (float)(M > 1 ? M - 1 : 1)) : var;
+    mm_new[c] = mm[c] * mom + mean[c] * (1.0f - mom);
+    mv_new[c] = mv[c] * mom + uv * (1.0f - mom);
+}
+// out[c] = sum over the rows (fixed order over the RED_S partials)
+__global__ void k_t_fin_colsum(const float* __restrict__ partial, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) out[c] = t_sum_s(partial, 0, C, c);
+}
+// a = relu((z - mean) * rstd * gamma + beta) [* keep / (1 - rate)]
+__global__ __launch_bounds__(256) void k_t_bn_fwd(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ a,
+                                                  const int* __restrict__ d_count, int P, int C, float rate, uint64_t seed, uint64_t step, int dlayer) {
+    const long long total = (long long)(*d_count) * P * C;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    float y = (z[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    y = y > 0.f ? y : 0.f;
+    if (rate > 0.f) y = oz_dropout_keep(seed, step, (uint64_t)dlayer, (uint64_t)i, rate) ? y / (1.0f - rate) : 0.f;
+    a[i] = y;
+}
+// dgamma = s1, dbeta = s0
+__global__ void k_t_fin_bnbwd(const float* __restrict__ partial, int C, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ sums /*[2][C]*/) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s0 = t_sum_s(partial, 0, C, c), s1 = t_sum_s(partial, 1, C, c);
+    dbeta[c] = s0; dgamma[c] = s1; sums[c] = s0; sums[C + c] = s1;
+}
+// dz = gamma * rstd * (dy - s0/M - xhat * s1/M), written at (b, oy+zoff, ox+zoff) of an Hz x Hz buffer
+__global__ __launch_bounds__(256) void k_t_bn_bwd(const float* __restrict__ dA, const float* __restrict__ a, const float* __restrict__ z,
+                                                  const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                  const float* __restrict__ sums, float post_scale, const int* __restrict__ d_count,
+                                                  int Hout, int C, int Hz, int zoff, float* __restrict__ dz) {
+    const int P = Hout * Hout;
+    const long long M = (long long)(*d_count) * P, total = M * C;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const long long m = i / C;
+    const float dy = a[i] > 0.f ? dA[i] * post_scale : 0.f;
+    const float xh = (z[i] - mean[c]) * rstd[c];
+    const float inv = 1.0f / (float)M;
+    const float g = gamma[c] * rstd[c] * (dy - sums[c] * inv - xh * sums[C + c] * inv);
+    const int b = (int)(m / P), pix = (int)(m % P);
+    dz[(((size_t)b * Hz + pix / Hout + zoff) * Hz + pix % Hout + zoff) * C + c] = g;
+}
+
+// ---------------------------------------------------------------- heads: forward, losses, gradient wrt f2
+// one 64-thread block per sample (A = n*n <= 64 policy outputs, lane = action)
+__global__ __launch_bounds__(64) void k_t_heads(const float* __restrict__ f2 /*[B][512]*/, const int* __restrict__ d_count, int n,
+                                                const float* __restrict__ Wpi /*[512][A]*/, const float* __restrict__ bpi,
+                                                const float* __restrict__ Wv /*[512]*/, const float* __restrict__ bv,
+                                                const float* __restrict__ pit /*[B][A]*/, const float* __restrict__ zt /*[B]*/,
+                                                float* __restrict__ p_out, float* __restrict__ v_out,
+                                                float* __restrict__ dlogit /*[B][A]*/, float* __restrict__ dvpre /*[B]*/,
+                                                float* __restrict__ loss /*[B][2]*/) {
+    const int b = blockIdx.x, lane = threadIdx.x, A = n * n, B = *d_count;
+    if (b >= B) return;
+    const float* x = f2 + (size_t)b * 512;
+    float logit = -INFINITY, vacc = 0.f;
+    if (lane < A) {
+        float acc = 0.f;
+        for (int k = 0; k < 512; ++k) acc = fmaf(x[k], Wpi[(size_t)k * A + lane], acc);
+        logit = acc + bpi[lane];
+    }
+    for (int k = lane; k < 512; k += 64) vacc = fmaf(x[k], Wv[k], vacc);
+    for (int o = 32; o; o >>= 1) vacc += __shfl_xor(vacc, o);
+    float mx = logit;
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float e = lane < A ? expf(logit - mx) : 0.f;
+    float se = e;
+    for (int o = 32; o; o >>= 1) se += __shfl_xor(se, o);
+    const float p = e / se;
+    const float v = tanhf(vacc + bv[0]);
+    // row-normalised, clipped cross entropy on the (n, n) view; the lanes of one board row are n consecutive lanes
+    // (every lane runs the shuffles; lanes >= A read a clamped source and their results are unused)
+    const int row = lane / n;
+    const float t = lane < A ? pit[(size_t)b * A + lane] : 0.f;
+    float S = 0.f;
+    for (int c = 0; c < n; ++c) { const int src = row * n + c; S += __shfl(p, src < 63 ? src : 63); }
+    const float q = lane < A ? p / S : 0.5f;
+    const bool inside = q >= 1e-7f && q <= 1.0f - 1e-7f;
+    const float qc = fminf(fmaxf(q, 1e-7f), 1.0f - 1e-7f);
+    float lpi = lane < A ? -t * logf(qc) : 0.f;
+    for (int o = 32; o; o >>= 1) lpi += __shfl_xor(lpi, o);
+    // dL/dq = -t/q inside the clip range (0 outside); q = p / S  =>  dL/dp_j = g_j / S - (sum_{c in row} g_c q_c) / S
+    const float gq = (lane < A && inside) ? -t / q : 0.f;
+    const float gqq = gq * q;
+    float rowdot = 0.f;
+    for (int c = 0; c < n; ++c) { const int src = row * n + c; rowdot += __shfl(gqq, src < 63 ? src : 63); }
+    const float normp = 1.0f / ((float)B * (float)n);
+    const float gp = lane < A ? (gq - rowdot) / S * normp : 0.f;
+    // softmax backward: dlogit_j = p_j (gp_j - sum_k gp_k p_k)
+    float dot = gp * p;
+    for (int o = 32; o; o >>= 1) dot += __shfl_xor(dot, o);
+    if (lane < A) {
+        dlogit[(size_t)b * A + lane] = p * (gp - dot);
+        p_out[(size_t)b * A + lane] = p;
+    }
+    if (lane == 0) {
+        const float d = v - zt[b];
+        v_out[b] = v;
+        dvpre[b] = 2.0f * d / (float)B * (1.0f - v * v);
+        loss[2 * b] = lpi / (float)n;          // per-sample mean over rows
+        loss[2 * b + 1] = d * d;
+    }
+}
+// dWpi[k][a] = sum_b f2[b][k] dlogit[b][a];  dWv[k] = sum_b f2[b][k] dvpre[b]   (block = k, thread = a; a == A handles v)
+__global__ __launch_bounds__(128) void k_t_heads_wgrad(const float* __restrict__ f2, const float* __restrict__ dlogit, const float* __restrict__ dvpre,
+                                                       const int* __restrict__ d_count, int A, float* __restrict__ dWpi, float* __restrict__ dWv) {
+    const int k = blockIdx.x, a = threadIdx.x, B = *d_count;
+    if (a > A) return;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc = fmaf(f2[(size_t)b * 512 + k], a < A ? dlogit[(size_t)b * A + a] : dvpre[b], acc);
+    if (a < A) dWpi[(size_t)k * A + a] = acc; else dWv[k] = acc;
+}
+// dbpi[a] = sum_b dlogit[b][a]; dbv = sum_b dvpre[b]; losses[0..2] = total, pi, v (batch means)
+__global__ __launch_bounds__(128) void k_t_heads_bias(const float* __restrict__ dlogit, const float* __restrict__ dvpre, const float* __restrict__ loss,
+                                                      const int* __restrict__ d_count, int A, float* __restrict__ dbpi, float* __restrict__ dbv,
+                                                      float* __restrict__ losses) {
+    const int a = threadIdx.x, B = *d_count;
+    if (a < A) { float s = 0.f; for (int b = 0; b < B; ++b) s += dlogit[(size_t)b * A + a]; dbpi[a] = s; }
+    if (a == A) { float s = 0.f; for (int b = 0; b < B; ++b) s += dvpre[b]; dbv[0] = s; }
+    if (a == A + 1) {
+        float lp = 0.f, lv = 0.f;
+        for (int b = 0; b < B; ++b) { lp += loss[2 * b]; lv += loss[2 * b + 1]; }
+        lp /= (float)B; lv /= (float)B;
+        losses[0] = lp + lv; losses[1] = lp; losses[2] = lv;
+    }
+}
+// df2[b][k] = sum_a dlogit[b][a] Wpi[k][a] + dvpre[b] Wv[k]
+__global__ __launch_bounds__(256) void k_t_heads_dgrad(const float* __restrict__ dlogit, const float* __restrict__ dvpre, const float* __restrict__ Wpi,
+                                                       const float* __restrict__ Wv, const int* __restrict__ d_count, int A, float* __restrict__ df2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)(*d_count) * 512) return;
+    const int b = (int)(i / 512), k = (int)(i % 512);
+    float acc = dvpre[b] * Wv[k];
+    for (int a = 0; a < A; ++a) acc = fmaf(dlogit[(size_t)b * A + a], Wpi[(size_t)k * A + a], acc);
+    df2[i] = acc;
+}
+
+// ---------------------------------------------------------------- weight gradient: TN implicit GEMM on fp32 MFMA
+// dW[t][ci][co] = sum_m Xs_t[m][ci] * dZ[m][co], m = (b, oy, ox).  Block tile 128 ci x 128 co for one tap, 4 waves of
+// 64x64 (2x2 v_mfma_f32_32x32x2_f32); the k index is the row m: both operand tiles are staged [32 rows][128 channels]
+// straight from their row-major tensors (coalesced, no transpose) and the MFMA operands are read k-major from LDS
+// (lane (i, kk) reads element [k0 + kk][i]: 32 consecutive floats per half wave, row stride padded by 32 banks).
+#define WG_STRIDE 160
+struct WgradGeom { int Hin, Hout, pad, Cin, Cout, taps, Hz, zoff; };
+__global__ __launch_bounds__(256) void k_wgrad_f32(const float* __restrict__ X, const float* __restrict__ dZ, const int* __restrict__ d_count,
+                                                   WgradGeom g, float* __restrict__ dW) {
+    __shared__ __attribute__((aligned(16))) float lds[2][32 * WG_STRIDE];
+    const int nci = g.Cin / 128, nco = g.Cout / 128;
+    const int tap = blockIdx.x / (nci * nco), rem = blockIdx.x % (nci * nco), ci0 = (rem / nco) * 128, co0 = (rem % nco) * 128;
+    const int P = g.Hout * g.Hout;
+    const long long M = (long long)(*d_count) * P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int srow = tid >> 5, c4 = (tid & 31) * 4;              // staging: rows srow + 8 i, 4 consecutive channels
+    const int dy = g.taps == 9 ? tap / 3 : 0, dx = g.taps == 9 ? tap % 3 : 0;
+
+    f32x4 ra[4], rb[4];
+    auto gload = [&](long long m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long m = m0 + srow + 8 * i;
+            f32x4 za = {0.f, 0.f, 0.f, 0.f}, zb = za;
+            if (m < M) {
+                const int b = (int)(m / P), pix = (int)(m % P), oy = pix / g.Hout, ox = pix % g.Hout;
+                const int iy = oy - g.pad + dy, ix = ox - g.pad + dx;
+                if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Hin)
+                    za = *reinterpret_cast<const f32x4*>(X + (((size_t)b * g.Hin + iy) * g.Hin + ix) * g.Cin + ci0 + c4);
+                zb = *reinterpret_cast<const f32x4*>(dZ + (((size_t)b * g.Hz + oy + g.zoff) * g.Hz + ox + g.zoff) * g.Cout + co0 + c4);
+            }
+            ra[i] = za; rb[i] = zb;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&lds[0][(srow + 8 * i) * WG_STRIDE + c4]) = ra[i];
+            *reinterpret_cast<f32x4*>(&lds[1][(srow + 8 * i) * WG_STRIDE + c4]) = rb[i];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int r32 = lane & 31, kk = lane >> 5;
+    const long long nk = (M + 31) / 32;
+    if (nk > 0) { gload(0); lstore(); }
+    __syncthreads();
+    for (long long kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload((kt + 1) * 32);
+        const float* At = &lds[0][kk * WG_STRIDE + wm * 64 + r32];
+        const float* Bt = &lds[1][kk * WG_STRIDE + wn * 64 + r32];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float a0 = At[2 * s * WG_STRIDE], a1 = At[2 * s * WG_STRIDE + 32];
+            const float b0 = Bt[2 * s * WG_STRIDE], b1 = Bt[2 * s * WG_STRIDE + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) lstore();
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31 (co), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (ci)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const int co = co0 + wn * 64 + j * 32 + r32;
+                dW[((size_t)tap * g.Cin + ci) * g.Cout + co] = acc[i][j][r];
+            }
+}
+
+// ---------------------------------------------------------------- operand layouts derived from the Keras-layout masters
+// out[c][r] = in[r][c]   (forward operand Wt[N][K] of k_gemm_f32 from the Keras kernel [K][N])
+__global__ __launch_bounds__(256) void k_t_transpose(const float* __restrict__ in, int R, int Cc, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) if (by + i < R && bx + tx < Cc) tile[i][tx] = in[(size_t)(by + i) * Cc + bx + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) if (bx + i < Cc && by + tx < R) out[(size_t)(bx + i) * R + by + tx] = tile[tx][i];
+}
+// data-gradient operand of a 3x3 convolution: Wd[ci][(8 - t) * Cout + co] = W[t][ci][co]
+__global__ __launch_bounds__(256) void k_t_dgrad_operand(const float* __restrict__ W, int Cin, int Cout, float* __restrict__ Wd) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9LL * Cin * Cout) return;
+    const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), t = (int)(i / ((long long)Cout * Cin));
+    Wd[(size_t)ci * 9 * Cout + (size_t)(8 - t) * Cout + co] = W[i];
+}
+
+// ---------------------------------------------------------------- Adam (tf.keras formulation) with clipvalue
+__global__ __launch_bounds__(256) void k_t_adam(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M1, float* __restrict__ V2,
+                                                long long count, float lr_t, float clip) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float g = G[i];
+    if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+    const float m = 0.9f * M1[i] + 0.1f * g;
+    const float v = 0.999f * V2[i] + 0.001f * g * g;
+    M1[i] = m; V2[i] = v;
+    P[i] -= lr_t * m / (sqrtf(v) + 1e-7f);
+}
+
+// ---------------------------------------------------------------- host object
+struct oz_trainer {
+    int n = 8, C = 512, cin = 2, Bmax = 32, device = 0;
+    float lr = 1e-3f, clip = 0.5f, rate = 0.3f, mom = 0.99f;
+    uint64_t seed = 0;
+    int64_t step = 0;
+    hipStream_t s = nullptr;
+    int64_t size[40], toff[40];          // element counts; offset in the trainable arena (-1: moving statistic)
+    int64_t total = 0;
+    float *P = nullptr, *G = nullptr, *M1 = nullptr, *V2 = nullptr;
+    bool own_grads = true;
+    float *stats[40] = {}, *stats_new[40] = {};
+    float *Wt[6] = {}, *Wd[6] = {};
+    uint64_t *d_own = nullptr, *d_opp = nullptr;
+    float *d_pit = nullptr, *d_zt = nullptr;
+    int* d_count = nullptr;
+    float *z[6] = {}, *a[6] = {}, *mean[6] = {}, *rstd[6] = {}, *dz[6] = {};
+    float *dA[2] = {}, *sums = nullptr, *partial = nullptr, *ones = nullptr, *zeros = nullptr;
+    float *p = nullptr, *v = nullptr, *dlogit = nullptr, *dvpre = nullptr, *loss = nullptr, *losses = nullptr;
+    int P_[6], Co[6], Hout[6], Hz[6], zoff[6];
+    std::vector<void*> allocs;
+    bool dirty = true;                   // derived operands need a refresh
+
+    ~oz_trainer() {
+        hipSetDevice(device);
+        for (void* q : allocs) hipFree(q);
+        if (s) hipStreamDestroy(s);
+    }
+    float* param(int idx) { return toff[idx] >= 0 ? P + toff[idx] : stats[idx]; }
+    float* grad(int idx) { return G + toff[idx]; }
+};
+
+// element counts of the 40 get_weights() arrays and their offsets in the trainable arena (-1: moving statistic);
+// every array starts 16-byte aligned.  Returns the arena size in floats.
+static int64_t t_layout(int n, int C, int cin, int64_t* size, int64_t* toff) {
+    const int64_t A = n * n, F = (int64_t)(n - 4) * (n - 4) * C;
+    const int cins[4] = {cin, C, C, C};
+    int idx = 0;
+    for (int l = 0; l < 4; ++l) { size[idx++] = 9LL * cins[l] * C; for (int j = 0; j < 5; ++j) size[idx++] = C; }
+    size[idx++] = F * 1024; for (int j = 0; j < 5; ++j) size[idx++] = 1024;
+    size[idx++] = 1024LL * 512; for (int j = 0; j < 5; ++j) size[idx++] = 512;
+    size[36] = 512 * A; size[37] = A; size[38] = 512; size[39] = 1;
+    int64_t total = 0;
+    for (int i = 0; i < 40; ++i) {
+        const bool stat = i < 36 && (i % 6 == 4 || i % 6 == 5);
+        toff[i] = stat ? -1 : total;
+        if (!stat) total += (size[i] + 3) / 4 * 4;
+    }
+    return total;
+}
+
+static int t_alloc(oz_trainer* t, void** out, size_t bytes, bool zero = true) {
+    OZ_HIP(hipMalloc(out, bytes ? bytes : 16));
+    t->allocs.push_back(*out);
+    if (zero) OZ_HIP(hipMemsetAsync(*out, 0, bytes ? bytes : 16, t->s));
+    return OZ_OK;
+}
+#define T_ALLOC(ptr, count) do { if (int rc__ = t_alloc(t, (void**)&(ptr), (size_t)(count) * sizeof(*(ptr)))) return rc__; } while (0)
+
+OZ_API int oz_trainer_create(oz_trainer** out, int n, int channels, int in_channels, int max_batch, float lr, float clipvalue,
+                             float dropout, float bn_momentum, uint64_t seed, float* external_grads) {
+    OZ_REQUIRE(out, "oz_trainer_create: out is NULL");
+    OZ_REQUIRE(n == 6 || n == 8, "oz_trainer_create: board size %d (6 or 8: conv3/conv4 are 'valid')", n);
+    OZ_REQUIRE(channels >= 128 && channels % 128 == 0, "oz_trainer_create: channels %d must be a multiple of 128", channels);
+    OZ_REQUIRE(in_channels == 1 || in_channels == 2, "oz_trainer_create: in_channels %d", in_channels);
+    OZ_REQUIRE(max_batch >= 1 && max_batch <= 65536, "oz_trainer_create: max_batch %d", max_batch);
+    OZ_REQUIRE(dropout >= 0.f && dropout < 1.f, "oz_trainer_create: dropout %f", dropout);
+    oz_trainer* t = new oz_trainer();
+    t->n = n; t->C = channels; t->cin = in_channels; t->Bmax = max_batch; t->lr = lr; t->clip = clipvalue; t->rate = dropout;
+    t->mom = bn_momentum; t->seed = seed; t->device = oz_current_device();
+    auto fail = [&](int rc) { delete t; return rc; };
+    if (hipSetDevice(t->device) != hipSuccess || hipStreamCreate(&t->s) != hipSuccess) { oz_set_error("oz_trainer_create: no GPU stream"); return fail(OZ_ERR_HIP); }
+    const int C = channels, A = n * n, F = (n - 4) * (n - 4) * C;
+    t->total = t_layout(n, C, in_channels, t->size, t->toff);
+    int rc = [&]() -> int {
+        T_ALLOC(t->P, t->total); T_ALLOC(t->M1, t->total); T_ALLOC(t->V2, t->total);
+        if (external_grads) { t->G = external_grads; t->own_grads = false; } else T_ALLOC(t->G, t->total);
+        for (int i = 0; i < 36; ++i) if (t->toff[i] < 0) { T_ALLOC(t->stats[i], t->size[i]); T_ALLOC(t->stats_new[i], t->size[i]); }
+        const int Hs[6] = {n, n, n - 2, n - 4, 1, 1};
+        for (int l = 0; l < 6; ++l) {
+            t->Hout[l] = Hs[l]; t->P_[l] = Hs[l] * Hs[l]; t->Co[l] = l < 4 ? C : (l == 4 ? 1024 : 512);
+            // conv3 / conv4 ('valid'): dz lives in a zero-bordered (Hout + 4)^2 buffer so that the data gradient is a plain valid conv
+            t->zoff[l] = (l == 2 || l == 3) ? 2 : 0; t->Hz[l] = Hs[l] + 2 * t->zoff[l];
+            const size_t rows = (size_t)max_batch * t->P_[l];
+            T_ALLOC(t->z[l], rows * t->Co[l]); T_ALLOC(t->a[l], rows * t->Co[l]);
+            T_ALLOC(t->dz[l], (size_t)max_batch * t->Hz[l] * t->Hz[l] * t->Co[l]);
+            T_ALLOC(t->mean[l], t->Co[l]); T_ALLOC(t->rstd[l], t->Co[l]);
+        }
+        const size_t amax = (size_t)max_batch * (size_t)A * C > (size_t)max_batch * 1024 ? (size_t)max_batch * A * C : (size_t)max_batch * 1024;
+        T_ALLOC(t->dA[0], amax); T_ALLOC(t->dA[1], amax);
+        T_ALLOC(t->sums, 2 * 8192);
+        size_t pmax = (size_t)RED_S * 2 * 1024;
+        if ((size_t)RED_S * 2 * C > pmax) pmax = (size_t)RED_S * 2 * C;
+        if ((size_t)RED_S * 9 * in_channels * C > pmax) pmax = (size_t)RED_S * 9 * in_channels * C;
+        T_ALLOC(t->partial, pmax);
+        const int vmax = F > 8192 ? F : 8192;
+        T_ALLOC(t->ones, vmax); T_ALLOC(t->zeros, vmax);
+        std::vector<float> one(vmax, 1.0f);
+        OZ_HIP(hipMemcpyAsync(t->ones, one.data(), vmax * sizeof(float), hipMemcpyHostToDevice, t->s));
+        OZ_HIP(hipStreamSynchronize(t->s));
+        for (int l = 1; l < 6; ++l) T_ALLOC(t->Wt[l], t->size[6 * l]);
+        for (int l = 1; l < 4; ++l) T_ALLOC(t->Wd[l], t->size[6 * l]);
+        T_ALLOC(t->d_own, max_batch); T_ALLOC(t->d_opp, max_batch); T_ALLOC(t->d_pit, (size_t)max_batch * A); T_ALLOC(t->d_zt, max_batch);
+        T_ALLOC(t->d_count, 1);
+        T_ALLOC(t->p, (size_t)max_batch * A); T_ALLOC(t->v, max_batch); T_ALLOC(t->dlogit, (size_t)max_batch * A); T_ALLOC(t->dvpre, max_batch);
+        T_ALLOC(t->loss, 2 * (size_t)max_batch); T_ALLOC(t->losses, 4);
+        OZ_HIP(hipStreamSynchronize(t->s));
+        return OZ_OK;
+    }();
+    if (rc) return fail(rc);
+    *out = t;
+    return OZ_OK;
+}
+
+OZ_API int oz_trainer_destroy(oz_trainer* t) { delete t; return OZ_OK; }
+
+OZ_API int oz_trainer_set_weight(oz_trainer* t, int index, const float* data, int64_t nelem) {
+    OZ_REQUIRE(t && data && index >= 0 && index < 40, "oz_trainer_set_weight: bad argument");
+    OZ_REQUIRE(nelem == t->size[index], "oz_trainer_set_weight: weight %d has %lld elements, got %lld", index, (long long)t->size[index], (long long)nelem);
+    OZ_HIP(hipSetDevice(t->device));
+    OZ_HIP(hipMemcpyAsync(t->param(index), data, nelem * sizeof(float), hipMemcpyHostToDevice, t->s));
+    OZ_HIP(hipStreamSynchronize(t->s));
+    t->dirty = true;
+    return OZ_OK;
+}
+OZ_API int oz_trainer_get_weight(oz_trainer* t, int index, float* data, int64_t nelem) {
+    OZ_REQUIRE(t && data && index >= 0 && index < 40 && nelem == t->size[index], "oz_trainer_get_weight: bad argument");
+    OZ_HIP(hipSetDevice(t->device));
+    OZ_HIP(hipMemcpyAsync(data, t->param(index), nelem * sizeof(float), hipMemcpyDeviceToHost, t->s));
+    OZ_HIP(hipStreamSynchronize(t->s));
+    return OZ_OK;
+}
+OZ_API int oz_trainer_get_grad(oz_trainer* t, int index, float* data, int64_t nelem) {
+    OZ_REQUIRE(t && data && index >= 0 && index < 40 && nelem == t->size[index] && t->toff[index] >= 0, "oz_trainer_get_grad: bad argument");
+    OZ_HIP(hipSetDevice(t->device));
+    OZ_HIP(hipMemcpyAsync(data, t->grad(index), nelem * sizeof(float), hipMemcpyDeviceToHost, t->s));
+    OZ_HIP(hipStreamSynchronize(t->s));
+    return OZ_OK;
+}
+OZ_API int oz_trainer_grad_arena(oz_trainer* t, void** device_ptr, int64_t* nelem) {
+    OZ_REQUIRE(t && device_ptr && nelem, "oz_trainer_grad_arena: bad argument");
+    *device_ptr = t->G; *nelem = t->total;
+    return OZ_OK;
+}
+OZ_API int oz_trainer_arena_size(int n, int channels, int in_channels, int64_t* nelem) {
+    OZ_REQUIRE(nelem, "oz_trainer_arena_size: bad argument");
+    int64_t size[40], toff[40];
+    const int64_t tot = t_layout(n, channels, in_channels, size, toff);
+    *nelem = tot;
+    return OZ_OK;
+}
+OZ_API int oz_trainer_sync(oz_trainer* t) {
+    OZ_REQUIRE(t, "oz_trainer_sync: NULL");
+    OZ_HIP(hipSetDevice(t->device));
+    OZ_HIP(hipStreamSynchronize(t->s));
+    return OZ_OK;
+}
+OZ_API int oz_trainer_step_count(oz_trainer* t, int64_t* step) {
+    OZ_REQUIRE(t && step, "oz_trainer_step_count: bad argument");
+    *step = t->step;
+    return OZ_OK;
+}
+
+static int t_refresh(oz_trainer* t) {
+    const int C = t->C, F = (t->n - 4) * (t->n - 4) * C;
+    const int Ks[6] = {0, 9 * C, 9 * C, 9 * C, F, 1024}, Ns[6] = {0, C, C, C, 1024, 512};
+    for (int l = 1; l < 6; ++l) {
+        hipLaunchKernelGGL(k_t_transpose, dim3((Ns[l] + 31) / 32, (Ks[l] + 31) / 32), dim3(256), 0, t->s, t->param(6 * l), Ks[l], Ns[l], t->Wt[l]);
+        OZ_HIP(hipGetLastError());
+    }
+    for (int l = 1; l < 4; ++l) {
+        const long long cnt = 9LL * C * C;
+        hipLaunchKernelGGL(k_t_dgrad_operand, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, t->s, t->param(6 * l), C, C, t->Wd[l]);
+        OZ_HIP(hipGetLastError());
+    }
+    t->dirty = false;
+    return OZ_OK;
+}
+
+template <int MODE>
+static int t_reduce(oz_trainer* t, RedArgs r) {
+    hipLaunchKernelGGL(k_t_colreduce<MODE>, dim3(r.C / 64, RED_S), dim3(256), 0, t->s, r, t->d_count, t->partial);
+    OZ_HIP(hipGetLastError());
+    return OZ_OK;
+}
+
+// BN (training mode) + ReLU (+ dropout) of layer l: z[l] -> a[l]
+static int t_bn_forward(oz_trainer* t, int l, int B) {
+    const int Cc = t->Co[l], P = t->P_[l];
+    RedArgs r = {}; r.x = t->z[l]; r.P = P; r.C = Cc;
+    if (int rc = t_reduce<0>(t, r)) return rc;
+    hipLaunchKernelGGL(k_t_fin_mean, dim3((Cc + 255) / 256), dim3(256), 0, t->s, t->partial, t->d_count, P, Cc, t->mean[l]);
+    r.mean = t->mean[l];
+    if (int rc = t_reduce<1>(t, r)) return rc;
+    hipLaunchKernelGGL(k_t_fin_var, dim3((Cc + 255) / 256), dim3(256), 0, t->s, t->partial, t->d_count, P, Cc, t->mean[l], t->rstd[l],
+                       t->stats[6 * l + 4], t->stats[6 * l + 5], t->stats_new[6 * l + 4], t->stats_new[6 * l + 5], t->mom, l < 4 ? 1 : 0);
+    const long long total = (long long)B * P * Cc;
+    hipLaunchKernelGGL(k_t_bn_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, t->s, t->z[l], t->mean[l], t->rstd[l], t->param(6 * l + 2),
+                       t->param(6 * l + 3), t->a[l], t->d_count, P, Cc, l >= 4 ? t->rate : 0.f, t->seed, (uint64_t)t->step, l - 4);
+    OZ_HIP(hipGetLastError());
+    return OZ_OK;
+}
+
+OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const uint64_t* opp, const float* pi_target, const float* z_target,
+                                       int B, float* losses3) {
+    OZ_REQUIRE(t && own && opp && pi_target && z_target, "oz_trainer_forward_backward: NULL argument");
+    OZ_REQUIRE(B >= 1 && B <= t->Bmax, "oz_trainer_forward_backward: batch %d outside [1, %d]", B, t->Bmax);
+    OZ_HIP(hipSetDevice(t->device));
+    hipStream_t s = t->s;
+    const int n = t->n, C = t->C, A = n * n, F = (n - 4) * (n - 4) * C;
+    OZ_HIP(hipMemcpyAsync(t->d_own, own, B * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    OZ_HIP(hipMemcpyAsync(t->d_opp, opp, B * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    OZ_HIP(hipMemcpyAsync(t->d_pit, pi_target, (size_t)B * A * sizeof(float), hipMemcpyHostToDevice, s));
+    OZ_HIP(hipMemcpyAsync(t->d_zt, z_target, B * sizeof(float), hipMemcpyHostToDevice, s));
+    OZ_HIP(hipMemcpyAsync(t->d_count, &B, sizeof(int), hipMemcpyHostToDevice, s));
+    if (t->dirty) if (int rc = t_refresh(t)) return rc;
+
+    // ---- forward
+    { const long long tot = (long long)B * A * C;
+      hipLaunchKernelGGL(k_t_conv1_fwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, t->d_own, t->d_opp, t->d_count, n, C, t->cin,
+                         t->param(0), t->param(1), t->z[0]);
+      OZ_HIP(hipGetLastError()); }
+    if (int rc = t_bn_forward(t, 0, B)) return rc;
+    const int Hin[6] = {n, n, n, n - 2, 1, 1}, pad[6] = {1, 1, 0, 0, 0, 0}, Cin[6] = {t->cin, C, C, C, F, 1024}, taps[6] = {9, 9, 9, 9, 1, 1};
+    for (int l = 1; l < 6; ++l) {
+        if (int rc = oz_gemm_f32_launch(t->a[l - 1], t->Wt[l], t->ones, t->param(6 * l + 1), t->z[l], t->d_count, B, Hin[l], t->Hout[l], pad[l],
+                                        Cin[l], taps[l], t->Co[l], 0, s)) return rc;
+        if (int rc = t_bn_forward(t, l, B)) return rc;
+    }
+    hipLaunchKernelGGL(k_t_heads, dim3(B), dim3(64), 0, s, t->a[5], t->d_count, n, t->param(36), t->param(37), t->param(38), t->param(39),
+                       t->d_pit, t->d_zt, t->p, t->v, t->dlogit, t->dvpre, t->loss);
+    OZ_HIP(hipGetLastError());
+
+    // ---- backward
+    hipLaunchKernelGGL(k_t_heads_wgrad, dim3(512), dim3(128), 0, s, t->a[5], t->dlogit, t->dvpre, t->d_count, A, t->grad(36), t->grad(38));
+    hipLaunchKernelGGL(k_t_heads_bias, dim3(1), dim3(128), 0, s, t->dlogit, t->dvpre, t->loss, t->d_count, A, t->grad(37), t->grad(39), t->losses);
+    hipLaunchKernelGGL(k_t_heads_dgrad, dim3((unsigned)(((long long)B * 512 + 255) / 256)), dim3(256), 0, s, t->dlogit, t->dvpre, t->param(36),
+                       t->param(38), t->d_count, A, t->dA[1]);
+    OZ_HIP(hipGetLastError());
+    int cur = 1;                                   // dA[cur] = gradient wrt a[l]
+    for (int l = 5; l >= 0; --l) {
+        const int Cc = t->Co[l], P = t->P_[l];
+        const float post = l >= 4 && t->rate > 0.f ? 1.0f / (1.0f - t->rate) : 1.0f;
+        RedArgs r = {}; r.x = t->dA[cur]; r.a = t->a[l]; r.z = t->z[l]; r.mean = t->mean[l]; r.rstd = t->rstd[l]; r.post_scale = post; r.P = P; r.C = Cc;
+        if (int rc = t_reduce<2>(t, r)) return rc;
+        hipLaunchKernelGGL(k_t_fin_bnbwd, dim3((Cc + 255) / 256), dim3(256), 0, s, t->partial, Cc, t->grad(6 * l + 2), t->grad(6 * l + 3), t->sums);
+        const long long total = (long long)B * P * Cc;
+        hipLaunchKernelGGL(k_t_bn_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t->dA[cur], t->a[l], t->z[l], t->mean[l], t->rstd[l],
+                           t->param(6 * l + 2), t->sums, post, t->d_count, t->Hout[l], Cc, t->Hz[l], t->zoff[l], t->dz[l]);
+        OZ_HIP(hipGetLastError());
+        // bias gradient = column sums of dz (mathematically 0 behind a training-mode BN; computed like autograd would)
+        RedArgs rb = {}; rb.x = t->dz[l]; rb.P = P; rb.C = Cc; rb.Hout = t->Hout[l]; rb.Hz = t->Hz[l]; rb.zoff = t->zoff[l];
+        if (int rc = t_reduce<3>(t, rb)) return rc;
+        hipLaunchKernelGGL(k_t_fin_colsum, dim3((Cc + 255) / 256), dim3(256), 0, s, t->partial, Cc, t->grad(6 * l + 1));
+        OZ_HIP(hipGetLastError());
+        // weight gradient
+        if (l == 0) {
+            hipLaunchKernelGGL(k_t_conv1_wgrad, dim3(9 * t->cin, (C + 255) / 256, RED_S), dim3(256), 0, s, t->d_own, t->d_opp, t->d_count, n, C, t->cin,
+                               t->dz[0], t->partial);
+            const long long cnt = 9LL * t->cin * C;
+            hipLaunchKernelGGL(k_t_sum_partials, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, t->partial, RED_S, cnt, t->grad(0));
+            OZ_HIP(hipGetLastError());
+        } else {
+            WgradGeom g; g.Hin = Hin[l]; g.Hout = t->Hout[l]; g.pad = pad[l]; g.Cin = Cin[l]; g.Cout = Cc; g.taps = taps[l]; g.Hz = t->Hz[l]; g.zoff = t->zoff[l];
+            hipLaunchKernelGGL(k_wgrad_f32, dim3(taps[l] * (Cin[l] / 128) * (Cc / 128)), dim3(256), 0, s, t->a[l - 1], t->dz[l], t->d_count, g, t->grad(6 * l));
+            OZ_HIP(hipGetLastError());
+            // data gradient -> dA[cur ^ 1] = gradient wrt a[l - 1]
+            if (l >= 4) {          // dense: dX = dZ . W^T; the Keras kernel [in][out] already is the [N = in][K = out] operand
+                if (int rc = oz_gemm_f32_launch(t->dz[l], t->param(6 * l), t->ones, t->zeros, t->dA[cur ^ 1], t->d_count, B, 1, 1, 0, Cc, 1, Cin[l], 0, s)) return rc;
+            } else {               // 3x3 conv: conv of dz (zero-bordered for 'valid' layers) with the reversed, channel-swapped taps
+                const int same = pad[l];
+                if (int rc = oz_gemm_f32_launch(t->dz[l], t->Wd[l], t->ones, t->zeros, t->dA[cur ^ 1], t->d_count, B, t->Hz[l], Hin[l], same ? 1 : 0, Cc, 9,
+                                                Cin[l], 0, s)) return rc;
+            }
+            cur ^= 1;
+        }
+    }
+    float h[4];
+    OZ_HIP(hipMemcpyAsync(h, t->losses, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    OZ_HIP(hipStreamSynchronize(s));
+    if (losses3) { losses3[0] = h[0]; losses3[1] = h[1]; losses3[2] = h[2]; }
+    return OZ_OK;
+}
+
+OZ_API int oz_trainer_apply(oz_trainer* t) {
+    OZ_REQUIRE(t, "oz_trainer_apply: NULL");
+    OZ_HIP(hipSetDevice(t->device));
+    t->step += 1;
+    const double b1t = pow(0.9, (double)t->step), b2t = pow(0.999, (double)t->step);
+    const float lr_t = (float)((double)t->lr * sqrt(1.0 - b2t) / (1.0 - b1t));
+    hipLaunchKernelGGL(k_t_adam, dim3((unsigned)((t->total + 255) / 256)), dim3(256), 0, t->s, t->P, t->G, t->M1, t->V2, (long long)t->total, lr_t, t->clip);
+    OZ_HIP(hipGetLastError());
+    for (int i = 0; i < 36; ++i)
+        if (t->toff[i] < 0) OZ_HIP(hipMemcpyAsync(t->stats[i], t->stats_new[i], t->size[i] * sizeof(float), hipMemcpyDeviceToDevice, t->s));
+    t->dirty = true;
+    return OZ_OK;
+}
+
+OZ_API int oz_trainer_outputs(oz_trainer* t, int B, float* p, float* v) {
+    OZ_REQUIRE(t && B >= 1 && B <= t->Bmax, "oz_trainer_outputs: bad argument");
+    OZ_HIP(hipSetDevice(t->device));
+    if (p) OZ_HIP(hipMemcpyAsync(p, t->p, (size_t)B * t->n * t->n * sizeof(float), hipMemcpyDeviceToHost, t->s));
+    if (v) OZ_HIP(hipMemcpyAsync(v, t->v, B * sizeof(float), hipMemcpyDeviceToHost, t->s));
+    OZ_HIP(hipStreamSynchronize(t->s));
+    return OZ_OK;
+}

@@ -79,3 +79,61 @@ def pooled_selfplay_records(engine, device, group=None):
     """records of every rank's completed games, identical on all ranks, sorted by (game_id, ply)"""
     allrec = tensor_to_records(gather_records(engine_records_tensor(engine, device), group))
     return allrec[np.lexsort((allrec["ply"], allrec["game_id"]))]
+
+
+# ---------------------------------------------------------------- data-parallel training (SURVEY.md 8(f) item 2)
+class GradientAllReduce:
+    """Averages a Trainer's gradient arena across ranks between backward and apply: ONE all-reduce per optimiser step
+    over the whole flat arena (16 M floats = 64 MB at 8x8 / 512 channels -- a single bucket keeps the xGMI ring at its
+    per-link bandwidth instead of paying per-tensor latency 28 times).  The arena is a torch tensor OWNED HERE and handed
+    to the library as `external_grads`, so RCCL reduces the memory the backward kernels wrote, with no copy.
+
+        ar = GradientAllReduce(board_size, channels, in_channels, device)     # before the Trainer
+        tr = Trainer(..., external_grads_ptr=ar.ptr)
+        fit(tr, ..., allreduce=ar)
+
+    With the gloo backend (CPU rehearsal of the control flow) the arena is staged through host memory."""
+
+    def __init__(self, board_size, channels, in_channels=2, device="cuda", group=None):
+        from .trainer import Trainer
+        self.group = group
+        self.flat = torch.zeros(Trainer.arena_size(board_size, channels, in_channels), dtype=torch.float32, device=device)
+        self.ptr = self.flat.data_ptr()
+
+    def __call__(self, trainer):
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(self.group)
+        if world == 1:
+            return
+        trainer.sync()                                   # the library's stream wrote the arena
+        if dist.get_backend(self.group) == "gloo" and self.flat.is_cuda:
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.copy_(host / world)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(world)
+        if self.flat.is_cuda:
+            torch.cuda.synchronize(self.flat.device)     # torch's stream -> before the library's Adam kernel reads it
+
+
+def average_moving_statistics(weights, group=None):
+    """BN moving statistics are per-replica under data parallelism (each rank normalises with its own batch); average
+    them at the end of a fit so that every rank holds the same inference network.  `weights` = the 40 get_weights()
+    arrays; returns the list with indices 6l+4, 6l+5 averaged."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return weights
+    world = dist.get_world_size(group)
+    idx = [i for i in range(36) if i % 6 in (4, 5)]
+    flat = torch.from_numpy(np.concatenate([np.asarray(weights[i], dtype=np.float32).ravel() for i in idx]))
+    if dist.get_backend(group) != "gloo":
+        flat = flat.cuda()
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat = (flat / world).cpu().numpy()
+    out, pos = list(weights), 0
+    for i in idx:
+        n = np.asarray(weights[i]).size
+        out[i] = flat[pos:pos + n].reshape(np.asarray(weights[i]).shape).copy()
+        pos += n
+    return out

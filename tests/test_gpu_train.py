@@ -1,0 +1,244 @@
+"""Training step parity (reference Net/NNet.py:53-68): the HIP forward / backward / Adam kernels,
+called through the C ABI, against oracle/train_ref.py (float64 torch autograd restatement of the Keras arithmetic).
+
+Tolerances (floating point, fp32 kernels vs float64 oracle): outputs and losses 2e-5 absolute; gradients
+max|d| <= 3e-4 * max|g_ref| + 1e-7 per tensor; the Adam update and the BN moving statistics 2e-6 absolute per step when both
+sides are fed the same gradients (step-locked test).  The biases that sit behind a training-mode BatchNormalization have a
+true gradient of exactly 0: what either side computes is rounding noise (asserted <= 1e-5), and Adam turns noise of any
+scale into steps of up to lr -- which is why free-running comparisons only bound those (they cannot influence any output).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BN_BIASES = [6 * l + 1 for l in range(6)]
+
+
+def _batch(n, B, seed, cin=2):
+    rs = np.random.RandomState(seed)
+    valid = np.uint64(sum(1 << (r * 8 + c) for r in range(n) for c in range(n)))
+    own = rs.randint(0, 2**63, size=B, dtype=np.uint64) & valid
+    opp = rs.randint(0, 2**63, size=B, dtype=np.uint64) & valid & ~own
+    pi = np.zeros((B, n * n), np.float32)
+    pi[np.arange(B), rs.randint(0, n * n, B)] = 1                      # the reference's one-hot targets
+    pi[0] = rs.dirichlet(np.ones(n * n)).astype(np.float32)            # and one dense target (visit-count style)
+    z = rs.choice([-1.0, 1.0], B).astype(np.float32)
+    return own, opp, pi, z
+
+
+def _pair(n, C, cin, B, seed, dropout=0.3, clip=0.5):
+    from oracle.train_ref import TrainRef
+    from othellozero_amd.trainer import Trainer
+    from othellozero_amd.weights import init_weights
+    w = init_weights(n, seed=seed, channels=C, randomize_all=True, in_channels=cin)
+    ref = TrainRef(w, n, lr=1e-3, clipvalue=clip, dropout=dropout, seed=77)
+    gpu = Trainer(n, C, cin, max_batch=B, lr=1e-3, clipvalue=clip, dropout=dropout, seed=77)
+    gpu.set_weights(w)
+    return ref, gpu
+
+
+def _check_grads(ref, gpu, scale=3e-4):
+    g = gpu.get_grads()
+    worst = 0.0
+    for i, gr in ref.grads.items():
+        gr = gr.numpy()
+        tol = scale * np.abs(gr).max() + 1e-7
+        if i in BN_BIASES:
+            assert np.abs(g[i]).max() <= 1e-5, f"bias {i} behind BN: gradient should be rounding noise, got {np.abs(g[i]).max()}"
+            continue
+        err = np.abs(g[i].astype(np.float64) - gr).max()
+        worst = max(worst, err / tol)
+        assert err <= tol, f"gradient {i} (shape {gr.shape}): max err {err:.3e} > {tol:.3e} (max |g| {np.abs(gr).max():.3e})"
+    return worst
+
+
+@pytest.mark.parametrize("n,C,cin,B", [(6, 128, 2, 8), (8, 128, 2, 5), (6, 128, 1, 7), (8, 256, 2, 32)])
+def test_forward_backward_matches_autograd(n, C, cin, B):
+    ref, gpu = _pair(n, C, cin, B, seed=3)
+    own, opp, pi, z = _batch(n, B, seed=11, cin=cin)
+    lr_ = ref.forward_backward(own, opp, pi, z)
+    lg = gpu.forward_backward(own, opp, pi, z)
+    assert np.allclose(lg, lr_, atol=2e-5, rtol=2e-5), (lg, lr_)
+    p, v = gpu.outputs(B)
+    assert np.abs(p - ref.outputs["p"]).max() <= 2e-5 and np.abs(v - ref.outputs["v"]).max() <= 2e-5
+    _check_grads(ref, gpu)
+
+
+def test_no_dropout_no_clip_and_determinism():
+    ref, gpu = _pair(6, 128, 2, 16, seed=4, dropout=0.0, clip=0.0)
+    own, opp, pi, z = _batch(6, 16, seed=12)
+    ref.forward_backward(own, opp, pi, z)
+    l1 = gpu.forward_backward(own, opp, pi, z)
+    g1 = gpu.get_grads()
+    _check_grads(ref, gpu)
+    l2 = gpu.forward_backward(own, opp, pi, z)
+    g2 = gpu.get_grads()
+    assert l1 == l2 and all(np.array_equal(g1[i], g2[i]) for i in g1)          # fixed-order reductions: bit-reproducible
+
+
+def test_adam_steps_and_moving_statistics_match():
+    """Step-locked comparison: at every step the gradients are checked against autograd at the (matched) weights, then
+    BOTH sides apply Adam to the GPU's gradients, so the update rule and the BN statistics are compared exactly.
+    (Letting each side use its own gradients is not a parity test: where |g| is at rounding level Adam's m / sqrt(v)
+    amplifies the noise to steps of +-lr, in TensorFlow as much as here.)"""
+    import torch
+    n, C, B, steps = 6, 128, 8, 4
+    ref, gpu = _pair(n, C, 2, B, seed=5)
+    w0 = ref.weights()
+    for s in range(steps):
+        own, opp, pi, z = _batch(n, B, seed=20 + s)
+        lr_ = ref.forward_backward(own, opp, pi, z)
+        lg = gpu.forward_backward(own, opp, pi, z)
+        assert np.allclose(lg, lr_, atol=5e-5, rtol=5e-5), (s, lg, lr_)
+        _check_grads(ref, gpu)
+        ref.apply(grads={i: torch.tensor(g.astype(np.float64)) for i, g in gpu.get_grads().items()})
+        gpu.apply()
+        wr, wg = ref.weights(), gpu.get_weights()
+        for i in range(40):
+            err = np.abs(wg[i].astype(np.float64) - wr[i]).max()
+            assert err <= 2e-6, f"step {s}, weight {i}: {err:.3e}"
+    assert gpu.step == steps
+    assert np.abs(wg[6] - w0[6]).max() > 5e-4                 # the steps really moved the weights (~lr per element per step)
+    assert np.abs(wg[4] - w0[4]).max() > 1e-4 and np.abs(wg[29] - w0[29]).max() > 1e-4      # moving statistics too
+
+
+def test_free_running_steps_stay_close():
+    """each side on its own gradients for a few steps: everything but the rounding-level-gradient elements agrees"""
+    n, C, B, steps = 6, 128, 8, 3
+    ref, gpu = _pair(n, C, 2, B, seed=8)
+    for s in range(steps):
+        own, opp, pi, z = _batch(n, B, seed=40 + s)
+        lr_ = ref.forward_backward(own, opp, pi, z)
+        lg = gpu.forward_backward(own, opp, pi, z)
+        assert np.allclose(lg, lr_, atol=2e-4, rtol=2e-4), (s, lg, lr_)
+        ref.apply()
+        gpu.apply()
+    wr, wg = ref.weights(), gpu.get_weights()
+    for i in range(40):
+        d = np.abs(wg[i].astype(np.float64) - wr[i])
+        assert d.max() <= steps * 2e-3 * 1.01, f"weight {i}: {d.max():.3e}"              # never more than 2 lr per step
+        if i not in BN_BIASES and d.size >= 1000:
+            assert (d > 3e-5).mean() < 0.02, f"weight {i}: {(d > 3e-5).mean():.4f} of the elements off by > 3e-5"
+
+
+def test_clipvalue_is_applied():
+    """a huge loss scale (targets far outside tanh's range) pushes gradients past 0.5: with clipvalue the first Adam
+    step is the same +-lr, but m and v differ -- checked through the second step against the oracle."""
+    n, C, B = 6, 128, 8
+    ref, gpu = _pair(n, C, 2, B, seed=6, dropout=0.0, clip=0.5)
+    own, opp, pi, z = _batch(n, B, seed=31)
+    z = z * 500.0
+    for _ in range(2):
+        ref.forward_backward(own, opp, pi, z)
+        gpu.forward_backward(own, opp, pi, z)
+        assert max(np.abs(g.numpy()).max() for g in ref.grads.values()) > 0.5
+        ref.apply()
+        gpu.apply()
+    wr, wg = ref.weights(), gpu.get_weights()
+    for i in (0, 6, 24, 30, 36, 38):
+        d = np.abs(wg[i].astype(np.float64) - wr[i])
+        assert (d > 3e-5).mean() < 0.02 and d.max() <= 4.1e-3
+
+
+def test_nnetwrapper_train_drop_in():
+    """NNetWrapper.train(examples) with the reference's example tuples; loss goes down on a fixed set, the inference
+    network afterwards carries the trained weights (predict == oracle forward of get_weights())."""
+    from oracle import nn_numpy
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.trainer import pack_examples
+    n, N = 6, 96
+    rs = np.random.RandomState(2)
+    examples = []
+    for _ in range(N):
+        occ = rs.rand(n, n) < 0.6
+        black = occ & (rs.rand(n, n) < 0.5)
+        board = np.stack([black, occ & ~black], axis=2)
+        pol = np.zeros((n, n))
+        pol[rs.randint(n), rs.randint(n)] = 1
+        examples.append((board, pol, int(rs.choice([-1, 1]))))
+    net = NNetWrapper((n, n), num_channels_1=128, batch_size=32, epochs=6, max_batch=4)
+    w_before = net.get_weights()
+    hist = net.train(examples)
+    assert len(hist.history["loss"]) == 6 and hist.history["loss"][-1] < hist.history["loss"][0]
+    assert all(np.isfinite(hist.history[k]).all() for k in hist.history)
+    w_after = net.get_weights()
+    assert np.abs(w_after[6] - w_before[6]).max() > 1e-3 and not np.array_equal(w_after[4], w_before[4])
+    own, opp, _, _ = pack_examples(examples[:4], n)
+    pi, v = net.predict_batch(own, opp)
+    pr, vr = nn_numpy.forward(w_after, own, opp, n)
+    assert np.abs(pi.reshape(4, -1) - pr).max() <= 1e-5 and np.abs(v - vr).max() <= 1e-5
+    hist2 = net.train(examples[:40])                                   # short last batch (40 = 32 + 8), optimiser state kept
+    assert net._trainer.step == 6 * 3 + 6 * 2 and np.isfinite(hist2.history["loss"]).all()
+
+
+DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from othellozero_amd.distributed import GradientAllReduce, average_moving_statistics
+from othellozero_amd.trainer import Trainer, fit
+from othellozero_amd.weights import init_weights
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=2)          # control-flow rehearsal: both ranks share GPU 0
+torch.cuda.set_device(0)
+n, C, B, N = 6, 128, 8, 24
+w = init_weights(n, seed=3, channels=C, randomize_all=True)
+def shard(r):
+    rs = np.random.RandomState(100 + r)
+    valid = np.uint64(sum(1 << (y * 8 + x) for y in range(n) for x in range(n)))
+    own = rs.randint(0, 2**63, size=N, dtype=np.uint64) & valid
+    opp = rs.randint(0, 2**63, size=N, dtype=np.uint64) & valid & ~own
+    pi = np.zeros((N, n * n), np.float32); pi[np.arange(N), rs.randint(0, n * n, N)] = 1
+    return own, opp, pi, rs.choice([-1.0, 1.0], N).astype(np.float32)
+ar = GradientAllReduce(n, C, 2, device="cuda")
+tr = Trainer(n, C, 2, max_batch=B, seed=9, external_grads_ptr=ar.ptr)
+tr.set_weights(w)
+hist = fit(tr, *shard(rank), batch_size=B, epochs=2, shuffle_seed=5, allreduce=ar)
+mine = tr.get_weights()
+flat = torch.from_numpy(np.concatenate([mine[i].ravel() for i in range(40) if i >= 36 or i % 6 not in (4, 5)]))
+both = [torch.zeros_like(flat) for _ in range(2)]
+dist.all_gather(both, flat)
+assert torch.equal(both[0], both[1]), "trainable weights diverged between the ranks"
+avg = average_moving_statistics(mine)
+if rank == 0:
+    # single-process emulation of the same job: two trainers, gradients averaged by hand between backward and apply
+    g = [torch.zeros(Trainer.arena_size(n, C, 2), dtype=torch.float32, device="cuda") for _ in range(2)]
+    t2 = [Trainer(n, C, 2, max_batch=B, seed=9, external_grads_ptr=g[r].data_ptr()) for r in range(2)]
+    data = [shard(r) for r in range(2)]
+    for t in t2: t.set_weights(w)
+    for ep in range(2):
+        order = np.random.RandomState(5 + ep).permutation(N)
+        for s in range(0, N, B):
+            idx = order[s:s + B]
+            for r in range(2):
+                t2[r].forward_backward(data[r][0][idx], data[r][1][idx], data[r][2][idx], data[r][3][idx])
+            m = (g[0] + g[1]) / 2
+            g[0].copy_(m); g[1].copy_(m); torch.cuda.synchronize()
+            for t in t2: t.apply()
+    e0, e1 = t2[0].get_weights(), t2[1].get_weights()
+    for i in range(40):
+        assert np.array_equal(e0[i], mine[i]), f"weight {i} differs from the single-process emulation"
+        if i < 36 and i % 6 in (4, 5):
+            assert np.allclose(avg[i], (e0[i] + e1[i]) / 2, atol=1e-7)
+    assert np.isfinite(hist.history["loss"]).all()
+dist.barrier()
+print("RANK_OK", rank)
+'''
+
+
+def test_data_parallel_two_ranks_equal_hand_averaged_gradients(tmp_path):
+    """GradientAllReduce + fit on two ranks (gloo, both on GPU 0): weights stay identical across ranks and equal, bit
+    for bit, a single-process run that averages the two gradient arenas by hand."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_gpu_worker.py"
+    script.write_text(DP_WORKER)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {rank}" in out, out
