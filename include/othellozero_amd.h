@@ -223,6 +223,8 @@ int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const uint64
                                 const float* z_target, int B, float* losses3);
 int oz_trainer_apply(oz_trainer* t);                         /* Adam step + BN moving-statistics commit (stream-ordered) */
 int oz_trainer_outputs(oz_trainer* t, int B, float* p /* [B][n*n] */, float* v /* [B] */);   /* of the last forward pass */
+/* post-activation output of block `layer` (0-3 conv, 4-5 dense; [B][pixels][channels]) of the last forward pass -- inspection */
+int oz_trainer_get_activation(oz_trainer* t, int layer, int B, float* data, int64_t nelem);
 int oz_trainer_sync(oz_trainer* t);
 int oz_trainer_step_count(oz_trainer* t, int64_t* step);
 

@@ -90,8 +90,22 @@ class TrainRef:
             self._new_stats[blk + 5] = self.w[blk + 5] * self.mom + upd_var.detach() * (1 - self.mom)
         return y
 
-    def forward_backward(self, own, opp, pi_target, z_target):
+    def _relu(self, y, layer):
+        """relu(y); where |y| < KINK the derivative is taken from `relu_masks[layer]` (the fp32 kernels' own decision)
+        instead of this float64 sign: relu' is ambiguous there at fp32 precision, and with ~1e6 units per batch some unit
+        always sits that close to the kink.  The forward value changes by < KINK."""
+        r = torch.relu(y)
+        if self.relu_masks is not None:
+            m = torch.tensor(np.asarray(self.relu_masks[layer], dtype=np.float64).reshape(tuple(y.shape)))
+            near = y.detach().abs() < 1e-5
+            self.kink_units += int(near.sum())
+            r = torch.where(near, y * m, r)
+        return r
+
+    def forward_backward(self, own, opp, pi_target, z_target, relu_masks=None):
+        """relu_masks: optional list of 6 {0,1} arrays (conv blocks NHWC, dense blocks (B, units)), see _relu"""
         n = self.n
+        self.relu_masks, self.kink_units = relu_masks, 0
         x = torch.tensor(planes(own, opp, n, self.in_channels))
         B = x.shape[0]
         for i in TRAINABLE:
@@ -104,11 +118,11 @@ class TrainRef:
             k = self.w[blk].permute(3, 2, 0, 1)                      # (3,3,Cin,Cout) -> (Cout,Cin,3,3)
             zc = torch.nn.functional.conv2d(h, k, self.w[blk + 1], padding=1 if same else 0)
             zc = self._bn_train(zc.permute(0, 2, 3, 1), blk, fused=True)
-            h = torch.relu(zc).permute(0, 3, 1, 2)
+            h = self._relu(zc, layer).permute(0, 3, 1, 2)
         f = h.permute(0, 2, 3, 1).reshape(B, -1)                      # Flatten of NHWC
         for j, blk in enumerate((24, 30)):
             zd = f @ self.w[blk] + self.w[blk + 1]
-            a = torch.relu(self._bn_train(zd, blk, fused=False))
+            a = self._relu(self._bn_train(zd, blk, fused=False), 4 + j)
             if self.rate > 0:
                 keep = torch.tensor(dropout_keep(self.seed, self.step, j, a.numel(), self.rate).reshape(a.shape))
                 a = a * keep / (1.0 - self.rate)

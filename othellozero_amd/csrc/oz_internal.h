@@ -32,7 +32,9 @@ struct GemmGeom {
     int Hin, Hout, pad, Cin, taps;   // taps = 9 (3x3 conv) or 1 (dense: Hin = Hout = 1, pad = 0)
     int N, K;                        // output channels, taps*Cin
     int relu;
+    int ksplit;                      // > 1: k loop split over blockIdx.y, raw sums to partial[split] (slab floats apart)
+    long long slab;
 };
 int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
                        const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
-                       hipStream_t s);
+                       hipStream_t s, float* partial, long long partial_floats);

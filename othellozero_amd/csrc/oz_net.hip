@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_conv1(const uint64_t* __restrict__ own,
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ in, const float* __restrict__ Wt,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      float* __restrict__ out, const int* __restrict__ d_count,
-                                                     GemmGeom g, int num_mt) {
+                                                     GemmGeom g, int num_mt, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][GM_BM * GM_LDS_STRIDE];   // [buf][A|B][row][k]
     // XCD-aware tile order: the N/128 column tiles of one row tile run on the same XCD (ids b, b+8 share an L2)
     const int nnt = g.N / GM_BN;
@@ -137,12 +137,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    const int nk = g.K / GM_BK;
+    // split-K (training step, few row tiles): blockIdx.y owns k-tiles [kt0, nk); raw partial sums go to partial[split]
+    const int nk_all = g.K / GM_BK, nk_s = (nk_all + g.ksplit - 1) / g.ksplit;
+    const int kt0 = blockIdx.y * nk_s, nk = min(nk_all, kt0 + nk_s);
     const int r32 = lane & 31, half = lane >> 5;
-    gload(0);
-    lstore(0);
+    if (kt0 < nk) { gload(kt0); lstore(kt0 & 1); }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
         const float* At = &lds[buf][0][(wm * 64 + r32) * GM_LDS_STRIDE + half * 4];
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
             for (int r = 0; r < 16; ++r) {
                 const long long m = (long long)mt * GM_BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m < M) {
+                    if (g.ksplit > 1) { partial[(size_t)blockIdx.y * g.slab + (size_t)m * g.N + col] = acc[i][jj][r]; continue; }
                     float v = fmaf(acc[i][jj][r], sc, sh);
                     if (g.relu) v = v > 0.f ? v : 0.f;
                     out[(size_t)m * g.N + col] = v;
@@ -185,18 +187,54 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
     }
 }
 
-// shared launcher (inference f32 path and the training step, oz_train.hip)
+// out = act(sum over splits (fixed order) * scale + shift)
+__global__ __launch_bounds__(256) void k_splitk_reduce_f32(const float* __restrict__ partial, long long slab, int ksplit, int N, int P,
+                                                           const int* __restrict__ d_count, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu, float* __restrict__ out) {
+    const long long total = (long long)(*d_count) * P * N;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= total) return;
+    f32x4 a = *reinterpret_cast<const f32x4*>(partial + i);
+    for (int s = 1; s < ksplit; ++s) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(partial + (size_t)s * slab + i);
+        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    const int col = (int)(i % N);
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = fmaf(a[q], scale[col + q], shift[col + q]);
+        r[q] = relu && v < 0.f ? 0.f : v;
+    }
+    *reinterpret_cast<f32x4*>(out + i) = r;
+}
+
+// shared launcher (inference f32 path and the training step, oz_train.hip).  `partial` (optional, `partial_floats`
+// long): when the launch would have fewer blocks than the chip has CUs, the k loop is split over blockIdx.y and reduced
+// in a fixed order by k_splitk_reduce_f32 -- same result for every batch position, different rounding than ksplit = 1.
 int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
                        const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
-                       hipStream_t s) {
+                       hipStream_t s, float* partial, long long partial_floats) {
     OZ_REQUIRE(N % GM_BN == 0 && Cin % GM_BK == 0, "gemm_f32: N %% 128 and Cin %% 32 must be 0 (N=%d Cin=%d)", N, Cin);
     GemmGeom g;
     g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.relu = relu;
     const long long Mmax = (long long)max_count * Hout * Hout;
     const int num_mt = (int)((Mmax + GM_BM - 1) / GM_BM);
     const int grid = ((num_mt + 7) / 8) * 8 * (N / GM_BN);
-    hipLaunchKernelGGL(k_gemm_f32, dim3(grid), dim3(256), 0, s, in, Wt, scale, shift, out, d_count, g, num_mt);
+    int ksplit = 1;
+    const int nk = g.K / GM_BK;
+    if (partial) {
+        while (ksplit < 16 && grid * ksplit < 256 && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * Mmax * N <= partial_floats) ksplit *= 2;
+    }
+    g.ksplit = ksplit; g.slab = Mmax * N;
+    hipLaunchKernelGGL(k_gemm_f32, dim3(grid, ksplit), dim3(256), 0, s, in, Wt, scale, shift, out, d_count, g, num_mt, partial);
     OZ_HIP(hipGetLastError());
+    if (ksplit > 1) {
+        const long long quads = (Mmax * N + 3) / 4;
+        hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, partial, g.slab, ksplit, N, Hout * Hout,
+                           d_count, scale, shift, relu, out);
+        OZ_HIP(hipGetLastError());
+    }
     return OZ_OK;
 }
 
@@ -345,7 +383,7 @@ struct OnnNet : oz_net {
 
     int launch_gemm(const float* in, const float* Wt, int layer, float* out, const int* d_count, int max_count, int Hin,
                     int Hout, int pad, int Cin, int taps, int N, hipStream_t s) {
-        return oz_gemm_f32_launch(in, Wt, d_scale[layer], d_shift[layer], out, d_count, max_count, Hin, Hout, pad, Cin, taps, N, 1, s);
+        return oz_gemm_f32_launch(in, Wt, d_scale[layer], d_shift[layer], out, d_count, max_count, Hin, Hout, pad, Cin, taps, N, 1, s, nullptr, 0);
     }
 
     // layer: 1..3 = conv2..4 (3x3, Cin = N = C), 4 = fc1, 5 = fc2 (taps 1)

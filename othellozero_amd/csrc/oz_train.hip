@@ -16,6 +16,7 @@
 // index is the batch x pixel row).  Column reductions (BN statistics, BN backward sums, bias gradients) use a
 // fixed-order two-stage reduction, so a step is deterministic.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -424,6 +425,9 @@ struct oz_trainer {
     float *z[6] = {}, *a[6] = {}, *mean[6] = {}, *rstd[6] = {}, *dz[6] = {};
     float *dA[2] = {}, *sums = nullptr, *partial = nullptr, *ones = nullptr, *zeros = nullptr;
     float *p = nullptr, *v = nullptr, *dlogit = nullptr, *dvpre = nullptr, *loss = nullptr, *losses = nullptr;
+    float* gpartial = nullptr;           // split-K scratch of the small-batch GEMMs
+    long long gpartial_floats = 16LL << 20;
+    int split_mask = 7;                  // diagnostic (env OZ_TRAIN_SPLIT_MASK): 1 forward, 2 dense dgrad, 4 conv dgrad GEMMs may split K
     int P_[6], Co[6], Hout[6], Hz[6], zoff[6];
     std::vector<void*> allocs;
     bool dirty = true;                   // derived operands need a refresh
@@ -475,6 +479,7 @@ OZ_API int oz_trainer_create(oz_trainer** out, int n, int channels, int in_chann
     oz_trainer* t = new oz_trainer();
     t->n = n; t->C = channels; t->cin = in_channels; t->Bmax = max_batch; t->lr = lr; t->clip = clipvalue; t->rate = dropout;
     t->mom = bn_momentum; t->seed = seed; t->device = oz_current_device();
+    if (const char* e = getenv("OZ_TRAIN_SPLIT_MASK")) t->split_mask = atoi(e);
     auto fail = [&](int rc) { delete t; return rc; };
     if (hipSetDevice(t->device) != hipSuccess || hipStreamCreate(&t->s) != hipSuccess) { oz_set_error("oz_trainer_create: no GPU stream"); return fail(OZ_ERR_HIP); }
     const int C = channels, A = n * n, F = (n - 4) * (n - 4) * C;
@@ -511,6 +516,7 @@ OZ_API int oz_trainer_create(oz_trainer** out, int n, int channels, int in_chann
         T_ALLOC(t->d_count, 1);
         T_ALLOC(t->p, (size_t)max_batch * A); T_ALLOC(t->v, max_batch); T_ALLOC(t->dlogit, (size_t)max_batch * A); T_ALLOC(t->dvpre, max_batch);
         T_ALLOC(t->loss, 2 * (size_t)max_batch); T_ALLOC(t->losses, 4);
+        T_ALLOC(t->gpartial, t->gpartial_floats);
         OZ_HIP(hipStreamSynchronize(t->s));
         return OZ_OK;
     }();
@@ -631,7 +637,7 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
     const int Hin[6] = {n, n, n, n - 2, 1, 1}, pad[6] = {1, 1, 0, 0, 0, 0}, Cin[6] = {t->cin, C, C, C, F, 1024}, taps[6] = {9, 9, 9, 9, 1, 1};
     for (int l = 1; l < 6; ++l) {
         if (int rc = oz_gemm_f32_launch(t->a[l - 1], t->Wt[l], t->ones, t->param(6 * l + 1), t->z[l], t->d_count, B, Hin[l], t->Hout[l], pad[l],
-                                        Cin[l], taps[l], t->Co[l], 0, s)) return rc;
+                                        Cin[l], taps[l], t->Co[l], 0, s, t->gpartial, (t->split_mask & 1) ? t->gpartial_floats : 0)) return rc;
         if (int rc = t_bn_forward(t, l, B)) return rc;
     }
     hipLaunchKernelGGL(k_t_heads, dim3(B), dim3(64), 0, s, t->a[5], t->d_count, n, t->param(36), t->param(37), t->param(38), t->param(39),
@@ -673,11 +679,11 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
             OZ_HIP(hipGetLastError());
             // data gradient -> dA[cur ^ 1] = gradient wrt a[l - 1]
             if (l >= 4) {          // dense: dX = dZ . W^T; the Keras kernel [in][out] already is the [N = in][K = out] operand
-                if (int rc = oz_gemm_f32_launch(t->dz[l], t->param(6 * l), t->ones, t->zeros, t->dA[cur ^ 1], t->d_count, B, 1, 1, 0, Cc, 1, Cin[l], 0, s)) return rc;
+                if (int rc = oz_gemm_f32_launch(t->dz[l], t->param(6 * l), t->ones, t->zeros, t->dA[cur ^ 1], t->d_count, B, 1, 1, 0, Cc, 1, Cin[l], 0, s, t->gpartial, (t->split_mask & 2) ? t->gpartial_floats : 0)) return rc;
             } else {               // 3x3 conv: conv of dz (zero-bordered for 'valid' layers) with the reversed, channel-swapped taps
                 const int same = pad[l];
                 if (int rc = oz_gemm_f32_launch(t->dz[l], t->Wd[l], t->ones, t->zeros, t->dA[cur ^ 1], t->d_count, B, t->Hz[l], Hin[l], same ? 1 : 0, Cc, 9,
-                                                Cin[l], 0, s)) return rc;
+                                                Cin[l], 0, s, t->gpartial, (t->split_mask & 4) ? t->gpartial_floats : 0)) return rc;
             }
             cur ^= 1;
         }
@@ -700,6 +706,15 @@ OZ_API int oz_trainer_apply(oz_trainer* t) {
     for (int i = 0; i < 36; ++i)
         if (t->toff[i] < 0) OZ_HIP(hipMemcpyAsync(t->stats[i], t->stats_new[i], t->size[i] * sizeof(float), hipMemcpyDeviceToDevice, t->s));
     t->dirty = true;
+    return OZ_OK;
+}
+
+OZ_API int oz_trainer_get_activation(oz_trainer* t, int layer, int B, float* data, int64_t nelem) {
+    OZ_REQUIRE(t && data && layer >= 0 && layer < 6 && B >= 1 && B <= t->Bmax, "oz_trainer_get_activation: bad argument");
+    OZ_REQUIRE(nelem == (int64_t)B * t->P_[layer] * t->Co[layer], "oz_trainer_get_activation: expected %lld elements", (long long)B * t->P_[layer] * t->Co[layer]);
+    OZ_HIP(hipSetDevice(t->device));
+    OZ_HIP(hipMemcpyAsync(data, t->a[layer], nelem * sizeof(float), hipMemcpyDeviceToHost, t->s));
+    OZ_HIP(hipStreamSynchronize(t->s));
     return OZ_OK;
 }
 

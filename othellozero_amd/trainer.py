@@ -101,6 +101,14 @@ class Trainer:
         _lib.check(_lib.load().oz_trainer_outputs(self._h, B, _lib.p_f32(p), _lib.p_f32(v)))
         return p, v
 
+    def activation(self, layer, B):
+        """post-activation output of block `layer` (0-3 conv: (B, H, H, C); 4-5 dense: (B, units)) of the last forward pass"""
+        n, C_ = self.n, self.channels
+        shape = [(B, n, n, C_), (B, n, n, C_), (B, n - 2, n - 2, C_), (B, n - 4, n - 4, C_), (B, 1024), (B, 512)][layer]
+        a = np.zeros(shape, np.float32)
+        _lib.check(_lib.load().oz_trainer_get_activation(self._h, layer, B, _lib.p_f32(a), a.size))
+        return a
+
     @property
     def step(self):
         s = C.c_int64()

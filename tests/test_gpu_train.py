@@ -27,6 +27,18 @@ def _batch(n, B, seed, cin=2):
     return own, opp, pi, z
 
 
+def _both(ref, gpu, batch):
+    """GPU step first, then the oracle with the GPU's ReLU decisions for the units within 1e-5 of the kink
+    (oracle/train_ref.py:_relu); returns (gpu losses, oracle losses)"""
+    own, opp, pi, z = batch
+    lg = gpu.forward_backward(own, opp, pi, z)
+    # (dense blocks: activations are post-dropout; a dropped unit has a == 0 whatever relu decided, and its gradient is 0
+    # on both sides, so its mask value does not matter)
+    masks = [(gpu.activation(l, len(z)) > 0).astype(np.float64) for l in range(6)]
+    lr_ = ref.forward_backward(own, opp, pi, z, relu_masks=masks)
+    return lg, lr_
+
+
 def _pair(n, C, cin, B, seed, dropout=0.3, clip=0.5):
     from oracle.train_ref import TrainRef
     from othellozero_amd.trainer import Trainer
@@ -56,9 +68,7 @@ def _check_grads(ref, gpu, scale=3e-4):
 @pytest.mark.parametrize("n,C,cin,B", [(6, 128, 2, 8), (8, 128, 2, 5), (6, 128, 1, 7), (8, 256, 2, 32)])
 def test_forward_backward_matches_autograd(n, C, cin, B):
     ref, gpu = _pair(n, C, cin, B, seed=3)
-    own, opp, pi, z = _batch(n, B, seed=11, cin=cin)
-    lr_ = ref.forward_backward(own, opp, pi, z)
-    lg = gpu.forward_backward(own, opp, pi, z)
+    lg, lr_ = _both(ref, gpu, _batch(n, B, 11, cin))
     assert np.allclose(lg, lr_, atol=2e-5, rtol=2e-5), (lg, lr_)
     p, v = gpu.outputs(B)
     assert np.abs(p - ref.outputs["p"]).max() <= 2e-5 and np.abs(v - ref.outputs["v"]).max() <= 2e-5
@@ -67,9 +77,8 @@ def test_forward_backward_matches_autograd(n, C, cin, B):
 
 def test_no_dropout_no_clip_and_determinism():
     ref, gpu = _pair(6, 128, 2, 16, seed=4, dropout=0.0, clip=0.0)
-    own, opp, pi, z = _batch(6, 16, seed=12)
-    ref.forward_backward(own, opp, pi, z)
-    l1 = gpu.forward_backward(own, opp, pi, z)
+    own, opp, pi, z = _batch(6, 16, 12)
+    l1, _ = _both(ref, gpu, (own, opp, pi, z))
     g1 = gpu.get_grads()
     _check_grads(ref, gpu)
     l2 = gpu.forward_backward(own, opp, pi, z)
@@ -87,9 +96,7 @@ def test_adam_steps_and_moving_statistics_match():
     ref, gpu = _pair(n, C, 2, B, seed=5)
     w0 = ref.weights()
     for s in range(steps):
-        own, opp, pi, z = _batch(n, B, seed=20 + s)
-        lr_ = ref.forward_backward(own, opp, pi, z)
-        lg = gpu.forward_backward(own, opp, pi, z)
+        lg, lr_ = _both(ref, gpu, _batch(n, B, 20 + s))
         assert np.allclose(lg, lr_, atol=5e-5, rtol=5e-5), (s, lg, lr_)
         _check_grads(ref, gpu)
         ref.apply(grads={i: torch.tensor(g.astype(np.float64)) for i, g in gpu.get_grads().items()})
