@@ -1,0 +1,197 @@
+"""Replay buffer, iteration loop and promotion rules -- the caller of the hot path (main.py:21-259), SURVEY.md 8(f) item 3.
+
+`CircularArray` is a drop-in for main.py:21-53 (same ring arithmetic, including its quirks: the write index only starts
+moving once the buffer is full, and `random.shuffle(buffer)` permutes the slots the ring later overwrites).
+`training(...)` keeps main.py:56-259's structure and decision rules, with the reference's WorkerManager fan-out replaced by
+the batched GPU engines:
+
+  episodes            worker_manager.run(EXECUTE_EPISODE, ...)          -> training.selfplay_batch (lock-step games in HBM)
+  new-vs-old matches  worker_manager.run(DUEL_BETWEEN_NEURAL_NETWORKS)  -> agents.arena_batch (half the games per colour)
+  fit                 neural_network.train(examples)                    -> oz_trainer_* (NNet.py)
+  evaluation          duel_between_agents vs RandomOthelloAgent         -> the same drop-in agents (agents.py), sequential
+
+Decision rules kept verbatim: promote after self-play when `new_net_victories >= self_play_threshold` (main.py:138);
+after an evaluation round keep the new network when `net_wins > old_net_wins * 1.1` (main.py:238), otherwise fall back to
+the old one; temperature drops to 0 from iteration `temperature_threshold` on (main.py:74-77).
+
+Deliberate differences (documented, switchable where it matters):
+* `reference_aliasing=True` reproduces `old_neural_network = neural_network` (main.py:142,243): after the first promotion
+  both names are ONE object, so later training also changes the "old" network.  False keeps a real copy.
+* the reference's worker-side `duel_between_neural_networks` (training.py:75-88) cannot run (it indexes a dict with the
+  tuple `duel_between_agents` returns); the intent -- `self_play_total_games` temperature-0 games, half per colour -- is what
+  `arena_batch` plays.
+* `examples-<n>.txt` (a str() dump of the whole buffer every iteration, main.py:252-253) is only written when asked.
+"""
+import logging
+import random
+
+import numpy as np
+
+from . import _lib
+from .agents import NeuralNetworkOthelloAgent, RandomOthelloAgent, arena_batch, duel_between_agents
+from .Othello import OthelloGame, OthelloPlayer
+from .training import expand_examples, selfplay_batch
+
+
+class CircularArray:
+    """main.py:21-53"""
+
+    def __init__(self, max_):
+        self._list = []
+        self._max = max_
+        self._index = 0
+
+    def append(self, item):
+        if len(self._list) < self._max:
+            return self._list.append(item)
+        self._list[self._index % len(self._list)] = item
+        self._index = (self._index % len(self._list)) + 1
+
+    def extend(self, items):
+        for item in items:
+            self.append(item)
+
+    def __len__(self):
+        return len(self._list)
+
+    def __getitem__(self, *args):
+        return self._list.__class__.__getitem__(self._list, *args)
+
+    def __setitem__(self, *args):
+        return self._list.__class__.__setitem__(self._list, *args)
+
+    def __iter__(self):
+        return iter(self._list)
+
+    def __str__(self):
+        return str(self._list)
+
+    def __repr__(self):
+        return '{}({})'.format(self.__class__.__name__, repr(len(self._list)))
+
+
+def examples_from_records(records, board_size, alias_final=True):
+    """move records of finished games -> the reference's example tuples [(board (n,n,2) bool, one-hot policy (n,n), z)],
+    8 per move in training.py:13-23's order.  alias_final=True shows every board as the game's FINAL position, which is
+    what execute_episode really returns; False stores the position at the move."""
+    boards, pol, z = expand_examples(records, board_size, alias_final=alias_final)
+    n = board_size
+    out = []
+    for b, p, zz in zip(boards.astype(bool), pol, z):
+        policy = np.zeros((n, n))
+        policy[p // n, p % n] = 1
+        out.append((b, policy, int(zz)))
+    return out
+
+
+def evaluate_against_random(board_size, neural_network, games, num_simulations, degree_exploration, label="Network"):
+    """main.py:163-192 / :197-233: `games` duels against RandomOthelloAgent, colours drawn by random.shuffle.
+    -> dict(wins, black_wins, black_games, white_wins, white_games)"""
+    r = dict(wins=0, black_wins=0, black_games=0, white_wins=0, white_games=0)
+    for k in range(games):
+        game = OthelloGame(board_size, current_player=OthelloPlayer.BLACK)
+        nn_agent = NeuralNetworkOthelloAgent(game, neural_network, num_simulations, degree_exploration)
+        random_agent = RandomOthelloAgent(game)
+        agents = [nn_agent, random_agent]
+        random.shuffle(agents)
+        agent_winner, points = duel_between_agents(game, *agents)
+        winner = OthelloPlayer.BLACK if agents[0] is agent_winner else OthelloPlayer.WHITE
+        colour = "black" if winner == OthelloPlayer.BLACK else "white"
+        r[colour + "_games"] += 1
+        if agent_winner is nn_agent:
+            r["wins"] += 1
+            r[colour + "_wins"] += 1
+        logging.info(f'{label} won: {r["wins"]}/{k + 1} => {round(r["wins"] / (k + 1), 2)} win rate, '
+                     f'black: {r["black_wins"]}/{r["black_games"]} , white: {r["white_wins"]}/{r["white_games"]}')
+    return r
+
+
+def self_play_match(board_size, neural_network, old_neural_network, total_games, num_simulations, degree_exploration, seed=0):
+    """main.py:110-134: total_games // 2 games with the new network as BLACK, the rest with it as WHITE.
+    -> number of games the new network won (a drawn game goes to BLACK, like get_winning_player)."""
+    as_black, as_white = total_games // 2, total_games // 2 + total_games % 2
+    wins = 0
+    if as_black:
+        res = arena_batch(neural_network, old_neural_network, board_size, as_black, num_simulations, degree_exploration, seed=seed)
+        wins += int((res["winner"] == 1).sum())
+    if as_white:
+        res = arena_batch(old_neural_network, neural_network, board_size, as_white, num_simulations, degree_exploration,
+                          seed=seed, first_game_id=as_black)
+        wins += int((res["winner"] == -1).sum())
+    return wins
+
+
+def training(board_size, num_iterations, num_episodes, num_simulations, degree_exploration, temperature, neural_network,
+             e_greedy, evaluation_interval, evaluation_iterations, temperature_threshold, self_play_training,
+             self_play_interval, self_play_total_games, self_play_threshold, checkpoint_filepath, training_buffer_size,
+             seed=1234, reference_aliasing=True, alias_final_boards=True, dump_examples=False, q_mode=_lib.QMODE_F64):
+    """main.py:56-259 on the GPU engines; returns `historic` = [(episodes done, win rate vs random), ...]"""
+    if self_play_training:
+        assert self_play_threshold <= self_play_total_games, 'Self-play threshold must be less than self-play games'
+
+    historic = []
+    total_episodes_done = 0
+    training_examples = CircularArray(training_buffer_size)
+    old_neural_network = neural_network.copy()
+    for i in range(1, num_iterations + 1):
+        logging.info(f'Iteration {i}/{num_iterations}: Starting iteration')
+        if temperature_threshold and i >= temperature_threshold:
+            logging.info(f'Iteration {i}/{num_iterations}: Temperature threshold reached, changing temperature to 0')
+            temperature = 0
+
+        logging.info(f'Iteration {i}/{num_iterations} - Generating episodes')
+        records = selfplay_batch(neural_network, board_size, num_games=num_episodes, num_simulations=num_simulations,
+                                 degree_exploration=degree_exploration, policy_temperature=temperature, e_greedy=e_greedy,
+                                 seed=seed, first_game_id=total_episodes_done, q_mode=q_mode)
+        training_examples.extend(examples_from_records(records, board_size, alias_final=alias_final_boards))
+        total_episodes_done += num_episodes
+        logging.info(f'Iteration {i}/{num_iterations}: All episodes finished')
+
+        logging.info(f'Iteration {i}/{num_iterations}: Training model with episodes examples')
+        random.shuffle(training_examples)
+        neural_network.train(training_examples, verbose=2 if logging.root.level <= logging.DEBUG else None)
+
+        if self_play_training and i % self_play_interval == 0:
+            logging.info(f'Iteration {i}/{num_iterations}: Self-play to evaluate the neural network training')
+            new_net_victories = self_play_match(board_size, neural_network, old_neural_network, self_play_total_games,
+                                                num_simulations, degree_exploration, seed=seed + i)
+            logging.info(f'Iteration {i}/{num_iterations} - Game results: {new_net_victories}/{self_play_total_games}: ')
+            if new_net_victories >= self_play_threshold:
+                logging.info(f'Iteration {i}/{num_iterations}: New neural network has been promoted')
+                neural_network.save_checkpoint(checkpoint_filepath)
+                logging.info(f'Iteration {i}/{num_iterations}: Saving trained model in "{checkpoint_filepath}"')
+                old_neural_network = neural_network if reference_aliasing else neural_network.copy()
+            else:
+                neural_network = old_neural_network if reference_aliasing else old_neural_network.copy()
+                logging.info(f'Iteration {i}/{num_iterations}: New neural network has not been promoted')
+        else:
+            neural_network.save_checkpoint(checkpoint_filepath)
+
+        if i % evaluation_interval == 0:
+            logging.info('New Neural Network evaluation!')
+            new = evaluate_against_random(board_size, neural_network, evaluation_iterations, num_simulations, degree_exploration,
+                                          label=f'Total Episodes Runned: {total_episodes_done} - Network')
+            logging.info('Old Neural Network evaluation!')
+            old = evaluate_against_random(board_size, old_neural_network, evaluation_iterations, num_simulations, degree_exploration,
+                                          label=f'Total Episodes Runned: {total_episodes_done} - Old Network')
+            if new["wins"] > (old["wins"] * 1.1):
+                logging.info("Saving new network!")
+                historic.append((total_episodes_done, (new["wins"] / evaluation_iterations)))
+                neural_network.save_checkpoint(checkpoint_filepath)
+                old_neural_network = neural_network if reference_aliasing else neural_network.copy()
+            else:
+                logging.info("Saving old network!")
+                historic.append((total_episodes_done, (old["wins"] / evaluation_iterations)))
+                old_neural_network.save_checkpoint(checkpoint_filepath)
+                neural_network = old_neural_network if reference_aliasing else old_neural_network.copy()
+            logging.info(historic)
+
+        logging.info(f'Total episodes done: {total_episodes_done}')
+        if dump_examples:
+            with open(f'examples-{board_size}.txt', 'w') as output:
+                output.write(str(training_examples))
+        with open(f'historic-last-training-session-{board_size}.txt', 'w') as output:
+            output.write(str(historic))
+
+    training.last_network = neural_network
+    return historic

