@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_t_heads_dgrad(const float* __restrict__
 #define WG_STRIDE 160
 struct WgradGeom { int Hin, Hout, pad, Cin, Cout, taps, Hz, zoff; };
 __global__ __launch_bounds__(256) void k_wgrad_f32(const float* __restrict__ X, const float* __restrict__ dZ, const int* __restrict__ d_count,
-                                                   WgradGeom g, float* __restrict__ dW) {
+                                                   WgradGeom g, float* __restrict__ dW, int msplit, float* __restrict__ partial, long long slab) {
     __shared__ __attribute__((aligned(16))) float lds[2][32 * WG_STRIDE];
     const int nci = g.Cin / 128, nco = g.Cout / 128;
     const int tap = blockIdx.x / (nci * nco), rem = blockIdx.x % (nci * nco), ci0 = (rem / nco) * 128, co0 = (rem % nco) * 128;
@@ -343,10 +343,13 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(const float* __restrict__ X, 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int r32 = lane & 31, kk = lane >> 5;
-    const long long nk = (M + 31) / 32;
-    if (nk > 0) { gload(0); lstore(); }
+    // rows (the k index) split over blockIdx.y when the launch is small: partial sums to partial[split], reduced in fixed order
+    const long long nk_all = (M + 31) / 32, nk_s = (nk_all + msplit - 1) / msplit, kt0 = blockIdx.y * nk_s;
+    const long long nk = nk_all < kt0 + nk_s ? nk_all : kt0 + nk_s;
+    float* __restrict__ outp = msplit > 1 ? partial + (size_t)blockIdx.y * slab : dW;
+    if (kt0 < nk) { gload(kt0 * 32); lstore(); }
     __syncthreads();
-    for (long long kt = 0; kt < nk; ++kt) {
+    for (long long kt = kt0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload((kt + 1) * 32);
         const float* At = &lds[0][kk * WG_STRIDE + wm * 64 + r32];
         const float* Bt = &lds[1][kk * WG_STRIDE + wn * 64 + r32];
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(const float* __restrict__ X, 
             for (int r = 0; r < 16; ++r) {
                 const int ci = ci0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                 const int co = co0 + wn * 64 + j * 32 + r32;
-                dW[((size_t)tap * g.Cin + ci) * g.Cout + co] = acc[i][j][r];
+                outp[((size_t)tap * g.Cin + ci) * g.Cout + co] = acc[i][j][r];
             }
 }
 
@@ -431,6 +434,7 @@ struct oz_trainer {
     int P_[6], Co[6], Hout[6], Hz[6], zoff[6];
     std::vector<void*> allocs;
     bool dirty = true;                   // derived operands need a refresh
+    std::mutex mu;                       // one caller at a time (ThreadWorker-style Python threads)
 
     ~oz_trainer() {
         hipSetDevice(device);
@@ -466,6 +470,7 @@ static int t_alloc(oz_trainer* t, void** out, size_t bytes, bool zero = true) {
     if (zero) OZ_HIP(hipMemsetAsync(*out, 0, bytes ? bytes : 16, t->s));
     return OZ_OK;
 }
+#define T_LOCK(t) std::lock_guard<std::mutex> lock__((t)->mu)
 #define T_ALLOC(ptr, count) do { if (int rc__ = t_alloc(t, (void**)&(ptr), (size_t)(count) * sizeof(*(ptr)))) return rc__; } while (0)
 
 OZ_API int oz_trainer_create(oz_trainer** out, int n, int channels, int in_channels, int max_batch, float lr, float clipvalue,
@@ -529,6 +534,7 @@ OZ_API int oz_trainer_destroy(oz_trainer* t) { delete t; return OZ_OK; }
 
 OZ_API int oz_trainer_set_weight(oz_trainer* t, int index, const float* data, int64_t nelem) {
     OZ_REQUIRE(t && data && index >= 0 && index < 40, "oz_trainer_set_weight: bad argument");
+    T_LOCK(t);
     OZ_REQUIRE(nelem == t->size[index], "oz_trainer_set_weight: weight %d has %lld elements, got %lld", index, (long long)t->size[index], (long long)nelem);
     OZ_HIP(hipSetDevice(t->device));
     OZ_HIP(hipMemcpyAsync(t->param(index), data, nelem * sizeof(float), hipMemcpyHostToDevice, t->s));
@@ -538,6 +544,7 @@ OZ_API int oz_trainer_set_weight(oz_trainer* t, int index, const float* data, in
 }
 OZ_API int oz_trainer_get_weight(oz_trainer* t, int index, float* data, int64_t nelem) {
     OZ_REQUIRE(t && data && index >= 0 && index < 40 && nelem == t->size[index], "oz_trainer_get_weight: bad argument");
+    T_LOCK(t);
     OZ_HIP(hipSetDevice(t->device));
     OZ_HIP(hipMemcpyAsync(data, t->param(index), nelem * sizeof(float), hipMemcpyDeviceToHost, t->s));
     OZ_HIP(hipStreamSynchronize(t->s));
@@ -545,6 +552,7 @@ OZ_API int oz_trainer_get_weight(oz_trainer* t, int index, float* data, int64_t 
 }
 OZ_API int oz_trainer_get_grad(oz_trainer* t, int index, float* data, int64_t nelem) {
     OZ_REQUIRE(t && data && index >= 0 && index < 40 && nelem == t->size[index] && t->toff[index] >= 0, "oz_trainer_get_grad: bad argument");
+    T_LOCK(t);
     OZ_HIP(hipSetDevice(t->device));
     OZ_HIP(hipMemcpyAsync(data, t->grad(index), nelem * sizeof(float), hipMemcpyDeviceToHost, t->s));
     OZ_HIP(hipStreamSynchronize(t->s));
@@ -552,6 +560,7 @@ OZ_API int oz_trainer_get_grad(oz_trainer* t, int index, float* data, int64_t ne
 }
 OZ_API int oz_trainer_grad_arena(oz_trainer* t, void** device_ptr, int64_t* nelem) {
     OZ_REQUIRE(t && device_ptr && nelem, "oz_trainer_grad_arena: bad argument");
+    T_LOCK(t);
     *device_ptr = t->G; *nelem = t->total;
     return OZ_OK;
 }
@@ -564,12 +573,14 @@ OZ_API int oz_trainer_arena_size(int n, int channels, int in_channels, int64_t* 
 }
 OZ_API int oz_trainer_sync(oz_trainer* t) {
     OZ_REQUIRE(t, "oz_trainer_sync: NULL");
+    T_LOCK(t);
     OZ_HIP(hipSetDevice(t->device));
     OZ_HIP(hipStreamSynchronize(t->s));
     return OZ_OK;
 }
 OZ_API int oz_trainer_step_count(oz_trainer* t, int64_t* step) {
     OZ_REQUIRE(t && step, "oz_trainer_step_count: bad argument");
+    T_LOCK(t);
     *step = t->step;
     return OZ_OK;
 }
@@ -617,6 +628,7 @@ static int t_bn_forward(oz_trainer* t, int l, int B) {
 OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const uint64_t* opp, const float* pi_target, const float* z_target,
                                        int B, float* losses3) {
     OZ_REQUIRE(t && own && opp && pi_target && z_target, "oz_trainer_forward_backward: NULL argument");
+    T_LOCK(t);
     OZ_REQUIRE(B >= 1 && B <= t->Bmax, "oz_trainer_forward_backward: batch %d outside [1, %d]", B, t->Bmax);
     OZ_HIP(hipSetDevice(t->device));
     hipStream_t s = t->s;
@@ -675,7 +687,14 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
             OZ_HIP(hipGetLastError());
         } else {
             WgradGeom g; g.Hin = Hin[l]; g.Hout = t->Hout[l]; g.pad = pad[l]; g.Cin = Cin[l]; g.Cout = Cc; g.taps = taps[l]; g.Hz = t->Hz[l]; g.zoff = t->zoff[l];
-            hipLaunchKernelGGL(k_wgrad_f32, dim3(taps[l] * (Cin[l] / 128) * (Cc / 128)), dim3(256), 0, s, t->a[l - 1], t->dz[l], t->d_count, g, t->grad(6 * l));
+            const int wblocks = taps[l] * (Cin[l] / 128) * (Cc / 128);
+            const long long wcount = (long long)taps[l] * Cin[l] * Cc, wtiles = ((long long)B * P + 31) / 32;
+            int msplit = 1;
+            while (msplit < 16 && wblocks * msplit < 512 && wtiles / (msplit * 2) >= 16 && wcount * msplit * 2 <= t->gpartial_floats) msplit *= 2;
+            hipLaunchKernelGGL(k_wgrad_f32, dim3(wblocks, msplit), dim3(256), 0, s, t->a[l - 1], t->dz[l], t->d_count, g, t->grad(6 * l), msplit,
+                               t->gpartial, wcount);
+            if (msplit > 1)
+                hipLaunchKernelGGL(k_t_sum_partials, dim3((unsigned)((wcount + 255) / 256)), dim3(256), 0, s, t->gpartial, msplit, wcount, t->grad(6 * l));
             OZ_HIP(hipGetLastError());
             // data gradient -> dA[cur ^ 1] = gradient wrt a[l - 1]
             if (l >= 4) {          // dense: dX = dZ . W^T; the Keras kernel [in][out] already is the [N = in][K = out] operand
@@ -697,6 +716,7 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
 
 OZ_API int oz_trainer_apply(oz_trainer* t) {
     OZ_REQUIRE(t, "oz_trainer_apply: NULL");
+    T_LOCK(t);
     OZ_HIP(hipSetDevice(t->device));
     t->step += 1;
     const double b1t = pow(0.9, (double)t->step), b2t = pow(0.999, (double)t->step);
@@ -711,6 +731,7 @@ OZ_API int oz_trainer_apply(oz_trainer* t) {
 
 OZ_API int oz_trainer_get_activation(oz_trainer* t, int layer, int B, float* data, int64_t nelem) {
     OZ_REQUIRE(t && data && layer >= 0 && layer < 6 && B >= 1 && B <= t->Bmax, "oz_trainer_get_activation: bad argument");
+    T_LOCK(t);
     OZ_REQUIRE(nelem == (int64_t)B * t->P_[layer] * t->Co[layer], "oz_trainer_get_activation: expected %lld elements", (long long)B * t->P_[layer] * t->Co[layer]);
     OZ_HIP(hipSetDevice(t->device));
     OZ_HIP(hipMemcpyAsync(data, t->a[layer], nelem * sizeof(float), hipMemcpyDeviceToHost, t->s));
@@ -720,6 +741,7 @@ OZ_API int oz_trainer_get_activation(oz_trainer* t, int layer, int B, float* dat
 
 OZ_API int oz_trainer_outputs(oz_trainer* t, int B, float* p, float* v) {
     OZ_REQUIRE(t && B >= 1 && B <= t->Bmax, "oz_trainer_outputs: bad argument");
+    T_LOCK(t);
     OZ_HIP(hipSetDevice(t->device));
     if (p) OZ_HIP(hipMemcpyAsync(p, t->p, (size_t)B * t->n * t->n * sizeof(float), hipMemcpyDeviceToHost, t->s));
     if (v) OZ_HIP(hipMemcpyAsync(v, t->v, B * sizeof(float), hipMemcpyDeviceToHost, t->s));
