@@ -79,11 +79,25 @@ def cpu_baseline(n, channels, sims, budget_s=12.0):
     while t < budget_s and games < 64:                                               # whole games until the budget is used
         dt, ep = run(games, n * n)
         t, exp, plies, games = t + dt, exp + ep["stats"]["expansions"], plies + ep["n_moves"], games + 1
+    # the same port on ONE thread ("at 1 thread and at all host cores"): a few plies are enough
+    net1 = oracle.CNet(w, n, channels=channels, nthreads=1)
+    m1 = oracle.Mcts(n, 1.0, oracle.QMODE_F64, evaluator=net1.evaluator())
+    t0 = time.perf_counter()
+    ep1 = m1.episode(sims, 1.0, 0.9, 1234, 0, max_moves=2)
+    t1 = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return {
         "value": exp / t, "unit": "node-expansions/s", "cores": threads, "kind": "port",
         "sample": f"{plies} plies of {games} sequential {n}x{n} game(s) at {sims} sims/move "
                   f"({exp} expansions, {plies * sims} sims, {t:.1f} s), batch-1 leaf eval, OpenMP x{threads}",
         "sims_per_s": plies * sims / t,
+        "value_1_thread": ep1["stats"]["expansions"] / t1, "sample_1_thread": f"first 2 plies of game 0 ({t1:.1f} s)",
+        "cpu_model": model, "host_cpus": os.cpu_count(),
     }
 
 
