@@ -117,16 +117,24 @@ class NNetWrapper(_NetHandle):
         own, opp, pi, z = T.pack_examples(examples, self.board_size_x, self.in_channels)
         if getattr(self, "_trainer", None) is None:
             assert self.num_channels % 128 == 0, "the training kernels need num_channels % 128 == 0"
+            # a GradientAllReduce owns the gradient arena (a torch tensor RCCL can reduce in place): the library writes into it
             self._trainer = T.Trainer(self.board_size_x, self.num_channels, self.in_channels, max_batch=self.batch_size, lr=self.lr,
                                       clipvalue=0.5 if self.network_type is NeuralNets.ONN else 0.0, dropout=self.dropout,
-                                      seed=self._model_index if seed is None else seed)
+                                      seed=self._model_index if seed is None else seed,
+                                      external_grads_ptr=getattr(allreduce, "ptr", None))
+            self._trainer_arena = getattr(allreduce, "ptr", None)
             self._fit_calls = 0
+        assert getattr(allreduce, "ptr", None) == self._trainer_arena, "train() must keep using the GradientAllReduce it started with"
         self._trainer.set_weights(self.get_weights())
         hist = T.fit(self._trainer, own, opp, pi, z, batch_size=self.batch_size, epochs=self.epochs,
                      shuffle_seed=1000003 * self._fit_calls + (self._model_index if seed is None else seed), allreduce=allreduce,
                      verbose=verbose)
         self._fit_calls += 1
-        self.set_weights(self._trainer.get_weights())
+        weights = self._trainer.get_weights()
+        if allreduce is not None:                       # BN moving statistics are per replica: average them
+            from .distributed import average_moving_statistics
+            weights = average_moving_statistics(weights, getattr(allreduce, "group", None))
+        self.set_weights(weights)
         return hist
 
     # ---- checkpoints (Net/NNet.py:90-96): Keras HDF5 weight files, read and written by keras_h5.py (no h5py needed);

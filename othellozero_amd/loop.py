@@ -124,10 +124,33 @@ def self_play_match(board_size, neural_network, old_neural_network, total_games,
 def training(board_size, num_iterations, num_episodes, num_simulations, degree_exploration, temperature, neural_network,
              e_greedy, evaluation_interval, evaluation_iterations, temperature_threshold, self_play_training,
              self_play_interval, self_play_total_games, self_play_threshold, checkpoint_filepath, training_buffer_size,
-             seed=1234, reference_aliasing=True, alias_final_boards=True, dump_examples=False, q_mode=_lib.QMODE_F64):
-    """main.py:56-259 on the GPU engines; returns `historic` = [(episodes done, win rate vs random), ...]"""
+             seed=1234, reference_aliasing=True, alias_final_boards=True, dump_examples=False, q_mode=_lib.QMODE_F64,
+             distributed=False):
+    """main.py:56-259 on the GPU engines; returns `historic` = [(episodes done, win rate vs random), ...]
+
+    distributed=True (torch.distributed initialised, one process per GPU): the episodes of an iteration are sharded over
+    the ranks by global game id and pooled with one all-gather of move records, every rank then holds the same replay
+    buffer (same `random` stream, seeded here), trains on its 1/world slice of it with one gradient all-reduce per step,
+    and plays the (deterministic) matches / evaluations redundantly, so all ranks take the same promotion decisions
+    without further communication; rank 0 writes the files."""
     if self_play_training:
         assert self_play_threshold <= self_play_total_games, 'Self-play threshold must be less than self-play games'
+
+    world, rank, allreduce = 1, 0, None
+    if distributed:
+        import torch
+        import torch.distributed as dist
+        from .distributed import GradientAllReduce, pooled_selfplay_records, shard_games
+        from .training import SelfPlayEngine
+        world, rank = dist.get_world_size(), dist.get_rank()
+        assert num_episodes >= world, "fewer episodes than ranks"
+        device = torch.device("cuda", torch.cuda.current_device())
+        allreduce = GradientAllReduce(board_size, neural_network.num_channels, neural_network.in_channels, device=device)
+        random.seed(seed)
+
+    def save(net):
+        if rank == 0:
+            net.save_checkpoint(checkpoint_filepath)
 
     historic = []
     total_episodes_done = 0
@@ -140,16 +163,29 @@ def training(board_size, num_iterations, num_episodes, num_simulations, degree_e
             temperature = 0
 
         logging.info(f'Iteration {i}/{num_iterations} - Generating episodes')
-        records = selfplay_batch(neural_network, board_size, num_games=num_episodes, num_simulations=num_simulations,
-                                 degree_exploration=degree_exploration, policy_temperature=temperature, e_greedy=e_greedy,
-                                 seed=seed, first_game_id=total_episodes_done, q_mode=q_mode)
+        if distributed:
+            first, count = shard_games(num_episodes, rank, world)
+            eng = SelfPlayEngine(neural_network, board_size, count, num_simulations, degree_exploration, temperature, e_greedy,
+                                 seed=seed, first_game_id=total_episodes_done + first, q_mode=q_mode)
+            eng.play_to_end()
+            records = pooled_selfplay_records(eng, device)          # the only exchange of the self-play phase
+            del eng
+        else:
+            records = selfplay_batch(neural_network, board_size, num_games=num_episodes, num_simulations=num_simulations,
+                                     degree_exploration=degree_exploration, policy_temperature=temperature, e_greedy=e_greedy,
+                                     seed=seed, first_game_id=total_episodes_done, q_mode=q_mode)
         training_examples.extend(examples_from_records(records, board_size, alias_final=alias_final_boards))
         total_episodes_done += num_episodes
         logging.info(f'Iteration {i}/{num_iterations}: All episodes finished')
 
         logging.info(f'Iteration {i}/{num_iterations}: Training model with episodes examples')
         random.shuffle(training_examples)
-        neural_network.train(training_examples, verbose=2 if logging.root.level <= logging.DEBUG else None)
+        verbose = 2 if logging.root.level <= logging.DEBUG else None
+        if distributed:
+            usable = len(training_examples) - len(training_examples) % world     # equal step counts on every rank
+            neural_network.train([training_examples[j] for j in range(rank, usable, world)], verbose=verbose, allreduce=allreduce)
+        else:
+            neural_network.train(training_examples, verbose=verbose)
 
         if self_play_training and i % self_play_interval == 0:
             logging.info(f'Iteration {i}/{num_iterations}: Self-play to evaluate the neural network training')
@@ -158,14 +194,14 @@ def training(board_size, num_iterations, num_episodes, num_simulations, degree_e
             logging.info(f'Iteration {i}/{num_iterations} - Game results: {new_net_victories}/{self_play_total_games}: ')
             if new_net_victories >= self_play_threshold:
                 logging.info(f'Iteration {i}/{num_iterations}: New neural network has been promoted')
-                neural_network.save_checkpoint(checkpoint_filepath)
+                save(neural_network)
                 logging.info(f'Iteration {i}/{num_iterations}: Saving trained model in "{checkpoint_filepath}"')
                 old_neural_network = neural_network if reference_aliasing else neural_network.copy()
             else:
                 neural_network = old_neural_network if reference_aliasing else old_neural_network.copy()
                 logging.info(f'Iteration {i}/{num_iterations}: New neural network has not been promoted')
         else:
-            neural_network.save_checkpoint(checkpoint_filepath)
+            save(neural_network)
 
         if i % evaluation_interval == 0:
             logging.info('New Neural Network evaluation!')
@@ -177,21 +213,22 @@ def training(board_size, num_iterations, num_episodes, num_simulations, degree_e
             if new["wins"] > (old["wins"] * 1.1):
                 logging.info("Saving new network!")
                 historic.append((total_episodes_done, (new["wins"] / evaluation_iterations)))
-                neural_network.save_checkpoint(checkpoint_filepath)
+                save(neural_network)
                 old_neural_network = neural_network if reference_aliasing else neural_network.copy()
             else:
                 logging.info("Saving old network!")
                 historic.append((total_episodes_done, (old["wins"] / evaluation_iterations)))
-                old_neural_network.save_checkpoint(checkpoint_filepath)
+                save(old_neural_network)
                 neural_network = old_neural_network if reference_aliasing else old_neural_network.copy()
             logging.info(historic)
 
         logging.info(f'Total episodes done: {total_episodes_done}')
-        if dump_examples:
+        if dump_examples and rank == 0:
             with open(f'examples-{board_size}.txt', 'w') as output:
                 output.write(str(training_examples))
-        with open(f'historic-last-training-session-{board_size}.txt', 'w') as output:
-            output.write(str(historic))
+        if rank == 0:
+            with open(f'historic-last-training-session-{board_size}.txt', 'w') as output:
+                output.write(str(historic))
 
     training.last_network = neural_network
     return historic
