@@ -11,7 +11,7 @@ run() { # name, rocprof args..., then bench args
   timeout -k 10 400 rocprofv3 "$@" --output-format csv -d $OUT/$name -o run -- python3 bench.py --precision $PREC --no-cpu-baseline $BENCH_ARGS > $OUT/$name.log 2>&1
   echo "$name done"
 }
-BENCH_ARGS="--steps 2 --warmup 1" run trace --kernel-trace --stats
+BENCH_ARGS="" run trace --kernel-trace --stats          # the default command: 64 move rounds = whole games
 BENCH_ARGS="--steps 1 --warmup 0" run fetch --kernel-trace --pmc FETCH_SIZE
 BENCH_ARGS="--steps 1 --warmup 0" run write --kernel-trace --pmc WRITE_SIZE
 BENCH_ARGS="--steps 1 --warmup 0" run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY
