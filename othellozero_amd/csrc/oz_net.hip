@@ -18,6 +18,7 @@
 // Every output row is an independent k-ordered fp32 FMA chain, so a position's (pi, v) does not
 // depend on where in the batch it sits (the search relies on that for reproducibility).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -400,6 +401,8 @@ struct OnnNet : oz_net {
         if (ksplit > 1) out = d_partial;          // raw k-slice sums; k_splitk_reduce_h2 below writes out_final (h2 layout)
         if (!h2_attr_set) {
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Big>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Big::LDS));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2BigPP::LDS));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2MidPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2MidPP::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Mid>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Mid::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Thin>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Thin::LDS));
@@ -436,10 +439,14 @@ struct OnnNet : oz_net {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && pending.size() > 4096) { if (int rc = collect_profile()) return rc; }
         if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); OZ_HIP(hipEventRecord(e0, s)); }
-        if (int rc = launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
+        static const bool pp = !(getenv("OZ_H2_PP") && atoi(getenv("OZ_H2_PP")) == 0);    // ping-pong main loop (default); OZ_H2_PP=0 selects the one-barrier-per-tile loop for A/B runs
+        if (int rc = pp ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s)
+                        : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
         if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
-        if (int rc = launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
-        if (int rc = launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
+        if (int rc = pp ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s)
+                        : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
+        if (int rc = pp ? launch_gemm_h2<H2BigPP>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)
+                        : launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
         // fc1: K = 8192 but only batch x 1024 outputs -> 4-way split-K (fixed-order reduce) to fill the chip
         if (int rc = launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
         if (int rc = launch_gemm_h2<H2Thin>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;

@@ -58,8 +58,13 @@ template <int NWM, int NWN, int NTI, int NTJ> struct H2Cfg {
     static constexpr int PB = (NTI % 2 == 0) ? 4 : 2, SLICE = PB * 16 * 256;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
     static_assert(NW * SLICE <= LDS, "epilogue slices must fit in the staging buffers");
+    static constexpr bool PP = false;     // main loop: false = one barrier per k-tile; true = 4-phase ping-pong (H2BigPP)
 };
 typedef H2Cfg<2, 4, 4, 2> H2Big;      // conv2, conv4: 256 x 256
+// the same tile with the ping-pong main loop: the two wave rows (= the two waves of every SIMD) run half a phase
+// apart, so one of them is in its MFMA cluster while the other issues LDS reads and LDS-DMA (see k_gemm_h2)
+struct H2BigPP : H2Cfg<2, 4, 4, 2> { static constexpr bool PP = true; };
+struct H2MidPP : H2Cfg<2, 4, 3, 2> { static constexpr bool PP = true; };
 typedef H2Cfg<2, 4, 3, 2> H2Mid;      // conv3 (M = B*36): 192 x 256 -> 1536 blocks = 6.0 rounds of 256 CUs (256 x 256: 4.5)
 typedef H2Cfg<2, 2, 2, 2> H2Small;    // 128 x 128
 typedef H2Cfg<1, 2, 2, 2> H2Thin;     // dense layers (M = batch): 64 x 128, 2 waves -> 512 / 256 blocks at B = 4096
@@ -224,12 +229,29 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
 
     // staging map: wave w, DMA instruction i fills LDS rows (w*I + i)*8 .. +7 of the operand tile; lane l -> row
     // +(l>>3), physical chunk l&7, which holds logical chunk (l&7) ^ ((row>>1)&7) of that row's 128-byte k-slice
+    // Ping-pong configs (CF::PP) stage the tile in "early" and "late" pieces instead: instructions 0,1 of a wave fill
+    // rows of the FIRST half of every wave tile (A: the first RI/2 16-row blocks of each wave row; B: the first RJ/2 of
+    // each wave column), instructions 2,3 rows of the second half -- the main loop reads the halves in different phases.
+    // (192-row tile: 3 A pieces per wave -- piece 0 early, piece 2 late, piece 1 early for waves 0-3 and late for waves 4-7)
+    auto a_late = [&](int i) -> int { return IA == 4 ? (i >> 1) : (i == 0 ? 0 : i == 2 ? 1 : (wave >= 4 ? 1 : 0)); };
+    auto a_row0 = [&](int i) -> int {
+        if constexpr (!CF::PP) return (wave * IA + i) * 8;
+        else {
+            constexpr int HR = BM / 4, HBLK = HR / 8;            // rows / 8-row blocks in one half of a wave row
+            const int hb = IA == 4 ? 2 * wave + (i & 1) : (i == 1 ? 8 + (wave & 3) : wave);
+            return (hb / HBLK) * (BM / 2) + a_late(i) * HR + (hb % HBLK) * 8;
+        }
+    };
+    auto b_row0 = [&](int i) -> int {
+        if constexpr (!CF::PP) return (wave * IB + i) * 8;
+        else { const int hb = 2 * wave + (i & 1); return (hb >> 2) * (BN / 4) + (i >> 1) * (BN / 8) + (hb & 3) * 8; }
+    };
     long long aidx[IA];      // uint4 index of (row's input pixel at tap (0,0), logical chunk)
     unsigned amask[IA];
     unsigned bidx[IB];
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-        const int row = (wave * IA + i) * 8 + (lane >> 3);
+        const int row = a_row0(i) + (lane >> 3);
         const int lc = (lane & 7) ^ h2_swz(row);
         const long long m = (long long)mt * BM + row;
         aidx[i] = 0; amask[i] = 0;
@@ -246,7 +268,7 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-        const int row = (wave * IB + i) * 8 + (lane >> 3);
+        const int row = b_row0(i) + (lane >> 3);
         const int lc = (lane & 7) ^ h2_swz(row);
         bidx[i] = (unsigned)(nt * BN + row) * (unsigned)wrowq + (unsigned)lc;
     }
@@ -257,20 +279,20 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         const int kt = kt_raw < nk ? kt_raw : nk - 1;        // past the end: re-stage the last tile (branch-free loop body)
         const int slice = kt / g.taps, tap = kt - slice * g.taps;         // tap-inner k order
         const long long toff = ((long long)(tap / 3) * g.Hin + (tap % 3)) * rowq + slice * 8;    // 32 ch = 8 uint4
-        unsigned char* la = smem + (size_t)buf * CF::BUF + wave * IA * 1024;
-        unsigned char* lb = smem + (size_t)buf * CF::BUF + CF::TILEA + wave * IB * 1024;
+        unsigned char* la = smem + (size_t)buf * CF::BUF;
+        unsigned char* lb = smem + (size_t)buf * CF::BUF + CF::TILEA;
 #ifdef H2_EXP_TAP0                        // timing experiment only (wrong results): A staged for tap 0 only = upper bound of tap reuse
         if (tap == 0)
 #endif
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             const uint4* ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + toff) : zsrc;
-            __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la + a_row0(i) * 128), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
             const uint4* gb = Wh + bidx[i] + kt * 8;
-            __builtin_amdgcn_global_load_lds((h2_gptr)gb, (h2_lptr)(lb + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((h2_gptr)gb, (h2_lptr)(lb + b_row0(i) * 128), 16, 0, 0);
         }
     };
 
@@ -286,6 +308,130 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     const int swz = h2_swz(r16);                             // tile bases are multiples of 16 rows
     const int oh1 = ((2 * kg) ^ swz) * 16, oh2 = ((2 * kg + 1) ^ swz) * 16;
 
+    if constexpr (CF::PP) {
+        // ---- 4-phase ping-pong main loop (block 256 x 256, 8 waves = 2 wave rows x 4 wave columns).
+        // A k-tile is processed as four quadrants of the 128 x 64 wave tile, (m0,n0) (m0,n1) (m1,n0) (m1,n1); phase q =
+        //   L section: ds_read the half-fragments the next MFMAs need (8 / 4 / 8 / 4 reads: A m0 | B n1 | A m1 | B n0 of the
+        //              NEXT tile, into the registers quadrant 3 has just released), issue 2 of the 8 LDS-DMA pieces of the
+        //              NEXT k-tile, s_waitcnt vmcnt(4), s_barrier
+        //   M section: lgkmcnt(0), 24 MFMAs, s_barrier.
+        // Wave row 1 runs one barrier behind wave row 0, and every SIMD holds one wave of each row: while one is in its
+        // M section the other is in its L section, so LDS reads, DMA issue and address arithmetic hide under MFMAs.
+        // LDS-DMA ordering (MI355X_MICROARCH.md: a ds_read sees DMA data only after the ISSUING waves' counted vmcnt and
+        // a barrier the reader has passed; with the stagger one barrier more): pieces read in phase q are retired by every
+        // wave's vmcnt in the L section of phase q-1.  Issue order per tile [Be0 Be1][Ae0 Ae1][Bl0 Bl1][Al0 Al1]
+        // (e = first half, l = second half of the wave tiles): each pair is read three phases after its issue (B n0 in
+        // phase 4, A m0 in the next phase 1, B n1 in phase 2, A m1 in phase 3), and at every L section all but the 4
+        // youngest pieces are complete -- exactly the pairs the next phase reads.  A region is restaged four or more
+        // phases after its last ds_read.
+        // 192-row tile (IA = 3): a wave issues 7 pieces per tile, 2 or 1 of them per A phase depending on the wave, and
+        // vmcnt(3) (the stricter of the two per-wave counts) retires what the next phase reads.
+        static_assert((IA == 4 || IA == 3) && IB == 4 && RI % 2 == 0 && RJ == 4, "ping-pong loop: 256 x 256 or 192 x 256 tile, 8 waves");
+        constexpr int HA = RI / 2;                           // 16-row A blocks per half of the wave tile
+        stage(kbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        f16x8 fa1[HA], fa2[HA], fb1[4], fb2[4];
+        {   // B n0 of the first tile (later tiles get it in phase 4 of the tile before)
+            const unsigned char* Bt0 = smem + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                fb1[j] = *reinterpret_cast<const f16x8*>(Bt0 + j * 16 * 128 + oh1);
+                fb2[j] = *reinterpret_cast<const f16x8*>(Bt0 + j * 16 * 128 + oh2);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (wm == 1) __builtin_amdgcn_s_barrier();           // stagger: wave row 1 is one barrier behind
+        // (slice, tap) of the tile being staged, advanced incrementally: no integer division in the loop
+        int ktn = kbeg + 1 < nk ? kbeg + 1 : nk - 1;
+        int slice_n = ktn / g.taps, tap_n = ktn - slice_n * g.taps;
+        for (int kt = kbeg; kt < nk; ++kt) {
+            const int buf = (kt - kbeg) & 1;
+            const int slice = slice_n, tap = tap_n, dy = (tap * 11) >> 5, dx = tap - 3 * dy;            // tap / 3, tap % 3 for tap < 9
+            const int ktc = ktn;
+            const long long toff = ((long long)dy * g.Hin + dx) * rowq + slice * 8;
+            unsigned char* la = smem + (size_t)(buf ^ 1) * CF::BUF;
+            unsigned char* lb = la + CF::TILEA;
+            const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * RI * 16 + r16) * 128;
+            const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+            auto dma_a = [&](int i) {
+                const uint4* ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + toff) : zsrc;
+                __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la + a_row0(i) * 128), 16, 0, 0);
+            };
+            auto dma_b = [&](int i) {
+                __builtin_amdgcn_global_load_lds((h2_gptr)(Wh + bidx[i] + ktc * 8), (h2_lptr)(lb + b_row0(i) * 128), 16, 0, 0);
+            };
+            auto lda = [&](int half) {
+#pragma unroll
+                for (int i = 0; i < HA; ++i) {
+                    fa1[i] = *reinterpret_cast<const f16x8*>(At + (half * HA + i) * 16 * 128 + oh1);
+                    fa2[i] = *reinterpret_cast<const f16x8*>(At + (half * HA + i) * 16 * 128 + oh2);
+                }
+            };
+            auto ldb = [&](int half, const unsigned char* base) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    fb1[half * 2 + j] = *reinterpret_cast<const f16x8*>(base + (half * 2 + j) * 16 * 128 + oh1);
+                    fb2[half * 2 + j] = *reinterpret_cast<const f16x8*>(base + (half * 2 + j) * 16 * 128 + oh2);
+                }
+            };
+            const unsigned char* Btn = smem + (size_t)(buf ^ 1) * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+            auto l_end = [&]() {                             // end of an L section
+#ifndef H2PP_NOWAIT                        // experiment (wrong results): no wait for the DMA pieces
+                if constexpr (IA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto mma = [&](int mh, int nh) {                 // quadrant (m half, n half): 24 MFMAs, then the closing barrier
+#ifdef H2PP_PRIO                          // s_setprio around the cluster measured 2 % SLOWER here (it pays in the 8-phase bf16 template)
+                __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+                for (int i = 0; i < HA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4v& c = acc[mh * HA + i][nh * 2 + j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa2[i], fb1[nh * 2 + j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1[i], fb2[nh * 2 + j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1[i], fb1[nh * 2 + j], c, 0, 0, 0);
+                    }
+#ifdef H2PP_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" ::: "memory");
+#ifndef H2PP_ONEBARRIER                    // experiment: drop the barrier that closes the M section
+                __builtin_amdgcn_s_barrier();
+#endif
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#if defined(H2PP_NODMA)                   // H2PP_* : timing experiments only (tools/build_variant.sh); NODMA gives wrong results
+            lda(0); l_end(); mma(0, 0); ldb(1, Bt); l_end(); mma(0, 1); lda(1); l_end(); mma(1, 0); ldb(0, Btn); l_end(); mma(1, 1);
+#elif defined(H2PP_DMA_FIRST)             // DMA issue before the LDS reads of the L section
+            dma_b(0); dma_b(1); lda(0); l_end(); mma(0, 0);
+            dma_a(0); dma_a(1); ldb(1, Bt); l_end(); mma(0, 1);
+            dma_b(2); dma_b(3); lda(1); l_end(); mma(1, 0);
+            dma_a(2); if (IA == 4) dma_a(3); ldb(0, Btn); l_end(); mma(1, 1);
+#else
+            auto dma_a_early = [&]() { dma_a(0); if (IA == 4 || wave < 4) dma_a(1); };
+            auto dma_a_late = [&]() { dma_a(IA - 1); if (IA == 4) dma_a(2); else if (wave >= 4) dma_a(1); };
+            lda(0); dma_b(0); dma_b(1); l_end(); mma(0, 0);               // phase 1
+            ldb(1, Bt); dma_a_early(); l_end(); mma(0, 1);                // phase 2
+            lda(1); dma_b(2); dma_b(3); l_end(); mma(1, 0);               // phase 3
+            ldb(0, Btn); dma_a_late(); l_end(); mma(1, 1);                // phase 4 (B n0 of the next tile)
+#endif
+            if (ktn + 1 < nk) { ++ktn; if (++tap_n == g.taps) { tap_n = 0; ++slice_n; } }    // past the end: re-stage the last tile
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave rows
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every piece has landed before the epilogue reuses the LDS
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else {
     stage(kbeg, 0);
     __syncthreads();                                         // drains the DMA (vmcnt(0)) and publishes the tile
     for (int kt = kbeg; kt < nk; ++kt) {
@@ -324,6 +470,7 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         __syncthreads();
 #endif
     }
+    }   // !CF::PP
 
     // ---- epilogue.  C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
     if (g.ksplit > 1) {      // raw fp32 partial sums of this k-slice into slab ks; k_splitk_reduce_h2 finishes the layer
