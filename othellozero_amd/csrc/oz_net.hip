@@ -759,6 +759,15 @@ OZ_API int oz_net_profile(oz_net* net, int enable) {
     o->profile = enable != 0;
     return OZ_OK;
 }
+#ifdef H2PP_STAMPS
+OZ_API int oz_debug_h2_stamps(unsigned long long* out48) {
+    OZ_HIP(hipDeviceSynchronize());
+    OZ_HIP(hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_h2_stamps), sizeof(unsigned long long) * 48));
+    OZ_HIP(hipMemcpyFromSymbol(out48 + 48, HIP_SYMBOL(g_h2_clk), sizeof(unsigned long long) * 16));
+    return OZ_OK;
+}
+#endif
+
 OZ_API int oz_net_profile_read(oz_net* net, double* conv2_ms_total, int64_t* conv2_launches) {
     OnnNet* o = as_onn(net);
     OZ_REQUIRE(o, "not an OthelloNN network");

@@ -23,8 +23,11 @@
 // ds_write pass); the LDS image is lane-linear per wave instruction (8 rows of 8 chunks) and made
 // bank-conflict-free by XOR-swizzling the 16-byte chunk index with h2_swz(row) on the SOURCE address and on the
 // read address (SQ_LDS_BANK_CONFLICT measured); A rows are gathered per 3x3 tap, out-of-image taps read a
-// zero line.  Two LDS stages, one barrier per k-tile, the next tile's DMA instructions interleaved with the
-// MFMA stream (sched_group_barrier).  Epilogue = BN scale/shift + ReLU, then fp32 rows or the h2 layout for the
+// zero line.  Two LDS stages.  Main loop of the 3x3 convolutions (H2BigPP / H2MidPP): 4-phase ping-pong -- the two
+// wave rows (one wave of each per SIMD) run one barrier apart, one in its MFMA cluster while the other issues its LDS
+// reads and LDS-DMA pieces, counted vmcnt so that pieces stay in flight across barriers (details at the loop).  The
+// dense layers keep the simple loop: one barrier per k-tile, DMA interleaved with the MFMA stream (sched_group_barrier).
+// Epilogue = BN scale/shift + ReLU, then fp32 rows or the h2 layout for the
 // next layer (transposed through LDS so that global stores are 16-byte chunks of whole rows).
 //
 // What was measured on the way (conv2 size, 4096 leaves; kept here so nobody re-discovers it):
@@ -38,7 +41,16 @@
 //   no DMA in the loop, 2.00 ms with no DMA and no barrier; A staged for 1 tap of 9 only: 2.36 ms.  So the floor of
 //   this structure is LDS reads + MFMA at the power-limited clock (~620 TFLOP/s fp32-equivalent); LDS-DMA issue/wait
 //   costs 16 %, barriers 3 %, and tap reuse for A alone would buy <= 4.5 %.
+//   4-phase ping-pong loop (H2BigPP): conv2 2.41 -> 2.15 ms on the same device (-10 %), bench 842 k -> 915 k expansions/s.
+//     In-kernel stamps (tools/pp_stamps.py, -DH2PP_STAMPS): clock 2.20-2.28 GHz; per interval (one wave row in its 24-MFMA
+//     cluster, the other in its L section) ~531 cycles against 395 of MFMA issue (16.4 cycles per MFMA, measured alone in
+//     tools/ubench/mfma_bank.hip, independent of the operands' VGPR banks); without any DMA 469.  Variants on that loop:
+//     s_setprio around the cluster -2 %; DMA before the reads of an L section +-0; chained vs product-major MFMA order
+//     +-0; accumulators in AGPRs (inline asm) slower; no vmcnt wait at all +-0 (the waits are free); 2 phases per tile
+//     (half the barriers, -DH2PP_2PHASE) +-0 on conv2 and slower on conv3/conv4.  What is left is the issue cost of the 8
+//     LDS-DMA pieces per wave and tile (~13 %) and barrier round trips.
 #pragma once
+#include <type_traits>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -128,6 +140,13 @@ __device__ __forceinline__ void h2_split(float x, _Float16& h1, _Float16& h2) {
 // (the natural (row>>1)&7 key is conflict-free only for the 32x32x16 map: measured 50 % conflict cycles here)
 __device__ __forceinline__ int h2_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) * 6); }
 
+#ifdef H2PP_STAMPS                        // diagnostic build only (tools/pp_stamps.py): cycle budget of the ping-pong loop
+__device__ unsigned long long g_h2_stamps[8][6];
+__device__ unsigned long long g_h2_clk[8][2];
+#define H2_ST(k) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); st_acc[k] += t__ - st_prev; st_prev = t__; } while (0)
+#else
+#define H2_ST(k) do { } while (0)
+#endif
 typedef const __attribute__((address_space(1))) void* h2_gptr;
 typedef __attribute__((address_space(3))) void* h2_lptr;
 
@@ -346,6 +365,10 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         // (slice, tap) of the tile being staged, advanced incrementally: no integer division in the loop
         int ktn = kbeg + 1 < nk ? kbeg + 1 : nk - 1;
         int slice_n = ktn / g.taps, tap_n = ktn - slice_n * g.taps;
+#ifdef H2PP_STAMPS
+        unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+        const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_t0 = st_prev;
+#endif
         for (int kt = kbeg; kt < nk; ++kt) {
             const int buf = (kt - kbeg) & 1;
             const int slice = slice_n, tap = tap_n, dy = (tap * 11) >> 5, dx = tap - 3 * dy;            // tap / 3, tap % 3 for tap < 9
@@ -377,56 +400,75 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                 }
             };
             const unsigned char* Btn = smem + (size_t)(buf ^ 1) * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
-            auto l_end = [&]() {                             // end of an L section
-#ifndef H2PP_NOWAIT                        // experiment (wrong results): no wait for the DMA pieces
-                if constexpr (IA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-#endif
+            // end of an L section: all but the `keep` youngest DMA pieces of this wave have landed, then the barrier
+            auto l_end = [&](auto keep) {
+                H2_ST(0);                                    // L work: address arithmetic, ds_read issue, DMA issue
+                constexpr int K = decltype(keep)::value;
+                if constexpr (K == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else if constexpr (K == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if constexpr (K == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if constexpr (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if constexpr (K == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                H2_ST(1);                                    // DMA wait
                 __builtin_amdgcn_s_barrier();
+                H2_ST(2);                                    // mid barrier
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                H2_ST(3);                                    // LDS read latency left
                 __builtin_amdgcn_sched_barrier(0);
             };
-            auto mma = [&](int mh, int nh) {                 // quadrant (m half, n half): 24 MFMAs, then the closing barrier
-#ifdef H2PP_PRIO                          // s_setprio around the cluster measured 2 % SLOWER here (it pays in the 8-phase bf16 template)
-                __builtin_amdgcn_s_setprio(1);
-#endif
+            // quadrant (m half, n half): 3 * 2 * HA MFMAs, product-major (2 * HA independent accumulators between two
+            // MFMAs of the same one; the chained order measured the same).  s_setprio around the cluster measured 2 % slower.
+            auto mma = [&](int mh, int nh) {
 #pragma unroll
-                for (int i = 0; i < HA; ++i)
+                for (int p = 0; p < 3; ++p)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        f32x4v& c = acc[mh * HA + i][nh * 2 + j];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa2[i], fb1[nh * 2 + j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1[i], fb2[nh * 2 + j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1[i], fb1[nh * 2 + j], c, 0, 0, 0);
-                    }
-#ifdef H2PP_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
+                    for (int i = 0; i < HA; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            f32x4v& c = acc[mh * HA + i][nh * 2 + j];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? fa2[i] : fa1[i], p == 1 ? fb2[nh * 2 + j] : fb1[nh * 2 + j], c, 0, 0, 0);
+                        }
                 __builtin_amdgcn_sched_barrier(0);
+            };
+            auto m_end = [&]() {                             // end of an M section: the closing barrier
                 asm volatile("" ::: "memory");
-#ifndef H2PP_ONEBARRIER                    // experiment: drop the barrier that closes the M section
+                H2_ST(4);                                    // MFMA cluster (issue)
                 __builtin_amdgcn_s_barrier();
-#endif
+                H2_ST(5);                                    // closing barrier
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             };
-#if defined(H2PP_NODMA)                   // H2PP_* : timing experiments only (tools/build_variant.sh); NODMA gives wrong results
-            lda(0); l_end(); mma(0, 0); ldb(1, Bt); l_end(); mma(0, 1); lda(1); l_end(); mma(1, 0); ldb(0, Btn); l_end(); mma(1, 1);
-#elif defined(H2PP_DMA_FIRST)             // DMA issue before the LDS reads of the L section
-            dma_b(0); dma_b(1); lda(0); l_end(); mma(0, 0);
-            dma_a(0); dma_a(1); ldb(1, Bt); l_end(); mma(0, 1);
-            dma_b(2); dma_b(3); lda(1); l_end(); mma(1, 0);
-            dma_a(2); if (IA == 4) dma_a(3); ldb(0, Btn); l_end(); mma(1, 1);
-#else
+            using std::integral_constant;
             auto dma_a_early = [&]() { dma_a(0); if (IA == 4 || wave < 4) dma_a(1); };
             auto dma_a_late = [&]() { dma_a(IA - 1); if (IA == 4) dma_a(2); else if (wave >= 4) dma_a(1); };
-            lda(0); dma_b(0); dma_b(1); l_end(); mma(0, 0);               // phase 1
-            ldb(1, Bt); dma_a_early(); l_end(); mma(0, 1);                // phase 2
-            lda(1); dma_b(2); dma_b(3); l_end(); mma(1, 0);               // phase 3
-            ldb(0, Btn); dma_a_late(); l_end(); mma(1, 1);                // phase 4 (B n0 of the next tile)
+#if defined(H2PP_NODMA)                   // timing experiment only (wrong results): the loop without any DMA
+            lda(0); l_end(integral_constant<int, 4>{}); mma(0, 0); m_end(); ldb(1, Bt); l_end(integral_constant<int, 4>{}); mma(0, 1); m_end();
+            lda(1); l_end(integral_constant<int, 4>{}); mma(1, 0); m_end(); ldb(0, Btn); l_end(integral_constant<int, 4>{}); mma(1, 1); m_end();
+#elif defined(H2PP_2PHASE)
+            // two phases per k-tile (half the barriers): L_A reads A m0, B n1 (B n0 came in L_B of the tile before) and issues
+            // the 6 (5) pieces of the next tile that its L_A / L_B read first; L_B reads A m1 and the next tile's B n0 ...
+            lda(0); ldb(1, Bt); dma_b(0); dma_b(1); dma_a_early(); dma_b(2); dma_b(3);
+            l_end(integral_constant<int, IA == 4 ? 6 : 5>{}); mma(0, 0); mma(0, 1); m_end();
+            lda(1); dma_a_late();
+            l_end(integral_constant<int, IA == 4 ? 2 : 1>{}); mma(1, 0); mma(1, 1); m_end();
+            ldb(0, Btn);                                     // after M_B: quadrant (m1, n0) is done; retired by the vmcnt of L_B
+#else
+            constexpr int KEEP = IA == 4 ? 4 : 3;
+            lda(0); dma_b(0); dma_b(1); l_end(integral_constant<int, KEEP>{}); mma(0, 0); m_end();               // phase 1
+            ldb(1, Bt); dma_a_early(); l_end(integral_constant<int, KEEP>{}); mma(0, 1); m_end();                // phase 2
+            lda(1); dma_b(2); dma_b(3); l_end(integral_constant<int, KEEP>{}); mma(1, 0); m_end();               // phase 3
+            ldb(0, Btn); dma_a_late(); l_end(integral_constant<int, KEEP>{}); mma(1, 1); m_end();                // phase 4 (B n0 of the next tile)
 #endif
             if (ktn + 1 < nk) { ++ktn; if (++tap_n == g.taps) { tap_n = 0; ++slice_n; } }    // past the end: re-stage the last tile
         }
+#ifdef H2PP_STAMPS
+        if (blockIdx.x == 0 && lane == 0) {
+            for (int q = 0; q < 6; ++q) g_h2_stamps[wave][q] = st_acc[q];
+            g_h2_clk[wave][0] = __builtin_amdgcn_s_memtime() - st_t0;
+            g_h2_clk[wave][1] = __builtin_amdgcn_s_memrealtime() - st_rt0;      // 100 MHz ticks
+        }
+#endif
         if (wm == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave rows
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every piece has landed before the epilogue reuses the LDS
         __builtin_amdgcn_s_barrier();
