@@ -640,3 +640,16 @@ def test_basenn_network_vs_float64_oracle(oz, precision, channels):
     p1, v1 = net.predict(brd[:, :, 0].astype(np.int64) - brd[:, :, 1].astype(np.int64))       # one-channel input
     assert np.array_equal(p1, pi[2]) and v1 == v[2]
     assert net.get_weights()[0].shape == (3, 3, 1, channels)
+
+
+@pytest.mark.gpu
+def test_pingpong_conv_loop_bit_identical_to_simple_loop():
+    """the 4-phase ping-pong main loop (default) and the one-barrier-per-k-tile loop (OZ_H2_PP=0) accumulate every
+    output in the same order: (pi, v) must be bit-identical over batch sizes / boards / repetitions -- a LDS-DMA
+    visibility race in the ping-pong schedule would show up as a mismatch (tools/pp_race_check.py)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pp_race_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 differ" in r.stdout
