@@ -647,6 +647,7 @@ def test_pingpong_conv_loop_bit_identical_to_simple_loop():
     """the 4-phase ping-pong main loop (default) and the one-barrier-per-k-tile loop (OZ_H2_PP=0) accumulate every
     output in the same order: (pi, v) must be bit-identical over batch sizes / boards / repetitions -- a LDS-DMA
     visibility race in the ping-pong schedule would show up as a mismatch (tools/pp_race_check.py)"""
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
