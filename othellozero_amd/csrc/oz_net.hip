@@ -448,7 +448,11 @@ struct OnnNet : oz_net {
         if (int rc = pp ? launch_gemm_h2<H2BigPP>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)
                         : launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
         // fc1: K = 8192 but only batch x 1024 outputs -> 4-way split-K (fixed-order reduce) to fill the chip
-        if (int rc = launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
+        // (large batches: on the 256 x 256 ping-pong tile, 16 x 4 tiles x 4 k-slices = one block per CU; bit-identical to
+        //  the 128 x 128 tile because the k-slices and the order inside them are the same -- tools/pp_race_check.py)
+        static const bool fc1pp = !(getenv("OZ_H2_FC1PP") && atoi(getenv("OZ_H2_FC1PP")) == 0);
+        if (int rc = (fc1pp && pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
+                                                        : launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
         if (int rc = launch_gemm_h2<H2Thin>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
         hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
         OZ_HIP(hipGetLastError());

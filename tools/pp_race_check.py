@@ -25,11 +25,10 @@ for n, C, B, reps in ((8, 512, 4096, 12), (8, 512, 1000, 8), (8, 256, 257, 8), (
 np.savez(sys.argv[2], **out)
 '''
 res = []
-for pp in ("0", "1"):
-    path = f"/tmp/pp_race_{pp}.npz"
-    env = dict(os.environ, OZ_H2_PP=pp)
-    subprocess.run([sys.executable, "-c", WORKER, ROOT, path], env=env, check=True, timeout=600)
+for tag, extra in (("simple", {"OZ_H2_PP": "0"}), ("pingpong", {"OZ_H2_PP": "1"}), ("pingpong_fc1small", {"OZ_H2_PP": "1", "OZ_H2_FC1PP": "0"})):
+    path = f"/tmp/pp_race_{tag}.npz"
+    subprocess.run([sys.executable, "-c", WORKER, ROOT, path], env=dict(os.environ, **extra), check=True, timeout=600)
     res.append(np.load(path))
-bad = [k for k in res[0].files if not np.array_equal(res[0][k], res[1][k])]
-print(f"{len(res[0].files)} arrays compared, {len(bad)} differ", bad[:5])
+bad = [k for k in res[0].files if not (np.array_equal(res[0][k], res[1][k]) and np.array_equal(res[0][k], res[2][k]))]
+print(f"{len(res[0].files)} arrays x 3 loop configurations compared, {len(bad)} differ", bad[:5])
 sys.exit(1 if bad else 0)
