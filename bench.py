@@ -201,6 +201,9 @@ def main():
             "nn_forward_ms_total_rank0": nn_ms, "nn_fraction_of_wall_rank0": nn_ms * 1e-3 / dt,
             "whole_net_tflops_rank0": d["expansions"] * FLOP_PER_EXPANSION.get(n, 0) / max(nn_ms * 1e-3, 1e-9) / 1e12,
             "roofline": roofline(args.precision, achieved, conv2_ms, conv2_launches, d["expansions"], n, args.channels),
+            # the tree / rules side is latency-bound integer work, ~1.3 KB of algorithmic HBM bytes per simulation
+            "tree_side_hbm": {"bytes_per_sim": 1300, "achieved_GBps": sims_all / dt * 1300 / 1e9, "peak_GBps": 8000.0,
+                              "frac": sims_all / dt * 1300 / 8e12, "note": "not the binding roof; reported per SURVEY 8(d)"},
         }
         out["dtype"] = "f32" if args.precision == "f32" else "f32 as 2xfp16 split (3 fp16 MFMA products per fp32 product, f32 accumulate)"
         if world == 1 and not args.no_cpu_baseline:
