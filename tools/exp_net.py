@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from othellozero_amd.NNet import NNetWrapper
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x2"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-B = 4096
+B = int(os.environ.get("EXP_B", "4096"))
 net = NNetWrapper((8, 8), num_channels_1=512, max_batch=B, seed=0, precision=prec)
 net.time_forward(B, 2)
 net.profile(True)
