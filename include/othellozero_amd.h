@@ -180,7 +180,9 @@ int oz_selfplay_eval_time(oz_selfplay* sp, double* ms_total, int64_t* launches, 
 
 /* ------------------------------------------------------------------ arena
  * duel_between_agents with two NeuralNetworkOthelloAgent (agents.py:44-84): net_a = BLACK, net_b = WHITE,
- * one OthelloMCTS per agent per game, temperature 0, ties broken by the RNG_TIE stream. */
+ * one OthelloMCTS per agent per game, temperature 0, ties broken by the RNG_TIE stream.
+ * One of net_a / net_b may be NULL: that colour is played by RandomOthelloAgent (agents.py:20-24; the evaluation games of
+ * main.py:163-233), its random.choice drawn from the RNG_TIE stream at that ply. */
 typedef struct oz_arena oz_arena;
 int oz_arena_create(oz_arena** out, int n, int num_games, int sims, double c, int q_mode, uint64_t seed,
                     uint64_t first_game_id, oz_net* net_a, oz_net* net_b, int node_cap, int edge_cap);

@@ -234,8 +234,9 @@ class Mcts:
 
 
 def arena(ma, mb, sims, seed, game_id):
+    """ma / mb = Mcts of the BLACK / WHITE agent; None = RandomOthelloAgent on that colour"""
     out = ArenaOut()
-    rc = lib().orc_arena(ma.h, mb.h, sims, seed, game_id, C.byref(out))
+    rc = lib().orc_arena(ma.h if ma is not None else None, mb.h if mb is not None else None, sims, seed, game_id, C.byref(out))
     if rc < 0:
         raise KeyError("orc_arena: KeyError path")
     k = out.n_moves

@@ -578,15 +578,25 @@ typedef struct {
 } orc_arena_out;
 
 /* duel_between_agents with two NeuralNetworkOthelloAgent, agents.py:44-84.
- * ma plays BLACK, mb plays WHITE; temperature forced to 0 (agents.py:46). */
+ * ma plays BLACK, mb plays WHITE; temperature forced to 0 (agents.py:46).
+ * Either may be NULL: that colour is played by RandomOthelloAgent (agents.py:20-24; main.py:163-233 evaluation games). */
 ORC_API int orc_arena(omcts* ma, omcts* mb, int sims, uint64_t seed, uint64_t game_id, orc_arena_out* out) {
-    const int n = ma->n;
+    const int n = ma ? ma->n : mb->n;            /* a NULL search = RandomOthelloAgent on that colour */
     ogame g; game_init(&g, n);
     memset(out, 0, sizeof *out);
     int ply = 0;
     while (!g.finished) {
         omcts* m = g.player == 1 ? ma : mb;
         uint64_t bl, wh; pack(&g.b, &bl, &wh);
+        if (!m) {   /* RandomOthelloAgent.play, agents.py:20-24: random.choice over the valid actions (ascending row-major) */
+            uint8_t acts[64];
+            int na = valid_actions(&g.b, n, g.player == 1 ? 0 : 1, acts);        /* ascending row-major, Othello:208-214 */
+            int sq = acts[orc_rng(seed, game_id, (uint64_t)ply, RNG_TIE) % (uint64_t)na];
+            out->action[ply] = (uint8_t)sq; out->player[ply] = (int8_t)g.player;
+            game_play(&g, sq >> 3, sq & 7);
+            ++ply;
+            continue;
+        }
         for (int s = 0; s < sims; ++s) orc_mcts_simulate(m, bl, wh, g.player, NULL);
         uint64_t k0 = g.player == 1 ? bl : wh, k1 = g.player == 1 ? wh : bl;
         int counts[64]; uint64_t legal;

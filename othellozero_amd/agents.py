@@ -67,11 +67,13 @@ def duel_between_agents(game, agent_1, agent_2):
 def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, degree_exploration=1.0, seed=0,
                 first_game_id=0, q_mode=_lib.QMODE_F64, node_cap=0, edge_cap=0):
     """num_games games of net_a (BLACK) vs net_b (WHITE), temperature 0, max-visit ties broken by the RNG_TIE
-    stream keyed (seed, game id, ply).  Returns dict(winner (+1 = net_a), points, n_moves, actions, players, final)."""
+    stream keyed (seed, game id, ply).  One of the two may be None: RandomOthelloAgent plays that colour.
+    Returns dict(winner (+1 = BLACK's agent), points, n_moves, actions, players, final)."""
     lib = _lib.require_gpu()
     h = C.c_void_p()
     _lib.check(lib.oz_arena_create(C.byref(h), board_size, num_games, num_simulations, float(degree_exploration), q_mode,
-                                   seed, first_game_id, net_a._h, net_b._h, node_cap, edge_cap))
+                                   seed, first_game_id, net_a._h if net_a is not None else None,
+                                   net_b._h if net_b is not None else None, node_cap, edge_cap))
     try:
         _lib.check(lib.oz_arena_run(h))
         G = num_games

@@ -737,6 +737,27 @@ __global__ __launch_bounds__(64) void k_sp_move(GamesDev gm, MctsDev t, int aren
     }
 }
 
+// RandomOthelloAgent.play (agents.py:20-24) for every live game whose mover is `side`: random.choice over the valid
+// actions in ascending row-major order -> the RNG_TIE stream (the fixture generator patches random.choice to it)
+__global__ void k_arena_random_move(GamesDev gm, int side) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= gm.G || gm.finished[g] || gm.player[g] != side) return;
+    uint64_t black = gm.black[g], white = gm.white[g];
+    int player = side, fin = 0;
+    const uint64_t legal = oz_legal(side == 1 ? black : white, side == 1 ? white : black, gm.valid);
+    const int ply = gm.ply[g];
+    const int action = oz_kth_bit(legal, (int)(oz_rng(gm.seed, gm.game_id[g], (uint64_t)ply, OZ_RNG_TIE) % (uint64_t)oz_popc(legal)));
+    const size_t lb = (size_t)g * 64;
+    if (ply < 64) {
+        gm.log_black[lb + ply] = black; gm.log_white[lb + ply] = white;
+        gm.log_action[lb + ply] = (uint8_t)action; gm.log_player[lb + ply] = (int8_t)player; gm.log_greedy[lb + ply] = 0;
+    }
+    oz_game_play(black, white, player, fin, action, gm.valid);
+    gm.black[g] = black; gm.white[g] = white; gm.player[g] = (int8_t)player;
+    gm.finished[g] = (uint8_t)fin; gm.ply[g] = ply + 1;
+    atomicAdd(&gm.counters[2], 1ULL);
+}
+
 static void initial_board(int n, uint64_t* black, uint64_t* white) {     // Othello/__init__.py:177-184
     const int h = n / 2;
     *white = (1ULL << ((h - 1) * 8 + h - 1)) | (1ULL << (h * 8 + h));
@@ -972,10 +993,10 @@ __global__ void k_arena_collect(GamesDev gm, uint8_t* actions, int8_t* players, 
 
 OZ_API int oz_arena_create(oz_arena** out, int n, int num_games, int sims, double c, int q_mode, uint64_t seed,
                            uint64_t first_game_id, oz_net* net_a, oz_net* net_b, int node_cap, int edge_cap) {
-    OZ_REQUIRE(out && net_a && net_b, "null argument");
+    OZ_REQUIRE(out && (net_a || net_b), "null argument (at most one of the two networks may be NULL = RandomOthelloAgent)");
     OZ_REQUIRE(sims >= 2, "num_simulations must be >= 2");
-    OZ_REQUIRE(net_a->n == n && net_b->n == n, "network board size mismatch");
-    OZ_REQUIRE(net_a->max_batch >= num_games && net_b->max_batch >= num_games, "network max_batch < num_games");
+    OZ_REQUIRE((!net_a || net_a->n == n) && (!net_b || net_b->n == n), "network board size mismatch");
+    OZ_REQUIRE((!net_a || net_a->max_batch >= num_games) && (!net_b || net_b->max_batch >= num_games), "network max_batch < num_games");
     oz_arena* a = new oz_arena();
     a->na = net_a; a->nb = net_b; a->sims = sims;
     const int max_plies = n * n - 4;
@@ -1036,19 +1057,23 @@ OZ_API int oz_arena_run(oz_arena* a) {
     std::vector<uint8_t> fin(G);
     for (int round = 0; round < max_rounds && !rc; ++round) {
         // BLACK movers search in agent A's tables with net A, WHITE movers in agent B's with net B
-        hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, ma->d, 1);
-        hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, mb->d, -1);
-        {
+        // a NULL network = RandomOthelloAgent on that colour: it moves first in the round (a game may then play two plies
+        // in one round, which changes nothing: games are independent and every ply is keyed by (game id, ply))
+        if (!a->na) hipLaunchKernelGGL(k_arena_random_move, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, 1);
+        if (!a->nb) hipLaunchKernelGGL(k_arena_random_move, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, -1);
+        if (a->na) hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, ma->d, 1);
+        if (a->nb) hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, mb->d, -1);
+        if (a->na) {
             std::lock_guard<std::mutex> la(a->na->mu);
             for (int i = 0; i < a->sims && !rc; ++i) rc = mcts_step_async(ma, a->na, false);
         }
-        if (!rc) {
+        if (!rc && a->nb) {
             std::lock_guard<std::mutex> lb(a->nb->mu);
             for (int i = 0; i < a->sims && !rc; ++i) rc = mcts_step_async(mb, a->nb, false);
         }
         if (rc) break;
-        hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, ma->d, 1);
-        hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, mb->d, 1);
+        if (a->na) hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, ma->d, 1);
+        if (a->nb) hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, mb->d, 1);
         if (hipGetLastError() != hipSuccess) { oz_set_error("arena kernel launch failed"); rc = OZ_ERR_HIP; break; }
         if ((round & 3) == 3 || round + 1 == max_rounds) {
             if ((rc = check_error_flag(ma))) break;

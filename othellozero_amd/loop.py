@@ -106,6 +106,25 @@ def evaluate_against_random(board_size, neural_network, games, num_simulations, 
     return r
 
 
+def evaluate_against_random_batch(board_size, neural_network, games, num_simulations, degree_exploration, seed=0):
+    """The same evaluation as `evaluate_against_random` played in lock step on the GPU (agents.arena_batch with a random
+    mover): the network takes BLACK in the first games // 2 + games % 2 games and WHITE in the rest (the reference draws the
+    colours with random.shuffle; the split here is fixed).  -> dict(wins, black_wins, black_games, white_wins, white_games)"""
+    as_black, as_white = games // 2 + games % 2, games // 2
+    r = dict(wins=0, black_wins=0, black_games=0, white_wins=0, white_games=0)
+    if as_black:
+        res = arena_batch(neural_network, None, board_size, as_black, num_simulations, degree_exploration, seed=seed)
+        r["black_wins"] = int((res["winner"] == 1).sum())
+    if as_white:
+        res = arena_batch(None, neural_network, board_size, as_white, num_simulations, degree_exploration, seed=seed, first_game_id=as_black)
+        r["white_wins"] = int((res["winner"] == -1).sum())
+        r["black_games"] = as_white - r["white_wins"]              # games BLACK (the random agent) won
+    r["white_games"] = r["white_wins"] + (as_black - r["black_wins"])
+    r["black_games"] += r["black_wins"]
+    r["wins"] = r["black_wins"] + r["white_wins"]
+    return r
+
+
 def self_play_match(board_size, neural_network, old_neural_network, total_games, num_simulations, degree_exploration, seed=0):
     """main.py:110-134: total_games // 2 games with the new network as BLACK, the rest with it as WHITE.
     -> number of games the new network won (a drawn game goes to BLACK, like get_winning_player)."""
@@ -125,8 +144,11 @@ def training(board_size, num_iterations, num_episodes, num_simulations, degree_e
              e_greedy, evaluation_interval, evaluation_iterations, temperature_threshold, self_play_training,
              self_play_interval, self_play_total_games, self_play_threshold, checkpoint_filepath, training_buffer_size,
              seed=1234, reference_aliasing=True, alias_final_boards=True, dump_examples=False, q_mode=_lib.QMODE_F64,
-             distributed=False):
+             distributed=False, batched_evaluation=False):
     """main.py:56-259 on the GPU engines; returns `historic` = [(episodes done, win rate vs random), ...]
+
+    batched_evaluation=True plays the evaluation games against RandomOthelloAgent in lock step on the GPU
+    (evaluate_against_random_batch) instead of one by one through the drop-in agents.
 
     distributed=True (torch.distributed initialised, one process per GPU): the episodes of an iteration are sharded over
     the ranks by global game id and pooled with one all-gather of move records, every rank then holds the same replay
@@ -205,11 +227,17 @@ def training(board_size, num_iterations, num_episodes, num_simulations, degree_e
 
         if i % evaluation_interval == 0:
             logging.info('New Neural Network evaluation!')
-            new = evaluate_against_random(board_size, neural_network, evaluation_iterations, num_simulations, degree_exploration,
-                                          label=f'Total Episodes Runned: {total_episodes_done} - Network')
-            logging.info('Old Neural Network evaluation!')
-            old = evaluate_against_random(board_size, old_neural_network, evaluation_iterations, num_simulations, degree_exploration,
-                                          label=f'Total Episodes Runned: {total_episodes_done} - Old Network')
+            if batched_evaluation:
+                new = evaluate_against_random_batch(board_size, neural_network, evaluation_iterations, num_simulations,
+                                                    degree_exploration, seed=seed + 7919 * i)
+                old = evaluate_against_random_batch(board_size, old_neural_network, evaluation_iterations, num_simulations,
+                                                    degree_exploration, seed=seed + 7919 * i + 1)
+            else:
+                new = evaluate_against_random(board_size, neural_network, evaluation_iterations, num_simulations, degree_exploration,
+                                              label=f'Total Episodes Runned: {total_episodes_done} - Network')
+                logging.info('Old Neural Network evaluation!')
+                old = evaluate_against_random(board_size, old_neural_network, evaluation_iterations, num_simulations, degree_exploration,
+                                              label=f'Total Episodes Runned: {total_episodes_done} - Old Network')
             if new["wins"] > (old["wins"] * 1.1):
                 logging.info("Saving new network!")
                 historic.append((total_episodes_done, (new["wins"] / evaluation_iterations)))

@@ -503,6 +503,43 @@ def arena_fixture():
 
 
 
+def arena_random_fixture():
+    """NeuralNetworkOthelloAgent vs RandomOthelloAgent (agents.py:20-24), both colour assignments: what main.py's
+    evaluation rounds play (main.py:163-233).  random.choice is the patched TIE stream for both agents (distinct plies)."""
+    specs = [
+        # name, n, sims, c, seed, game, salt of the network, network colour (+1 BLACK / -1 WHITE), regime
+        ("rnd8_nn_black", 8, 30, 1, 77, 0, 301, 1, "nep50"),
+        ("rnd8_nn_white", 8, 30, 1, 77, 1, 302, -1, "nep50"),
+        ("rnd6_nn_black_f64", 6, 60, 1, 77, 2, 303, 1, "f64"),
+        ("rnd6_nn_white", 6, 25, 1, 77, 3, 304, -1, "nep50"),
+    ]
+    out, names = {}, []
+    saved = patched_rng()
+    try:
+        for name, n, sims, c, seed, game, salt, colour, regime in specs:
+            Ctx.seed, Ctx.game, Ctx.ply, Ctx.counts = seed, game, 0, []
+            CountingGame.log = []
+            g = CountingGame(n)
+            nn_agent = agents.NeuralNetworkOthelloAgent(g, StubNet(n, salt, 0, regime), sims, c)
+            rnd_agent = agents.RandomOthelloAgent(g)
+            pair = (nn_agent, rnd_agent) if colour == 1 else (rnd_agent, nn_agent)
+            winner, points = agents.duel_between_agents(g, *pair)
+            log = CountingGame.log
+            out[f"{name}/meta"] = np.array([n, sims, seed, game, salt, colour, 0 if regime == "nep50" else 1, len(log)], dtype=np.int64)
+            out[f"{name}/c"] = np.array([float(c)])
+            out[f"{name}/player"] = np.array([x[2] for x in log], dtype=np.int8)
+            out[f"{name}/action"] = np.array([x[3] for x in log], dtype=np.uint8)
+            fb, fw = pack(g.board(BoardView.TWO_CHANNELS))
+            out[f"{name}/final"] = np.array([fb, fw], dtype=np.uint64)
+            out[f"{name}/result"] = np.array([1 if winner is pair[0] else -1, points, 1 if winner is nn_agent else 0], dtype=np.int32)
+            names.append(name)
+            print("arena_random", name, "moves", len(log), "black wins" if winner is pair[0] else "white wins", points)
+    finally:
+        restore_rng(saved)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "arena_random.npz"), **out)
+
+
 # ---------------------------------------------------------------- BaseNN (one-channel view) episode
 class StubNetBNN(StubNet):
     """same integer-hash net, reached through the one-channel board view (othelo_mcts.py:17-18,85-86)"""
@@ -551,6 +588,6 @@ def bnn_fixture():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rules", "pairwise", "symmetries", "mcts", "episodes", "arena", "bnn"]
+    which = sys.argv[1:] or ["rules", "pairwise", "symmetries", "mcts", "episodes", "arena", "bnn", "arena_random"]
     for w in which:
         globals()[w + "_fixture"]()

@@ -385,6 +385,38 @@ def test_arena_vs_golden_and_oracle(oz, golden_arena):
         assert (int(r["winner"][gi]), int(r["points"][gi])) == (o["winner"], o["points"]), gi
 
 
+def test_arena_against_random_agent_vs_golden_and_oracle(oz):
+    """batched arena with RandomOthelloAgent on one colour (oz_arena_create with a NULL network) == the reference's traces
+    (arena_random.npz) and == the oracle on 24 concurrent games per colour; the loop-level evaluation helper on top"""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.agents import arena_batch
+    from othellozero_amd.loop import evaluate_against_random_batch
+    g = load_golden("arena_random.npz")
+    for name in g["names"]:
+        name = str(name)
+        n, sims, seed, game, salt, colour, qmode, k = (int(x) for x in g[f"{name}/meta"])
+        net = StubNetWrapper((n, n), salt, 0, max_batch=1)
+        r = arena_batch(net if colour == 1 else None, None if colour == 1 else net, n, 1, sims, float(g[f"{name}/c"][0]),
+                        seed=seed, first_game_id=game, q_mode=qmode)
+        assert int(r["n_moves"][0]) == k, name
+        assert np.array_equal(r["actions"][0][:k], g[f"{name}/action"]) and np.array_equal(r["players"][0][:k], g[f"{name}/player"]), name
+        assert (int(r["final_black"][0]), int(r["final_white"][0])) == tuple(int(x) for x in g[f"{name}/final"]), name
+        assert (int(r["winner"][0]), int(r["points"][0])) == tuple(int(x) for x in g[f"{name}/result"][:2]), name
+    G, n, sims = 24, 6, 40
+    net = StubNetWrapper((n, n), 51, 0, max_batch=G)
+    for colour in (1, -1):
+        r = arena_batch(net if colour == 1 else None, None if colour == 1 else net, n, G, sims, 1.0, seed=9, first_game_id=700, q_mode=1)
+        for gi in range(G):
+            m = oracle.Mcts(n, 1.0, 1, salt=51)
+            o = oracle.arena(m if colour == 1 else None, None if colour == 1 else m, sims, 9, 700 + gi)
+            k = o["n_moves"]
+            assert int(r["n_moves"][gi]) == k and np.array_equal(r["actions"][gi][:k], o["action"]), (colour, gi)
+            assert (int(r["winner"][gi]), int(r["points"][gi])) == (o["winner"], o["points"]), (colour, gi)
+    ev = evaluate_against_random_batch(n, net, 11, sims, 1.0, seed=3)
+    assert ev["black_games"] + ev["white_games"] == 11 and ev["wins"] == ev["black_wins"] + ev["white_wins"] <= 11
+    assert ev["black_wins"] <= 6 and ev["white_wins"] <= 5
+
+
 def test_agents_dropin_duel(oz, golden_arena, monkeypatch):
     """duel_between_agents with two NeuralNetworkOthelloAgent (host-side nets) == the reference's trace"""
     from othellozero_amd.Othello import OthelloGame

@@ -73,7 +73,7 @@ def test_training_loop_end_to_end(tmp_path, monkeypatch):
     historic = training(board_size=n, num_iterations=2, num_episodes=8, num_simulations=8, degree_exploration=1, temperature=1,
                         neural_network=net, e_greedy=0.9, evaluation_interval=1, evaluation_iterations=2, temperature_threshold=2,
                         self_play_training=True, self_play_interval=1, self_play_total_games=3, self_play_threshold=2,
-                        checkpoint_filepath=ckpt, training_buffer_size=8 * 40, seed=11)
+                        checkpoint_filepath=ckpt, training_buffer_size=8 * 40, seed=11, batched_evaluation=True)
     assert len(historic) == 2 and all(0 <= rate <= 1 for _, rate in historic) and [e for e, _ in historic] == [8, 16]
     assert os.path.exists(ckpt) and len(keras_h5.flat_weights(keras_h5.load_keras_weights(ckpt))) == 40
     assert os.path.exists(tmp_path / f"historic-last-training-session-{n}.txt")

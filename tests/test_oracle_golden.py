@@ -196,6 +196,21 @@ def test_arena(golden_arena):
         assert (r["winner"], r["points"]) == tuple(int(x) for x in g[f"{name}/result"]), name
 
 
+def test_arena_against_random_agent():
+    """NeuralNetworkOthelloAgent vs RandomOthelloAgent (the evaluation games of main.py:163-233), both colours:
+    the oracle's random mover reproduces the reference's traces (fixture arena_random.npz)"""
+    g = load_golden("arena_random.npz")
+    for name in g["names"]:
+        name = str(name)
+        n, sims, seed, game, salt, colour, qmode, k = (int(x) for x in g[f"{name}/meta"])
+        m = oracle.Mcts(n, float(g[f"{name}/c"][0]), qmode, salt=salt)
+        r = oracle.arena(m if colour == 1 else None, None if colour == 1 else m, sims, seed, game)
+        assert r["n_moves"] == k, name
+        assert np.array_equal(r["action"], g[f"{name}/action"]) and np.array_equal(r["player"], g[f"{name}/player"]), name
+        assert (r["final_black"], r["final_white"]) == tuple(int(x) for x in g[f"{name}/final"]), name
+        assert (r["winner"], r["points"]) == tuple(int(x) for x in g[f"{name}/result"][:2]), name
+
+
 def test_stub_net_python_callback_equals_builtin():
     """the evaluator-callback plumbing gives the same search as the builtin stub"""
     def ev(own, opp, n):
