@@ -77,35 +77,34 @@ class OthelloGame:
     ALL_DIRECTIONS = np.array([(1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1)])
 
     def __init__(self, board_size=8, initial_board=None, current_player=OthelloPlayer.BLACK):
-        assert board_size % 2 == 0, 'Board size must be even'
-        assert initial_board is None or initial_board.shape == (board_size, board_size, 2), \
-            f'Expecting initial board shape ({board_size}, {board_size}, 2)'
+        # same checks and messages as Othello/__init__.py:105-108; the game keeps the caller's array (no copy, R11)
+        if board_size % 2:
+            raise AssertionError('Board size must be even')
+        if initial_board is not None and initial_board.shape != (board_size, board_size, 2):
+            raise AssertionError(f'Expecting initial board shape ({board_size}, {board_size}, 2)')
         assert board_size in (4, 6, 8), 'the HIP rule kernels cover board sizes 4, 6 and 8'
-        self._board = initial_board if initial_board is not None else self.initial_board(board_size)
-        self._board_size = board_size
-        self._round = 1
-        self.current_player = current_player
-        self._one_channel_board_last_update = None
-        self._one_channel_board = None
-        self._has_finished = OthelloGame.has_board_finished(self._board) if initial_board is not None else False
+        given = initial_board is not None
+        self._board = initial_board if given else OthelloGame.initial_board(board_size)
+        self._n, self._round, self.current_player = board_size, 1, current_player
+        self._flat_view = (None, None)              # (round it was built in, one-channel array)
+        self._has_finished = given and OthelloGame.has_board_finished(self._board)
 
     @property
     def board_size(self):
-        return self._board_size
+        return self._n
 
     @property
     def round(self):
         return self._round
 
     def board(self, view=BoardView.ONE_CHANNEL):
-        if view == BoardView.TWO_CHANNELS:
+        if view is BoardView.TWO_CHANNELS:
             return self._board                      # the live array, no copy (R11)
-        elif view == BoardView.ONE_CHANNEL:
-            if self._one_channel_board_last_update != self.round:
-                self._one_channel_board = OthelloGame.convert_to_one_channel_board(self._board)
-                self._one_channel_board_last_update = self.round
-            return self._one_channel_board
-        raise TypeError('Expecting BoardView type')
+        if view is not BoardView.ONE_CHANNEL:
+            raise TypeError('Expecting BoardView type')
+        if self._flat_view[0] != self._round:       # rebuilt once per round, a fresh array each time (Othello:127-133)
+            self._flat_view = (self._round, OthelloGame.convert_to_one_channel_board(self._board))
+        return self._flat_view[1]
 
     def is_valid_action(self, row, col):
         return OthelloGame.is_valid_player_action(self._board, self.current_player, row, col)
@@ -121,7 +120,7 @@ class OthelloGame:
 
     def play(self, row, col):
         assert not self._has_finished, 'Game has ended'
-        n = self._board_size
+        n = self._n
         black, white = _lib.pack_board(self._board)
         b2, w2, p2, f2 = rules_play([black], [white], [self.current_player.value], [int(row) * 8 + int(col)], n)
         self._board[...] = _lib.unpack_board(int(b2[0]), int(w2[0]), n)          # in place, like flip_board_squares
@@ -138,18 +137,21 @@ class OthelloGame:
     # ---- static board functions (Othello/__init__.py:177-274)
     @staticmethod
     def initial_board(board_size):
-        assert board_size % 2 == 0, 'Board size must be even'
-        initial = np.array([[[0, 1], [1, 0]], [[1, 0], [0, 1]]], dtype=bool)
-        pad = (board_size - 2) // 2
-        return np.pad(initial, ((pad, pad), (pad, pad), (0, 0)), constant_values=0)
+        if board_size % 2:
+            raise AssertionError('Board size must be even')
+        b = np.zeros((board_size, board_size, 2), dtype=bool)
+        lo, hi = board_size // 2 - 1, board_size // 2
+        b[lo, hi, 0] = b[hi, lo, 0] = True          # BLACK on the anti-diagonal of the centre (Othello:177-184)
+        b[lo, lo, 1] = b[hi, hi, 1] = True          # WHITE on the diagonal
+        return b
 
     @staticmethod
     def get_board_free_squares(board):
-        return np.argwhere(np.amax(board, axis=2) == 0)
+        return np.argwhere(~np.asarray(board, dtype=bool).any(axis=2))
 
     @staticmethod
     def is_board_square_free(board, row, col):
-        return np.amax(board[row, col]) == 0
+        return np.asarray(board[row, col]).max() == 0
 
     @staticmethod
     def _legal_mask(board, player):
@@ -192,7 +194,9 @@ class OthelloGame:
 
     @staticmethod
     def get_board_winning_player(board):
-        return max(OthelloGame.get_board_players_points(board).items(), key=lambda item: item[1])
+        pts = OthelloGame.get_board_players_points(board)          # a draw goes to BLACK (first maximum, Othello:258-260)
+        black, white = pts[OthelloPlayer.BLACK], pts[OthelloPlayer.WHITE]
+        return (OthelloPlayer.BLACK, black) if black >= white else (OthelloPlayer.WHITE, white)
 
     @staticmethod
     def get_board_players_points(board):
@@ -206,10 +210,9 @@ class OthelloGame:
 
     @staticmethod
     def convert_to_one_channel_board(board):
-        one_channel = board[:, :, 0] * OthelloPlayer.BLACK.value
-        one_channel = one_channel + board[:, :, 1] * OthelloPlayer.WHITE.value
-        return one_channel
+        b = np.asarray(board)
+        return b[:, :, 0].astype(np.int64) - b[:, :, 1].astype(np.int64)    # +1 BLACK, -1 WHITE, 0 empty (Othello:266-270)
 
     @staticmethod
     def invert_board(board):
-        return np.flip(board, axis=2)
+        return np.asarray(board)[:, :, ::-1]          # a view with the two channels swapped, like np.flip(board, axis=2)

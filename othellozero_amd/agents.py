@@ -17,6 +17,8 @@ from .othelo_mcts import OthelloMCTS
 
 
 class OthelloAgent:
+    """agents.py:9-17: an agent is bound to ONE game object and moves on it when asked"""
+
     def __init__(self, game):
         self.game = game
 
@@ -25,43 +27,50 @@ class OthelloAgent:
 
 
 class RandomOthelloAgent(OthelloAgent):
-    def play(self):                                   # agents.py:20-24
-        possible_moves = tuple(self.game.get_valid_actions())
-        move = random.choice(possible_moves)
-        self.game.play(*move)
+    def play(self):
+        """agents.py:20-24: one `random.choice` over the valid actions in row-major order"""
+        moves = tuple(self.game.get_valid_actions())
+        self.game.play(*random.choice(moves))
 
 
 class NeuralNetworkOthelloAgent(OthelloAgent):
+    """agents.py:44-68: a private OthelloMCTS per agent (its table persists over the game), `num_simulations`
+    simulations before every move, the temperature argument ignored and forced to 0 (agents.py:46), the move =
+    the first valid action with the largest policy entry."""
+
     def __init__(self, game, neural_network, num_simulations, degree_exploration, temperature=0,
                  q_mode=_lib.QMODE_F64):
-        self.temperature = 0                          # the argument is ignored, as in agents.py:46
-        self.neural_network = neural_network
-        self.num_simulations = num_simulations
-        n = game.board_size
-        self.mcts = OthelloMCTS(n, neural_network, degree_exploration, q_mode=q_mode,
-                                node_cap=num_simulations * (n * n // 2) + 64)
         super().__init__(game)
+        self.neural_network, self.num_simulations, self.temperature = neural_network, num_simulations, 0
+        side = game.board_size
+        # an agent searches on its own turns only: about half the plies
+        self.mcts = OthelloMCTS(side, neural_network, degree_exploration, q_mode=q_mode,
+                                node_cap=num_simulations * (side * side // 2) + 64)
 
-    def play(self):                                   # agents.py:52-68
-        state = self.game.board(BoardView.TWO_CHANNELS)
-        self.mcts.simulate_n(state, self.game.current_player, self.num_simulations)
-        if self.game.current_player == OthelloPlayer.WHITE:
-            state = OthelloGame.invert_board(state)
-        action_probabilities = self.mcts.get_policy_action_probabilities(state, self.temperature)
-        valid_actions = self.game.get_valid_actions()
-        best_action = max(valid_actions, key=lambda position: action_probabilities[tuple(position)])
-        self.game.play(*best_action)
+    def play(self):
+        game = self.game
+        mover = game.current_player
+        board = game.board(BoardView.TWO_CHANNELS)
+        self.mcts.simulate_n(board, mover, self.num_simulations)
+        canonical = board if mover == OthelloPlayer.BLACK else OthelloGame.invert_board(board)
+        policy = self.mcts.get_policy_action_probabilities(canonical, self.temperature)
+        best = None
+        for action in game.get_valid_actions():               # max() keeps the FIRST maximum: strict '>' below
+            if best is None or policy[tuple(action)] > policy[tuple(best)]:
+                best = action
+        game.play(*best)
 
 
 def duel_between_agents(game, agent_1, agent_2):
-    """agents.py:71-84 -> (winning agent, points)"""
-    players_agents = {OthelloPlayer.BLACK: agent_1, OthelloPlayer.WHITE: agent_2}
+    """agents.py:71-84: agent_1 moves for BLACK, agent_2 for WHITE, until the game is over.
+    -> (winning agent, its points); a draw goes to BLACK's agent (get_winning_player)."""
+    by_colour = {OthelloPlayer.BLACK: agent_1, OthelloPlayer.WHITE: agent_2}
     logging.info('Duel - Started')
     while not game.has_finished():
         logging.info(f'Duel - Round: {game.round}')
-        players_agents[game.current_player].play()
-    winner, points = game.get_winning_player()
-    return players_agents[winner], points
+        by_colour[game.current_player].play()
+    colour, points = game.get_winning_player()
+    return by_colour[colour], points
 
 
 def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, degree_exploration=1.0, seed=0,
