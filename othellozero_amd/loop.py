@@ -34,18 +34,21 @@ from .training import expand_examples, selfplay_batch
 
 
 class CircularArray:
-    """main.py:21-53"""
+    """Ring buffer with the semantics of main.py:21-53, quirks included: it grows like a list up to `max_`; once full,
+    item k overwrites slot `_index % len` and `_index` becomes that slot + 1 (so it runs 1..len and restarts at slot 0
+    through the modulo).  Indexing, slicing, assignment, iteration, len, str and repr go to the underlying list."""
 
     def __init__(self, max_):
-        self._list = []
-        self._max = max_
-        self._index = 0
+        self._list, self._max, self._index = [], max_, 0
 
     def append(self, item):
-        if len(self._list) < self._max:
-            return self._list.append(item)
-        self._list[self._index % len(self._list)] = item
-        self._index = (self._index % len(self._list)) + 1
+        held = len(self._list)
+        if held < self._max:
+            self._list.append(item)
+            return
+        slot = self._index % held
+        self._list[slot] = item
+        self._index = slot + 1
 
     def extend(self, items):
         for item in items:
@@ -54,11 +57,11 @@ class CircularArray:
     def __len__(self):
         return len(self._list)
 
-    def __getitem__(self, *args):
-        return self._list.__class__.__getitem__(self._list, *args)
+    def __getitem__(self, key):
+        return self._list[key]
 
-    def __setitem__(self, *args):
-        return self._list.__class__.__setitem__(self._list, *args)
+    def __setitem__(self, key, value):
+        self._list[key] = value
 
     def __iter__(self):
         return iter(self._list)
@@ -67,7 +70,7 @@ class CircularArray:
         return str(self._list)
 
     def __repr__(self):
-        return '{}({})'.format(self.__class__.__name__, repr(len(self._list)))
+        return f'{type(self).__name__}({len(self._list)!r})'
 
 
 def examples_from_records(records, board_size, alias_final=True):
