@@ -47,7 +47,9 @@
 //     tools/ubench/mfma_bank.hip, independent of the operands' VGPR banks); without any DMA 469.  Variants on that loop:
 //     s_setprio around the cluster -2 %; DMA before the reads of an L section +-0; chained vs product-major MFMA order
 //     +-0; accumulators in AGPRs (inline asm) slower; no vmcnt wait at all +-0 (the waits are free); 2 phases per tile
-//     (half the barriers, -DH2PP_2PHASE) +-0 on conv2 and slower on conv3/conv4.  What is left is the issue cost of the 8
+//     (half the barriers, -DH2PP_2PHASE) +-0 on conv2 and slower on conv3/conv4; the last 4 / 8 MFMAs of a cluster
+//     issued after its closing barrier (hand-over overlap) 5 / 7 % slower; a second copy of the loop without the zero-line
+//     select for the pad-0 layers pushed spills into the loop (2.19 -> 2.53 ms).  What is left is the issue cost of the 8
 //     LDS-DMA pieces per wave and tile (~13 %) and barrier round trips.
 #pragma once
 #include <type_traits>
