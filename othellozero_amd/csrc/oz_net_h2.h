@@ -49,7 +49,8 @@
 //     +-0; accumulators in AGPRs (inline asm) slower; no vmcnt wait at all +-0 (the waits are free); 2 phases per tile
 //     (half the barriers, -DH2PP_2PHASE) +-0 on conv2 and slower on conv3/conv4; the last 4 / 8 MFMAs of a cluster
 //     issued after its closing barrier (hand-over overlap) 5 / 7 % slower; a second copy of the loop without the zero-line
-//     select for the pad-0 layers pushed spills into the loop (2.19 -> 2.53 ms).  What is left is the issue cost of the 8
+//     select for the pad-0 layers pushed spills into the loop (2.19 -> 2.53 ms); s_setprio 1 for wave row 1 over the whole loop
+//     -1 %; the nt cache policy on the A pieces -5 %.  What is left is the issue cost of the 8
 //     LDS-DMA pieces per wave and tile (~13 %) and barrier round trips.
 #pragma once
 #include <type_traits>
