@@ -249,3 +249,29 @@ def test_data_parallel_two_ranks_equal_hand_averaged_gradients(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {rank}" in out, out
+
+
+def test_trained_network_in_split_precision_matches_float64():
+    """after real optimiser steps (weights, biases and BN statistics no longer at their initial values) the f16x2 inference
+    kernels still reproduce the float64 forward of the trained weights within the 1e-5 tolerance of the hot path"""
+    from oracle import nn_numpy
+    from othellozero_amd.NNet import NNetWrapper
+    n, N = 6, 128
+    rs = np.random.RandomState(5)
+    examples = []
+    for _ in range(N):
+        occ = rs.rand(n, n) < 0.7
+        black = occ & (rs.rand(n, n) < 0.5)
+        pol = np.zeros((n, n))
+        pol[rs.randint(n), rs.randint(n)] = 1
+        examples.append((np.stack([black, occ & ~black], axis=2), pol, int(rs.choice([-1, 1]))))
+    net = NNetWrapper((n, n), num_channels_1=256, batch_size=32, epochs=5, max_batch=64, precision="f16x2")
+    net.train(examples)                                                    # 20 Adam steps
+    w = net.get_weights()
+    valid = np.uint64(sum(1 << (r * 8 + c) for r in range(n) for c in range(n)))
+    own = rs.randint(0, 2**63, size=64, dtype=np.uint64) & valid
+    opp = rs.randint(0, 2**63, size=64, dtype=np.uint64) & valid & ~own
+    pi, v = net.predict_batch(own, opp)
+    pr, vr = nn_numpy.forward(w, own, opp, n)
+    assert np.abs(pi.reshape(64, -1) - pr).max() <= 1e-5 and np.abs(v - vr).max() <= 1e-5
+    assert np.abs(np.asarray(w[4])).max() > 1e-3 and np.abs(np.asarray(w[5]) - 1).max() > 1e-3     # BN statistics moved
