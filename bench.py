@@ -192,8 +192,8 @@ def main():
             "config": {
                 "workload": f"{G} concurrent {n}x{n} self-play games per GPU, {args.sims} sims/move, batched leaf eval "
                             "(BASELINE configs[1]); step = one move round (100 lock-step simulations + one move per game), "
-                            "finished games refilled",
-                "games_per_gpu": G, "sims_per_move": args.sims, "board": n, "net": f"OthelloNN {args.channels} filters, random init seed 0",
+                            f"finished games refilled; leaf evaluator = the reference's OthelloNN ({args.channels} filters), random init seed 0",
+                "games_per_gpu": G, "sims_per_move": args.sims, "board": n,
                 "q_mode": "float64 (NumPy 1.18.5 promotion)", "parallelism": f"games sharded x{world}, all-gather of move records",
             },
             "games_per_s": games_all / dt, "sims_per_s": sims_all / dt, "moves_per_s": moves_all / dt,
