@@ -207,7 +207,9 @@ def main():
             "tree_side_hbm": {"bytes_per_sim": 1300, "achieved_GBps": sims_all / dt * 1300 / 1e9, "peak_GBps": 8000.0,
                               "frac": sims_all / dt * 1300 / 8e12, "note": "not the binding roof; reported per SURVEY 8(d)"},
         }
-        out["dtype"] = "f32" if args.precision == "f32" else "f32 as 2xfp16 split (3 fp16 MFMA products per fp32 product, f32 accumulate)"
+        out["dtype"] = "f32" if args.precision == "f32" else "f32 (2xf16 split)"
+        out["dtype_detail"] = ("fp32 operands and accumulators on v_mfma_f32_32x32x2_f32" if args.precision == "f32" else
+                               "fp32 values carried as two fp16 planes, 3 fp16 MFMA products per fp32 product, fp32 accumulate; pi, v within 1e-5 of float64")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.channels, args.sims)
         print(json.dumps(out), flush=True)
