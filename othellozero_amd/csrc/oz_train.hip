@@ -37,6 +37,8 @@ OZ_HD bool oz_dropout_keep(uint64_t seed, uint64_t step, uint64_t layer, uint64_
     return u >= rate;
 }
 
+#include "oz_train_fused.h"
+
 // ---------------------------------------------------------------- conv1 forward (raw, + bias) and its weight gradient
 // x[b][iy][ix][ch]: cin = 2 -> (own bit, opp bit); cin = 1 -> own bit - opp bit (Net/BaseNN.py:41-44)
 __device__ __forceinline__ float t_plane(uint64_t o, uint64_t p, int sq, int ch, int cin) {
@@ -611,6 +613,13 @@ static int t_reduce(oz_trainer* t, RedArgs r) {
 // BN (training mode) + ReLU (+ dropout) of layer l: z[l] -> a[l]
 static int t_bn_forward(oz_trainer* t, int l, int B) {
     const int Cc = t->Co[l], P = t->P_[l];
+    if ((long long)B * P <= OZ_BN_FUSED_MAX_ROWS) {      // small batch: the whole layer in one launch (oz_train_fused.h)
+        hipLaunchKernelGGL(k_t_bn_fwd_fused, dim3(Cc / OZ_BN_COLS), dim3(1024), 0, t->s, t->z[l], t->a[l], t->d_count, P, Cc, t->param(6 * l + 2),
+                           t->param(6 * l + 3), t->mean[l], t->rstd[l], t->stats[6 * l + 4], t->stats[6 * l + 5], t->stats_new[6 * l + 4],
+                           t->stats_new[6 * l + 5], t->mom, l < 4 ? 1 : 0, l >= 4 ? t->rate : 0.f, t->seed, (uint64_t)t->step, l - 4);
+        OZ_HIP(hipGetLastError());
+        return OZ_OK;
+    }
     RedArgs r = {}; r.x = t->z[l]; r.P = P; r.C = Cc;
     if (int rc = t_reduce<0>(t, r)) return rc;
     hipLaunchKernelGGL(k_t_fin_mean, dim3((Cc + 255) / 256), dim3(256), 0, t->s, t->partial, t->d_count, P, Cc, t->mean[l]);
@@ -666,6 +675,12 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
     for (int l = 5; l >= 0; --l) {
         const int Cc = t->Co[l], P = t->P_[l];
         const float post = l >= 4 && t->rate > 0.f ? 1.0f / (1.0f - t->rate) : 1.0f;
+        if ((long long)B * P <= OZ_BN_FUSED_MAX_ROWS) {  // small batch: BN backward, dgamma / dbeta / bias gradient in one launch
+            hipLaunchKernelGGL(k_t_bn_bwd_fused, dim3(Cc / OZ_BN_COLS), dim3(1024), 0, s, t->dA[cur], t->a[l], t->z[l], t->mean[l], t->rstd[l],
+                               t->param(6 * l + 2), post, t->d_count, t->Hout[l], Cc, t->Hz[l], t->zoff[l], t->dz[l], t->grad(6 * l + 2),
+                               t->grad(6 * l + 3), t->grad(6 * l + 1));
+            OZ_HIP(hipGetLastError());
+        } else {
         RedArgs r = {}; r.x = t->dA[cur]; r.a = t->a[l]; r.z = t->z[l]; r.mean = t->mean[l]; r.rstd = t->rstd[l]; r.post_scale = post; r.P = P; r.C = Cc;
         if (int rc = t_reduce<2>(t, r)) return rc;
         hipLaunchKernelGGL(k_t_fin_bnbwd, dim3((Cc + 255) / 256), dim3(256), 0, s, t->partial, Cc, t->grad(6 * l + 2), t->grad(6 * l + 3), t->sums);
@@ -678,6 +693,7 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
         if (int rc = t_reduce<3>(t, rb)) return rc;
         hipLaunchKernelGGL(k_t_fin_colsum, dim3((Cc + 255) / 256), dim3(256), 0, s, t->partial, Cc, t->grad(6 * l + 1));
         OZ_HIP(hipGetLastError());
+        }
         // weight gradient
         if (l == 0) {
             hipLaunchKernelGGL(k_t_conv1_wgrad, dim3(9 * t->cin, (C + 255) / 256, RED_S), dim3(256), 0, s, t->d_own, t->d_opp, t->d_count, n, C, t->cin,
@@ -723,8 +739,8 @@ OZ_API int oz_trainer_apply(oz_trainer* t) {
     const float lr_t = (float)((double)t->lr * sqrt(1.0 - b2t) / (1.0 - b1t));
     hipLaunchKernelGGL(k_t_adam, dim3((unsigned)((t->total + 255) / 256)), dim3(256), 0, t->s, t->P, t->G, t->M1, t->V2, (long long)t->total, lr_t, t->clip);
     OZ_HIP(hipGetLastError());
-    for (int i = 0; i < 36; ++i)
-        if (t->toff[i] < 0) OZ_HIP(hipMemcpyAsync(t->stats[i], t->stats_new[i], t->size[i] * sizeof(float), hipMemcpyDeviceToDevice, t->s));
+    for (int i = 0; i < 36; ++i)            // the staged moving statistics become the current ones (pointer swap, stream-ordered use)
+        if (t->toff[i] < 0) { float* tmp = t->stats[i]; t->stats[i] = t->stats_new[i]; t->stats_new[i] = tmp; }
     t->dirty = true;
     return OZ_OK;
 }

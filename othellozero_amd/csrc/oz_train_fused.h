@@ -1,0 +1,93 @@
+// oz_train_fused.h -- small-batch BatchNormalization kernels of the training step (included by oz_train.hip).
+//
+// At the reference's batch size (32 boards: 1152-2048 rows per conv layer, 32 per dense layer) the five launches of the
+// general BN forward path (sum, mean, centred sum of squares, rstd + moving statistics, apply) and the five of the
+// backward path cost ~5 us each for a few microseconds of work.  Here one 1024-thread block owns 16 channels for ALL rows
+// and does the whole layer in one launch: 64 row lanes x 16 columns (C / 16 blocks), every thread walks its rows in order (loads unrolled for
+// memory-level parallelism), the 64 partial sums are combined in a fixed order through LDS (bit-reproducible), the activation stays L2-resident between passes.
+// Used when rows <= OZ_BN_FUSED_MAX_ROWS; larger batches keep the multi-block reductions (bandwidth-bound there).
+#pragma once
+
+#define OZ_BN_FUSED_MAX_ROWS 16384
+
+#define OZ_BN_RL 64                        // row lanes per block
+#define OZ_BN_COLS 16                      // channels per block
+__device__ __forceinline__ float t_block_sum4(float v, float (*sh)[OZ_BN_COLS], int lane4, int c64) {
+    __syncthreads();                       // sh may still be read from the previous reduction
+    sh[lane4][c64] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < OZ_BN_RL; ++i) s += sh[i][c64];          // fixed order
+    return s;
+}
+
+// a = relu((z - mean) * rstd * gamma + beta) [* keep / (1 - rate)]; also mean, rstd and the staged moving statistics
+__global__ __launch_bounds__(1024) void k_t_bn_fwd_fused(const float* __restrict__ z, float* __restrict__ a, const int* __restrict__ d_count,
+                                                        int P, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                        const float* __restrict__ mm, const float* __restrict__ mv,
+                                                        float* __restrict__ mm_new, float* __restrict__ mv_new, float mom, int fused_var,
+                                                        float rate, uint64_t seed, uint64_t step, int dlayer) {
+    __shared__ float sh[OZ_BN_RL][OZ_BN_COLS];
+    const int c64 = threadIdx.x & (OZ_BN_COLS - 1), lane4 = threadIdx.x / OZ_BN_COLS, c = blockIdx.x * OZ_BN_COLS + c64;
+    const long long M = (long long)(*d_count) * P;
+    float s = 0.f;
+    _Pragma("unroll 4") for (long long m = lane4; m < M; m += OZ_BN_RL) s += z[(size_t)m * C + c];
+    const float mean = t_block_sum4(s, sh, lane4, c64) / (float)M;
+    float q = 0.f;
+    _Pragma("unroll 4") for (long long m = lane4; m < M; m += OZ_BN_RL) { const float d = z[(size_t)m * C + c] - mean; q = fmaf(d, d, q); }
+    const float var = t_block_sum4(q, sh, lane4, c64) / (float)M;
+    const float rstd = 1.0f / sqrtf(var + 1e-3f);
+    if (lane4 == 0) {
+        mean_out[c] = mean; rstd_out[c] = rstd;
+        const float uv = fused_var ? var * ((float)M / (float)(M > 1 ? M - 1 : 1)) : var;
+        mm_new[c] = mm[c] * mom + mean * (1.0f - mom);
+        mv_new[c] = mv[c] * mom + uv * (1.0f - mom);
+    }
+    const float g = gamma[c], b = beta[c];
+    _Pragma("unroll 4") for (long long m = lane4; m < M; m += OZ_BN_RL) {
+        const size_t i = (size_t)m * C + c;
+        float y = (z[i] - mean) * rstd * g + b;
+        y = y > 0.f ? y : 0.f;
+        if (rate > 0.f) y = oz_dropout_keep(seed, step, (uint64_t)dlayer, (uint64_t)i, rate) ? y / (1.0f - rate) : 0.f;
+        a[i] = y;
+    }
+}
+
+// dy = (a > 0 ? dA * post_scale : 0); dgamma = sum dy * xhat, dbeta = sum dy;
+// dz = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M), written at (b, oy + zoff, ox + zoff) of an Hz x Hz buffer;
+// dbias = sum dz (rounding noise behind a training-mode BN, computed like autograd would)
+__global__ __launch_bounds__(1024) void k_t_bn_bwd_fused(const float* __restrict__ dA, const float* __restrict__ a, const float* __restrict__ z,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, float post_scale, const int* __restrict__ d_count,
+                                                        int Hout, int C, int Hz, int zoff, float* __restrict__ dz,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+    __shared__ float sh[OZ_BN_RL][OZ_BN_COLS];
+    const int c64 = threadIdx.x & (OZ_BN_COLS - 1), lane4 = threadIdx.x / OZ_BN_COLS, c = blockIdx.x * OZ_BN_COLS + c64;
+    const int P = Hout * Hout;
+    const long long M = (long long)(*d_count) * P;
+    const float mu = mean[c], rs = rstd[c];
+    float s0 = 0.f, s1 = 0.f;
+    _Pragma("unroll 4") for (long long m = lane4; m < M; m += OZ_BN_RL) {
+        const size_t i = (size_t)m * C + c;
+        const float dy = a[i] > 0.f ? dA[i] * post_scale : 0.f;
+        s0 += dy;
+        s1 = fmaf(dy, (z[i] - mu) * rs, s1);
+    }
+    const float S0 = t_block_sum4(s0, sh, lane4, c64);
+    const float S1 = t_block_sum4(s1, sh, lane4, c64);
+    const float inv = 1.0f / (float)M, gr = gamma[c] * rs;
+    float sb = 0.f;
+    _Pragma("unroll 4") for (long long m = lane4; m < M; m += OZ_BN_RL) {
+        const size_t i = (size_t)m * C + c;
+        const float dy = a[i] > 0.f ? dA[i] * post_scale : 0.f;
+        const float xh = (z[i] - mu) * rs;
+        const float g = gr * (dy - S0 * inv - xh * S1 * inv);
+        const int b = (int)(m / P), pix = (int)(m % P);
+        dz[(((size_t)b * Hz + pix / Hout + zoff) * Hz + pix % Hout + zoff) * C + c] = g;
+        sb += g;
+    }
+    const float SB = t_block_sum4(sb, sh, lane4, c64);
+    if (lane4 == 0) { dgamma[c] = S1; dbeta[c] = S0; dbias[c] = SB; }
+}
