@@ -37,4 +37,4 @@ struct GemmGeom {
 };
 int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
                        const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
-                       hipStream_t s, float* partial, long long partial_floats);
+                       hipStream_t s, float* partial, long long partial_floats, int sizing_count = 0);

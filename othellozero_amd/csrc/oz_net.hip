@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_f32(const float* __restri
 // in a fixed order by k_splitk_reduce_f32 -- same result for every batch position, different rounding than ksplit = 1.
 int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
                        const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
-                       hipStream_t s, float* partial, long long partial_floats) {
+                       hipStream_t s, float* partial, long long partial_floats, int sizing_count) {
     OZ_REQUIRE(N % GM_BN == 0 && Cin % GM_BK == 0, "gemm_f32: N %% 128 and Cin %% 32 must be 0 (N=%d Cin=%d)", N, Cin);
     GemmGeom g;
     g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.relu = relu;
@@ -225,7 +225,11 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
     int ksplit = 1;
     const int nk = g.K / GM_BK;
     if (partial) {
-        while (ksplit < 16 && grid * ksplit < 256 && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * Mmax * N <= partial_floats) ksplit *= 2;
+        // the split is chosen from `sizing_count` when given (a per-network constant: results then do not depend on the
+        // size of an individual call), else from this launch's own grid
+        const long long Ms = (long long)(sizing_count > 0 ? sizing_count : max_count) * Hout * Hout;
+        const int grid_s = ((int)((Ms + GM_BM - 1) / GM_BM) + 7) / 8 * 8 * (N / GM_BN);
+        while (ksplit < 16 && grid_s * ksplit < 256 && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * (Ms > Mmax ? Ms : Mmax) * N <= partial_floats) ksplit *= 2;
     }
     g.ksplit = ksplit; g.slab = Mmax * N;
     hipLaunchKernelGGL(k_gemm_f32, dim3(grid, ksplit), dim3(256), 0, s, in, Wt, scale, shift, out, d_count, g, num_mt, partial);
@@ -354,6 +358,7 @@ struct OnnNet : oz_net {
     float* d_scale_h2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int* d_flag = nullptr;
     float* d_partial = nullptr;      // split-K slabs [4][max_batch][1024]
+    float* d_part32 = nullptr;       // precision f32, max_batch <= 32: split-K slabs of the latency path
     uint4* d_zero = nullptr;
     bool h2_attr_set = false;
     std::vector<void*> allocs;
@@ -384,7 +389,9 @@ struct OnnNet : oz_net {
 
     int launch_gemm(const float* in, const float* Wt, int layer, float* out, const int* d_count, int max_count, int Hin,
                     int Hout, int pad, int Cin, int taps, int N, hipStream_t s) {
-        return oz_gemm_f32_launch(in, Wt, d_scale[layer], d_shift[layer], out, d_count, max_count, Hin, Hout, pad, Cin, taps, N, 1, s, nullptr, 0);
+        // small networks (max_batch <= 32: the drop-in OthelloMCTS / agents path) split K over the idle CUs: latency, not throughput
+        return oz_gemm_f32_launch(in, Wt, d_scale[layer], d_shift[layer], out, d_count, max_count, Hin, Hout, pad, Cin, taps, N, 1, s,
+                                  d_part32, d_part32 ? (long long)16 * max_batch * 64 * 512 : 0, max_batch);
     }
 
     // layer: 1..3 = conv2..4 (3x3, Cin = N = C), 4 = fc1, 5 = fc2 (taps 1)
@@ -393,7 +400,7 @@ struct OnnNet : oz_net {
                        int Hout, int pad, int Cin, int taps, int N, hipStream_t s, int ksplit = 1) {
         H2Geom g;
         g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.out_h2 = out_h2; g.relu = 1;
-        g.ksplit = ksplit; g.slab = (long long)max_batch * N;
+        g.ksplit = ksplit; g.slab = (long long)max_batch * Hout * Hout * N;
         const long long Mmax = (long long)max_count * Hout * Hout;
         const int num_mt = (int)((Mmax + CF::BM - 1) / CF::BM);
         const int grid = ((num_mt + 7) / 8) * 8 * (N / CF::BN) * ksplit;
@@ -411,9 +418,9 @@ struct OnnNet : oz_net {
         hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
                            d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag);
         if (ksplit > 1) {
-            const long long threads = (long long)max_count * (N / 8);
+            const long long threads = (long long)max_count * Hout * Hout * (N / 8);
             hipLaunchKernelGGL(k_splitk_reduce_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)d_partial,
-                               g.slab, ksplit, N, d_count, d_scale_h2[layer - 1], d_shift[layer], 1, (uint4*)out_final, d_flag);
+                               g.slab, ksplit, N, Hout * Hout, d_count, d_scale_h2[layer - 1], d_shift[layer], 1, (uint4*)out_final, d_flag);
         }
         OZ_HIP(hipGetLastError());
         return OZ_OK;
@@ -439,6 +446,20 @@ struct OnnNet : oz_net {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && pending.size() > 4096) { if (int rc = collect_profile()) return rc; }
         if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); OZ_HIP(hipEventRecord(e0, s)); }
+        if (max_batch <= 32) {
+            // small networks (the drop-in OthelloMCTS / agents path, one position per call): latency, not throughput --
+            // 128 x 128 tiles with the k loop split 16 ways over otherwise idle CUs, fixed-order reduce (keyed on max_batch,
+            // a per-network constant, so a position's result does not depend on the size of the call)
+            if (int rc = launch_gemm_h2<H2Small>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, 16)) return rc;
+            if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
+            if (int rc = launch_gemm_h2<H2Small>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, 16)) return rc;
+            if (int rc = launch_gemm_h2<H2Small>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, 16)) return rc;
+            if (int rc = launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)) return rc;
+            if (int rc = launch_gemm_h2<H2Thin>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
+            hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+            OZ_HIP(hipGetLastError());
+            return OZ_OK;
+        }
         static const bool pp = !(getenv("OZ_H2_PP") && atoi(getenv("OZ_H2_PP")) == 0);    // ping-pong main loop (default); OZ_H2_PP=0 selects the one-barrier-per-tile loop for A/B runs
         if (int rc = pp ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s)
                         : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
@@ -611,6 +632,9 @@ OZ_API int oz_net_commit(oz_net* net) {
             for (int c = 0; c < Ns[i]; ++c) t[(size_t)c * Ks[i] + k] = src[(size_t)k * Ns[i] + c];
         if (int rc = upload(o, &o->d_wt[i], t)) return rc;
     }
+    if (o->precision == 0 && !o->d_part32 && o->max_batch <= 32) {
+        if (int rc = o->alloc(&o->d_part32, (size_t)16 * o->max_batch * 64 * 512)) return rc;
+    }
     if (o->precision == 1) {
         // conv2..4 in the h2 layout [Cout][K/8][h1 x8 | h2 x8], k = tap*Cin + ci, pre-scaled by an exact power of two
         for (int i = 0; i < 5; ++i) {
@@ -641,7 +665,8 @@ OZ_API int oz_net_commit(oz_net* net) {
         }
         if (!o->d_flag) { if (int rc = o->alloc(&o->d_flag, 1)) return rc; }
         OZ_HIP(hipMemset(o->d_flag, 0, sizeof(int)));
-        if (!o->d_partial) { if (int rc = o->alloc(&o->d_partial, (size_t)4 * o->max_batch * 1024)) return rc; }
+        // split-K slabs: fc1 (4 x max_batch x 1024); small networks also split the convolutions 16 ways (latency path)
+        if (!o->d_partial) { if (int rc = o->alloc(&o->d_partial, o->max_batch <= 32 ? (size_t)16 * o->max_batch * 64 * 1024 : (size_t)4 * o->max_batch * 1024)) return rc; }
         if (!o->d_zero) { if (int rc = o->alloc(&o->d_zero, 16)) return rc; }
         OZ_HIP(hipMemset(o->d_zero, 0, 256));
     }

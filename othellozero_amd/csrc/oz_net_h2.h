@@ -95,14 +95,14 @@ struct H2Geom {
 
 // finishes a split-K layer: out[m][n] = act((sum_s slab[s][m][n]) * scale[n] + shift[n]) with the slices added in a
 // FIXED order (bit-reproducible), written in the h2 layout.  One thread per (row, 8 channels).
-__global__ __launch_bounds__(256) void k_splitk_reduce_h2(const float* __restrict__ part, long long slab, int ksplit, int N,
+__global__ __launch_bounds__(256) void k_splitk_reduce_h2(const float* __restrict__ part, long long slab, int ksplit, int N, int P,
                                                           const int* __restrict__ d_count, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int relu, uint4* __restrict__ out,
                                                           int* __restrict__ flag) {
     const int ng = N >> 3;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long m = idx / ng;
-    if (m >= *d_count) return;
+    if (m >= (long long)(*d_count) * P) return;          // rows = positions x output pixels
     const int c8 = (int)(idx % ng) * 8;
     float acc[8];
     const float* p = part + (size_t)m * N + c8;

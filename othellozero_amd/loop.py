@@ -91,6 +91,12 @@ def evaluate_against_random(board_size, neural_network, games, num_simulations, 
     """main.py:163-192 / :197-233: `games` duels against RandomOthelloAgent, colours drawn by random.shuffle.
     -> dict(wins, black_wins, black_games, white_wins, white_games)"""
     r = dict(wins=0, black_wins=0, black_games=0, white_wins=0, white_games=0)
+    if getattr(neural_network, "max_batch", 1) > 32 and hasattr(neural_network, "get_weights"):
+        # one position per call: a twin with max_batch 1 takes the library's latency path (k loops split over idle CUs)
+        from .NNet import NNetWrapper
+        neural_network = NNetWrapper((board_size, board_size), network=neural_network.network_type,
+                                     num_channels_1=neural_network.num_channels, max_batch=1,
+                                     weights=neural_network.get_weights(), precision=neural_network.precision)
     for k in range(games):
         game = OthelloGame(board_size, current_player=OthelloPlayer.BLACK)
         nn_agent = NeuralNetworkOthelloAgent(game, neural_network, num_simulations, degree_exploration)
