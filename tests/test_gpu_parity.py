@@ -686,3 +686,28 @@ def test_pingpong_conv_loop_bit_identical_to_simple_loop():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "pp_race_check.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 differ" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+@pytest.mark.parametrize("n,network", [(8, "ONN"), (6, "ONN"), (8, "BNN")])
+def test_small_network_latency_path_vs_float64(oz, n, network, precision):
+    """networks with max_batch <= 32 (the drop-in single-position path) split every GEMM's k loop 16 ways: same 1e-5
+    tolerance against float64, invariance to the size of the call, agreement with a throughput-path twin to rounding"""
+    from othellozero_amd.NNet import NNetWrapper, NeuralNets
+    from othellozero_amd.weights import init_weights
+    cin = 2 if network == "ONN" else 1
+    w = init_weights(n, seed=21, channels=512, randomize_all=True, in_channels=cin)
+    for i in (36, 38):
+        w[i] = w[i] * 4.0
+    kind = NeuralNets.ONN if network == "ONN" else NeuralNets.BNN
+    small = NNetWrapper((n, n), num_channels_1=512, max_batch=4, weights=w, precision=precision, network=kind)
+    own, opp = _boards(n, 7, seed=3 * n)
+    pi, v = small.predict_batch(own, opp)                       # chunks of 4, 3
+    pi64, v64 = nn_numpy.forward(w, own, opp, n)
+    assert np.abs(pi.reshape(7, -1) - pi64).max() <= 1e-5 and np.abs(v - v64).max() <= 1e-5
+    p1, v1 = small.predict_batch(own[5:6], opp[5:6])            # a call of another size: bit-identical
+    assert np.array_equal(p1[0], pi[5]) and v1[0] == v[5]
+    big = NNetWrapper((n, n), num_channels_1=512, max_batch=64, weights=w, precision=precision, network=kind)
+    pb, vb = big.predict_batch(own, opp)
+    assert np.abs(pb - pi).max() <= 2e-6 and np.abs(vb - v).max() <= 2e-6
