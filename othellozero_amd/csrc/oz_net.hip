@@ -394,6 +394,25 @@ struct OnnNet : oz_net {
                                   d_part32, d_part32 ? (long long)16 * max_batch * 64 * 512 : 0, max_batch);
     }
 
+    // k-split of a 3x3 convolution on BM-row tiles (N = C, 256-column tiles): the smallest power of two <= 8 that brings
+    // the grid to >= 192 blocks, from max_batch (a per-network constant, so results do not depend on the size of a call)
+    int conv_ksplit(int pixels, int BM) const {
+        const long long blocks = (((long long)max_batch * pixels + BM - 1) / BM) * (C / 256);
+        int k = 1;
+        while (k < 8 && blocks * k < 192) k *= 2;
+        return k;
+    }
+    size_t partial_floats() const {
+        if (max_batch <= 32) return (size_t)16 * max_batch * 64 * 1024;
+        size_t need = (size_t)4 * max_batch * 1024;                                  // fc1
+        const int px[3] = {n * n, (n - 2) * (n - 2), (n - 4) * (n - 4)}, bm[3] = {256, 192, 256};
+        for (int i = 0; i < 3; ++i) {
+            const int k = conv_ksplit(px[i], bm[i]);
+            if (k > 1 && (size_t)k * max_batch * px[i] * C > need) need = (size_t)k * max_batch * px[i] * C;
+        }
+        return need;
+    }
+
     // layer: 1..3 = conv2..4 (3x3, Cin = N = C), 4 = fc1, 5 = fc2 (taps 1)
     template <typename CF>
     int launch_gemm_h2(const void* in, int layer, void* out, int out_h2, const int* d_count, int max_count, int Hin,
@@ -461,13 +480,16 @@ struct OnnNet : oz_net {
             return OZ_OK;
         }
         static const bool pp = !(getenv("OZ_H2_PP") && atoi(getenv("OZ_H2_PP")) == 0);    // ping-pong main loop (default); OZ_H2_PP=0 selects the one-barrier-per-tile loop for A/B runs
-        if (int rc = pp ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s)
-                        : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
+        // medium networks (arenas, evaluation batches, the loop's 100 episodes): a convolution whose grid would leave most
+        // CUs idle splits its k loop (conv_ksplit: from max_batch, a per-network constant; 1 at the bench's 4096 games)
+        const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), 192), k4 = conv_ksplit((n - 4) * (n - 4), 256);
+        if (int rc = pp ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)
+                        : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)) return rc;
         if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
-        if (int rc = pp ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s)
-                        : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
-        if (int rc = pp ? launch_gemm_h2<H2BigPP>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)
-                        : launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
+        if (int rc = pp ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
+                        : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
+        if (int rc = pp ? launch_gemm_h2<H2BigPP>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
+                        : launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)) return rc;
         // fc1: K = 8192 but only batch x 1024 outputs -> 4-way split-K (fixed-order reduce) to fill the chip
         // (large batches: on the 256 x 256 ping-pong tile, 16 x 4 tiles x 4 k-slices = one block per CU; bit-identical to
         //  the 128 x 128 tile because the k-slices and the order inside them are the same -- tools/pp_race_check.py)
@@ -666,7 +688,7 @@ OZ_API int oz_net_commit(oz_net* net) {
         if (!o->d_flag) { if (int rc = o->alloc(&o->d_flag, 1)) return rc; }
         OZ_HIP(hipMemset(o->d_flag, 0, sizeof(int)));
         // split-K slabs: fc1 (4 x max_batch x 1024); small networks also split the convolutions 16 ways (latency path)
-        if (!o->d_partial) { if (int rc = o->alloc(&o->d_partial, o->max_batch <= 32 ? (size_t)16 * o->max_batch * 64 * 1024 : (size_t)4 * o->max_batch * 1024)) return rc; }
+        if (!o->d_partial) { if (int rc = o->alloc(&o->d_partial, o->partial_floats())) return rc; }
         if (!o->d_zero) { if (int rc = o->alloc(&o->d_zero, 16)) return rc; }
         OZ_HIP(hipMemset(o->d_zero, 0, 256));
     }
