@@ -389,11 +389,13 @@ struct OnnNet : oz_net {
 
     int launch_gemm(const float* in, const float* Wt, int layer, float* out, const int* d_count, int max_count, int Hin,
                     int Hout, int pad, int Cin, int taps, int N, hipStream_t s) {
-        // small networks (max_batch <= 32: the drop-in OthelloMCTS / agents path) split K over the idle CUs: latency, not throughput
+        // small and medium networks (max_batch <= 512) split K over the idle CUs: latency, not throughput
         return oz_gemm_f32_launch(in, Wt, d_scale[layer], d_shift[layer], out, d_count, max_count, Hin, Hout, pad, Cin, taps, N, 1, s,
-                                  d_part32, d_part32 ? (long long)16 * max_batch * 64 * 512 : 0, max_batch);
+                                  d_part32, d_part32 ? (long long)part32_mult() * max_batch * 64 * 512 : 0, max_batch);
     }
 
+    // precision f32: split-K slabs per position-row budget (small networks 16 slices, medium ones fewer; none for large batches)
+    int part32_mult() const { return max_batch <= 32 ? 16 : max_batch <= 128 ? 8 : max_batch <= 512 ? 2 : 0; }
     // k-split of a 3x3 convolution on BM-row tiles (N = C, 256-column tiles): the smallest power of two <= 8 that brings
     // the grid to >= 192 blocks, from max_batch (a per-network constant, so results do not depend on the size of a call)
     int conv_ksplit(int pixels, int BM) const {
@@ -654,8 +656,8 @@ OZ_API int oz_net_commit(oz_net* net) {
             for (int c = 0; c < Ns[i]; ++c) t[(size_t)c * Ks[i] + k] = src[(size_t)k * Ns[i] + c];
         if (int rc = upload(o, &o->d_wt[i], t)) return rc;
     }
-    if (o->precision == 0 && !o->d_part32 && o->max_batch <= 32) {
-        if (int rc = o->alloc(&o->d_part32, (size_t)16 * o->max_batch * 64 * 512)) return rc;
+    if (o->precision == 0 && !o->d_part32 && o->part32_mult() > 0) {
+        if (int rc = o->alloc(&o->d_part32, (size_t)o->part32_mult() * o->max_batch * 64 * 512)) return rc;
     }
     if (o->precision == 1) {
         // conv2..4 in the h2 layout [Cout][K/8][h1 x8 | h2 x8], k = tap*Cin + ci, pre-scaled by an exact power of two
