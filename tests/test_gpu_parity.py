@@ -711,3 +711,37 @@ def test_small_network_latency_path_vs_float64(oz, n, network, precision):
     big = NNetWrapper((n, n), num_channels_1=512, max_batch=64, weights=w, precision=precision, network=kind)
     pb, vb = big.predict_batch(own, opp)
     assert np.abs(pb - pi).max() <= 2e-6 and np.abs(vb - v).max() <= 2e-6
+
+
+@pytest.mark.gpu
+def test_game_sharding_does_not_change_the_pooled_records(oz):
+    """BASELINE configs[2] / [3] in miniature: a job of 24 games played by ONE engine, and the same job sharded over three
+    'ranks' (engines owning global game ids [0,8), [8,16), [16,24), as bench.py / distributed.shard_games assign them)
+    give the same multiset of move records -- with refills, too (second generation ids continue with the job-wide stride)"""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    from othellozero_amd.distributed import shard_games
+    n, G, sims = 6, 24, 12
+    def run(num, first, stride, rounds):
+        eng = SelfPlayEngine(StubNetWrapper((n, n), 61, 0, max_batch=num), n, num, sims, 1.0, 1.0, 0.9, seed=5, first_game_id=first,
+                             game_id_stride=stride, refill=stride > 0, record_cap=num * 4 * n * n)
+        eng.run(rounds)
+        return eng.records()
+    whole = run(G, 0, 0, n * n)
+    parts = [run(cnt, first, 0, n * n) for first, cnt in (shard_games(G, r, 3) for r in range(3))]
+    pooled = np.concatenate(parts)
+    pooled = pooled[np.lexsort((pooled["ply"], pooled["game_id"]))]
+    assert len(whole) == len(pooled) and whole.tobytes() == pooled.tobytes()
+    # with refill: 2 generations; a finished slot restarts as game id + job-wide stride
+    whole2 = run(G, 0, G, 70)
+    parts2 = [run(cnt, first, G, 70) for first, cnt in (shard_games(G, r, 3) for r in range(3))]
+    pooled2 = np.concatenate(parts2)
+    done_w = {int(g) for g in np.unique(whole2["game_id"])}
+    done_p = {int(g) for g in np.unique(pooled2["game_id"])}
+    common = sorted(done_w & done_p)
+    assert len(common) >= G                                    # at least the whole first generation
+    for gid in common[:G + 4]:
+        a = whole2[whole2["game_id"] == gid]
+        b = pooled2[pooled2["game_id"] == gid]
+        b = b[np.argsort(b["ply"])]
+        assert a.tobytes() == b.tobytes(), gid
