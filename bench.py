@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x2"],
                     help="conv arithmetic: exact fp32 matrix cores, or f32 via 2 x fp16 split (same 1e-5 parity tolerance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--driver", default="lockstep", choices=["free", "lockstep"],
+                    help="free: oz_selfplay_run_steps (every game runs on by itself, full leaf batches; identical records); "
+                         "lockstep: oz_selfplay_run (one simulation per game per step, moves aligned)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -148,21 +151,29 @@ def main():
     net = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0, precision=args.precision)   # same weights on every rank
     eng = SelfPlayEngine(net, n, G, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * G,
                          game_id_stride=world * G, q_mode=_lib.QMODE_F64, refill=True,
-                         record_cap=G * (args.steps + args.warmup + 2))
+                         record_cap=int(G * (args.steps + args.warmup + 2) * 1.25))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.run(args.warmup)
+    # one bench step = `sims` network batches of up to G leaves: a move round in lock step; in free-running mode the same
+    # number of batches, each full (network-free simulations and moves ride along).  Measured: no throughput difference --
+    # a batch's cost is proportional to its leaves, so filling the ~8 % empty slots buys nothing
+    def advance(k, sync):
+        if args.driver == "free":
+            eng.run_steps(k * args.sims, sync=sync)
+        else:
+            eng.run(k, sync=sync)
+    advance(args.warmup, True)
     eng.sync()
     net.profile(True)
     s0 = eng.stats()
     ev0 = eng.eval_time()
     barrier()
     t0 = time.perf_counter()
-    eng.run(args.steps, sync=False)
+    advance(args.steps, False)
     eng.sync()
     pooled = gather_records(engine_records_tensor(eng, dev))       # the path's only exchange step
     barrier()
@@ -191,10 +202,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{G} concurrent {n}x{n} self-play games per GPU, {args.sims} sims/move, batched leaf eval "
-                            "(BASELINE configs[1]); step = one move round (100 lock-step simulations + one move per game), "
+                            "(BASELINE configs[1]); step = " + (f"{args.sims} network batches of up to {G} leaves, games free-running "
+                                                                  "(a game plays its move as soon as its simulations are complete; records identical to lock step), "
+                                                                  if args.driver == "free" else
+                                                                  "one move round (100 lock-step simulations + one move per game), ") +
                             f"finished games refilled; leaf evaluator = the reference's OthelloNN ({args.channels} filters), random init seed 0",
                 "games_per_gpu": G, "sims_per_move": args.sims, "board": n,
-                "q_mode": "float64 (NumPy 1.18.5 promotion)", "parallelism": f"games sharded x{world}, all-gather of move records",
+                "q_mode": "float64 (NumPy 1.18.5 promotion)", "driver": args.driver, "parallelism": f"games sharded x{world}, all-gather of move records",
             },
             "games_per_s": games_all / dt, "sims_per_s": sims_all / dt, "moves_per_s": moves_all / dt,
             "games_completed": int(games_all), "expansions": int(exp_all), "simulations": int(sims_all),

@@ -164,6 +164,11 @@ int oz_selfplay_destroy(oz_selfplay* sp);
 /* `rounds` move rounds: every live game runs cfg.sims simulations, chooses, records and plays one move.
  * Asynchronous (stream ordered); oz_selfplay_sync waits. */
 int oz_selfplay_run(oz_selfplay* sp, int rounds);
+/* free-running form of oz_selfplay_run: `steps` network batches; in each of them every live game first plays its move if the
+ * simulations of the move are complete, runs the simulations that need no network (finished boards) and contributes the
+ * leaf of its next first-visit simulation -- batches stay full instead of ~92 % full, moves are no longer aligned across
+ * games, every game's simulations / moves / records are exactly those of oz_selfplay_run (training.py:39-67). */
+int oz_selfplay_run_steps(oz_selfplay* sp, int steps);
 int oz_selfplay_sync(oz_selfplay* sp);
 int oz_selfplay_get_stats(oz_selfplay* sp, oz_selfplay_stats* out);
 /* per-slot view: boards, player to move, finished flag, plies played, global game id */

@@ -87,7 +87,7 @@ SIGNATURES = {
     "oz_mcts_dump_node": [_vp, C.c_int, C.c_int, _u64p, _u64p, _i32p, _u64p, _i32p, _f64p, _u8p, _f64p],
     "oz_mcts_stats": [_vp, _i64p],
     "oz_selfplay_create": [C.POINTER(_vp), C.POINTER(SelfplayConfig), _vp],
-    "oz_selfplay_destroy": [_vp], "oz_selfplay_run": [_vp, C.c_int], "oz_selfplay_sync": [_vp],
+    "oz_selfplay_destroy": [_vp], "oz_selfplay_run": [_vp, C.c_int], "oz_selfplay_run_steps": [_vp, C.c_int], "oz_selfplay_sync": [_vp],
     "oz_selfplay_get_stats": [_vp, C.POINTER(SelfplayStats)],
     "oz_selfplay_state": [_vp, _u64p, _u64p, _i8p, _u8p, _i32p, _u64p],
     "oz_selfplay_records": [_vp, _vp, C.c_int64, _i64p],

@@ -116,11 +116,11 @@ __device__ double pairwise_sum(const double* a, int len) {
 // ---------------------------------------------------------------- K4: select / descend
 // MCTS.simulate down to the first terminal or unexpanded state (MCTS/__init__.py:39-44,58-67),
 // get_next_state (othelo_mcts.py:43-49).  One wave per game.
-__global__ __launch_bounds__(64) void k_select(MctsDev t) {
-    const int g = blockIdx.x, lane = threadIdx.x;
+// (body shared by k_select and the free-running k_advance; returns the status it stored in leaf_status[g])
+__device__ __forceinline__ int select_body(const MctsDev& t, int g, int lane) {
     if (!t.active[g]) {
         if (lane == 0) t.leaf_status[g] = OZ_LEAF_IDLE;
-        return;
+        return OZ_LEAF_IDLE;
     }
     uint64_t own = t.root_own[g], opp = t.root_opp[g];
     const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
@@ -169,7 +169,9 @@ __global__ __launch_bounds__(64) void k_select(MctsDev t) {
         if (status == OZ_LEAF_TERMINAL) st[ST_TERMINAL] += 1;
         if (err) atomicOr(t.error_flag, err);
     }
+    return status;
 }
+__global__ __launch_bounds__(64) void k_select(MctsDev t) { select_body(t, blockIdx.x, threadIdx.x); }
 
 // ---------------------------------------------------------------- K13: leaf compaction
 // ballot + prefix sum over the games; slot order = game order (deterministic).
@@ -220,6 +222,22 @@ __device__ __forceinline__ void q_update(const MctsDev& t, size_t e, double val,
     }
     t.edge_Q[e] = q;
     t.edge_N[e] = (uint32_t)(N + 1) | tag;
+}
+
+// backup (MCTS/__init__.py:68-71): the level-d caller sees the leaf value negated (depth-1-d) times
+__device__ __forceinline__ void backup_body(const MctsDev& t, int g, int lane, double value, int vt) {
+    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    const int depth = t.depth[g];
+    if (lane < depth) {
+        const int2 pe = t.path[(size_t)g * OZ_MAX_DEPTH + lane];
+        const double val = ((depth - 1 - lane) & 1) ? -value : value;
+        q_update(t, eb + pe.y, val, vt);
+        t.node_Ns[nb + pe.x] += 1;
+    }
+    if (lane == 0) {
+        t.last_value[g] = (depth & 1) ? -value : value;
+        t.last_vtype[g] = vt;
+    }
 }
 
 // slot_is_game != 0: pi / v are indexed by game (host evaluator path); else by compacted slot.
@@ -273,18 +291,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(MctsDev t, int slot_is_gam
         value = (double)t.term_value[g];
         vt = VT_INT;
     }
-    // backup (MCTS/__init__.py:68-71): the level-d caller sees the leaf value negated (depth-1-d) times
-    const int depth = t.depth[g];
-    if (lane < depth) {
-        const int2 pe = t.path[(size_t)g * OZ_MAX_DEPTH + lane];
-        const double val = ((depth - 1 - lane) & 1) ? -value : value;
-        q_update(t, eb + pe.y, val, vt);
-        t.node_Ns[nb + pe.x] += 1;
-    }
-    if (lane == 0) {
-        t.last_value[g] = (depth & 1) ? -value : value;
-        t.last_vtype[g] = vt;
-    }
+    backup_body(t, g, lane, value, vt);
 }
 
 // ---------------------------------------------------------------- host object
@@ -651,8 +658,7 @@ __global__ void k_sp_roots(GamesDev gm, MctsDev t, int mover_filter /* 0 all, +1
 // K7: root policy extraction + action choice + OthelloGame.play + example recording
 // (othelo_mcts.py:51-67, training.py:45-67 / agents.py:52-68).  One wave per game.
 //   arena != 0: agents.py semantics (temperature 0, argmax over valid actions of the one-hot).
-__global__ __launch_bounds__(64) void k_sp_move(GamesDev gm, MctsDev t, int arena) {
-    const int g = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void sp_move_body(const GamesDev& gm, const MctsDev& t, int g, int lane, int arena) {
     if (!t.active[g]) return;
     const uint64_t own = t.root_own[g], opp = t.root_opp[g];
     const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
@@ -736,6 +742,58 @@ __global__ __launch_bounds__(64) void k_sp_move(GamesDev gm, MctsDev t, int aren
         gm.finished[g] = (uint8_t)fin; gm.ply[g] = nply;
     }
 }
+__global__ __launch_bounds__(64) void k_sp_move(GamesDev gm, MctsDev t, int arena) { sp_move_body(gm, t, blockIdx.x, threadIdx.x, arena); }
+
+// ---------------------------------------------------------------- free-running self-play step
+// The lock-step driver gives every game one simulation per step; simulations that end on a finished board need no
+// network evaluation, so ~8 % of the slots of a leaf batch stay empty and a move round always costs `sims` network passes.
+// k_advance lets every game run on by itself until its next simulation needs the network: it counts the simulation the
+// previous step completed, plays the move once `sims` of them are done (k_sp_move's body: action choice, play, records,
+// refill), walks further simulations that end on finished boards (k_select's body + the backup), and stops at the first
+// first-visit leaf -- so (almost) every game contributes one leaf to every batch.  A game's own sequence of simulations,
+// moves and random draws is exactly the lock-step one (games are independent, streams are keyed by game id and ply, a
+// position's (pi, v) does not depend on the batch it sits in), so records are identical; only the interleaving of the
+// games changes.  OZ_ADVANCE_CAP bounds the work of one call (late-game positions whose whole remaining tree is known
+// can run many network-free simulations); a game that hits the cap simply contributes no leaf to this batch.
+#define OZ_ADVANCE_CAP 24
+// one wave = one game: stores of one lane must have completed (and may not be reordered by the compiler) before the
+// other lanes load the same locations in the next phase of the loop
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__global__ __launch_bounds__(64) void k_advance(GamesDev gm, MctsDev t, int sims, int* __restrict__ sims_done) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    int done = sims_done[g];
+    if (t.leaf_status[g] == OZ_LEAF_EVAL) ++done;          // the simulation whose leaf the previous step evaluated and backed up
+    int status = OZ_LEAF_IDLE;
+    for (int it = 0; it < OZ_ADVANCE_CAP; ++it) {
+        if (gm.finished[g]) { if (lane == 0) { t.active[g] = 0; t.leaf_status[g] = OZ_LEAF_IDLE; } status = OZ_LEAF_IDLE; break; }
+        // roots of the position to move in (k_sp_roots)
+        const int p = gm.player[g];
+        if (lane == 0) {
+            t.active[g] = 1;
+            t.root_own[g] = p == 1 ? gm.black[g] : gm.white[g];
+            t.root_opp[g] = p == 1 ? gm.white[g] : gm.black[g];
+        }
+        wave_sync();                                       // lane 0's stores are visible to the wave's next loads
+        if (done >= sims) {                                // training.py:42-67: the move after num_simulations simulations
+            sp_move_body(gm, t, g, lane, 0);
+            done = 0;
+            wave_sync();
+            continue;                                      // (a finished game is refilled by the move, or goes idle above)
+        }
+        status = select_body(t, g, lane);
+        if (status != OZ_LEAF_TERMINAL) break;             // EVAL: wait for the network; IDLE: error path
+        wave_sync();
+        backup_body(t, g, lane, (double)t.term_value[g], VT_INT);
+        ++done;
+        status = OZ_LEAF_IDLE;
+        if (lane == 0) t.leaf_status[g] = OZ_LEAF_IDLE;    // nothing pending if the cap ends the loop here
+        wave_sync();
+    }
+    if (lane == 0) sims_done[g] = done;
+}
 
 // RandomOthelloAgent.play (agents.py:20-24) for every live game whose mover is `side`: random.choice over the valid
 // actions in ascending row-major order -> the RNG_TIE stream (the fixture generator patches random.choice to it)
@@ -769,6 +827,8 @@ struct oz_selfplay {
     oz_mcts* m = nullptr;
     oz_net* net = nullptr;
     GamesDev gm;
+    int* d_sims_done = nullptr;      // free-running mode: simulations completed for the move in progress, per game
+    int mode = 0;                    // 0 fresh, 1 driven by oz_selfplay_run (lock step), 2 by oz_selfplay_run_steps (free-running)
     std::vector<void*> allocs;
     std::mutex mu;
     long long records_read = 0;
@@ -828,6 +888,8 @@ OZ_API int oz_selfplay_create(oz_selfplay** out, const oz_selfplay_config* cfg, 
     const long long rcap = cfg->record_cap > 0 ? cfg->record_cap : (long long)cfg->num_games * 64 * 4;
     int rc = mcts_create(&sp->m, cfg->n, cfg->num_games, node_cap, edge_cap, cfg->c, cfg->q_mode);
     if (!rc) rc = games_alloc(sp, cfg->num_games, cfg->n, rcap);
+    if (!rc) rc = sp->alloc(&sp->d_sims_done, cfg->num_games);
+    if (!rc && hipMemset(sp->d_sims_done, 0, sizeof(int) * cfg->num_games) != hipSuccess) rc = OZ_ERR_HIP;
     if (!rc) {
         sp->gm.seed = cfg->seed; sp->gm.id_stride = cfg->game_id_stride ? cfg->game_id_stride : (uint64_t)cfg->num_games;
         sp->gm.temperature = cfg->temperature; sp->gm.e_greedy = cfg->e_greedy; sp->gm.refill = cfg->refill;
@@ -859,12 +921,39 @@ OZ_API int oz_selfplay_run(oz_selfplay* sp, int rounds) {
     std::lock_guard<std::mutex> lkn(sp->net->mu);
     oz_mcts* m = sp->m;
     hipSetDevice(m->device);
+    OZ_REQUIRE(sp->mode != 2, "oz_selfplay_run after oz_selfplay_run_steps: moves are in progress (use one driver per engine)");
+    sp->mode = 1;
     const int G = sp->gm.G;
     for (int r = 0; r < rounds; ++r) {
         hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, m->stream, sp->gm, m->d, 0);
         for (int s = 0; s < sp->cfg.sims; ++s)
             if (int rc = mcts_step_async(m, sp->net, true)) return rc;
         hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, m->stream, sp->gm, m->d, 0);
+        OZ_HIP(hipGetLastError());
+        if (m->pending.size() > 4096) { if (int rc = mcts_collect_eval_time(m)) return rc; }
+    }
+    return OZ_OK;
+}
+
+OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
+    OZ_REQUIRE(sp, "null selfplay");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    std::lock_guard<std::mutex> lkn(sp->net->mu);
+    oz_mcts* m = sp->m;
+    hipSetDevice(m->device);
+    MctsDev& d = m->d;
+    if (sp->mode == 1) OZ_HIP(hipMemsetAsync(d.leaf_status, 0, sizeof(int) * d.G, m->stream));    // no simulation is pending after whole rounds
+    sp->mode = 2;
+    for (int i = 0; i < steps; ++i) {
+        hipLaunchKernelGGL(k_advance, dim3(d.G), dim3(64), 0, m->stream, sp->gm, d, sp->cfg.sims, sp->d_sims_done);
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, m->stream, d);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1));
+        OZ_HIP(hipEventRecord(e0, m->stream));
+        if (int rc = oz_net_forward_device(sp->net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, m->stream)) return rc;
+        OZ_HIP(hipEventRecord(e1, m->stream));
+        m->pending.push_back({e0, e1});
+        hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, m->stream, d, 0);
         OZ_HIP(hipGetLastError());
         if (m->pending.size() > 4096) { if (int rc = mcts_collect_eval_time(m)) return rc; }
     }

@@ -105,6 +105,14 @@ class SelfPlayEngine:
         if sync:
             self.sync()
 
+    def run_steps(self, steps, sync=True):
+        """free-running form of run(): `steps` network batches; every live game plays on by itself (its move when the
+        simulations of the move are complete, simulations that need no network, the next first-visit leaf), so batches stay
+        full; per game the simulations / moves / records are exactly those of run()"""
+        _lib.check(_lib.load().oz_selfplay_run_steps(self._h, int(steps)))
+        if sync:
+            self.sync()
+
     def sync(self):
         _lib.check(_lib.load().oz_selfplay_sync(self._h))
 

@@ -745,3 +745,39 @@ def test_game_sharding_does_not_change_the_pooled_records(oz):
         b = pooled2[pooled2["game_id"] == gid]
         b = b[np.argsort(b["ply"])]
         assert a.tobytes() == b.tobytes(), gid
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,sims,T,keep", [(6, 20, 1.0, 0), (8, 12, 1.0, 0), (6, 9, 0.0, 0x3), (8, 30, 1.0, 0)])
+def test_free_running_selfplay_equals_lock_step(oz, n, sims, T, keep):
+    """oz_selfplay_run_steps (every game runs on by itself; full leaf batches) produces exactly the move records of the
+    lock-step oz_selfplay_run -- first generation and refilled games -- and needs fewer network batches"""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    G = 48
+    def make():
+        return SelfPlayEngine(StubNetWrapper((n, n), 71, keep, max_batch=G), n, G, sims, 1.0, T, 0.9, seed=13, first_game_id=100,
+                              game_id_stride=G, refill=True, record_cap=G * 6 * n * n)
+    lock = make()
+    rounds = 2 * (n * n - 4) + 4                               # two generations
+    lock.run(rounds)
+    rl = lock.records()
+    free = make()
+    steps = 0
+    while True:
+        free.run_steps(50)
+        steps += 50
+        st = free.stats()
+        if st["games_completed"] >= 2 * G or steps > rounds * sims * 2:
+            break
+    rf = free.records()
+    both = sorted(set(int(x) for x in np.unique(rl["game_id"])) & set(int(x) for x in np.unique(rf["game_id"])))
+    assert len(both) >= G + G // 2, (len(both), steps)
+    for gid in both:
+        a, b = rl[rl["game_id"] == gid], rf[rf["game_id"] == gid]
+        assert a.tobytes() == b.tobytes(), gid
+    sl, sf = lock.stats(), free.stats()
+    assert sf["overflow"] == 0 and sl["overflow"] == 0
+    # the free-running driver wastes no batch slot on network-free simulations
+    ev = free.eval_time()
+    assert sf["expansions"] / max(ev["launches"], 1) > 0.9 * G or sf["live_games"] < G
