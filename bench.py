@@ -54,7 +54,10 @@ def roofline(precision, achieved, conv2_ms, launches, expansions, n, channels):
         r.update(kernel="k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)",
                  peak=PEAK_F32_MATRIX_TFLOPS, frac=achieved / PEAK_F32_MATRIX_TFLOPS)
     else:
-        r.update(kernel="k_gemm_h2<H2BigPP> (conv2: 3x3 same, 512->512, implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, 4-phase ping-pong loop)",
+        lut = os.environ.get("OZ_H2_LUT", "1") != "0" and os.environ.get("OZ_H2_PP", "1") != "0"
+        r.update(kernel=("k_gemm_h2<H2BigPPLut> (conv2: 3x3 same, 512->512, implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, "
+                         "4-phase ping-pong loop; A rows gathered from the conv1 pattern table)") if lut else
+                 "k_gemm_h2<H2BigPP> (conv2: 3x3 same, 512->512, implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, 4-phase ping-pong loop)",
                  peak=PEAK_F16_MATRIX_TFLOPS, frac=achieved / PEAK_F16_MATRIX_TFLOPS,
                  mfma_products_per_fp32_product=3, matrix_pipe_tflops=3 * achieved,
                  matrix_pipe_frac=3 * achieved / PEAK_F16_MATRIX_TFLOPS,

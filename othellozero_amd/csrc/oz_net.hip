@@ -360,6 +360,10 @@ struct OnnNet : oz_net {
     float* d_partial = nullptr;      // split-K slabs [4][max_batch][1024]
     float* d_part32 = nullptr;       // precision f32, max_batch <= 32: split-K slabs of the latency path
     uint4* d_zero = nullptr;
+    // conv1 as a lookup (H2BigPPLut): the OZ_LUT_ROWS possible conv1 output rows and the per-pixel pattern ids of a batch
+    uint4* d_lut = nullptr;
+    unsigned short* d_lut_ids = nullptr;
+    bool lut_ok = false;
     bool h2_attr_set = false;
     std::vector<void*> allocs;
     // profiling of the dominant launch (conv2)
@@ -418,7 +422,8 @@ struct OnnNet : oz_net {
     // layer: 1..3 = conv2..4 (3x3, Cin = N = C), 4 = fc1, 5 = fc2 (taps 1)
     template <typename CF>
     int launch_gemm_h2(const void* in, int layer, void* out, int out_h2, const int* d_count, int max_count, int Hin,
-                       int Hout, int pad, int Cin, int taps, int N, hipStream_t s, int ksplit = 1) {
+                       int Hout, int pad, int Cin, int taps, int N, hipStream_t s, int ksplit = 1,
+                       const unsigned short* lut_ids = nullptr) {
         H2Geom g;
         g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.out_h2 = out_h2; g.relu = 1;
         g.ksplit = ksplit; g.slab = (long long)max_batch * Hout * Hout * N;
@@ -431,13 +436,15 @@ struct OnnNet : oz_net {
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Big>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Big::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2BigPP::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2MidPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2MidPP::LDS));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPPLut>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       H2BigPPLut::LDS + 9 * H2BigPPLut::BM * 2));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Mid>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Mid::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Thin>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Thin::LDS));
             h2_attr_set = true;
         }
-        hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS, s, (const uint4*)in, (const uint4*)d_wh[layer - 1],
-                           d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag);
+        hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS + (CF::LUT ? 9 * CF::BM * 2 : 0), s, (const uint4*)in,
+                           (const uint4*)d_wh[layer - 1], d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag, lut_ids);
         if (ksplit > 1) {
             const long long threads = (long long)max_count * Hout * Hout * (N / 8);
             hipLaunchKernelGGL(k_splitk_reduce_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)d_partial,
@@ -461,9 +468,18 @@ struct OnnNet : oz_net {
 
     int forward_h2(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi, float* d_v,
                    hipStream_t s) {
-        const long long threads = (long long)max_count * n * (C / 8);       // one thread per (board row, 8 channels)
-        hipLaunchKernelGGL(k_conv1_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, C,
-                           d_w1, d_scale[0], d_shift[0], (uint4*)act1, d_flag);
+        static const bool pp = !(getenv("OZ_H2_PP") && atoi(getenv("OZ_H2_PP")) == 0);    // ping-pong main loop (default); OZ_H2_PP=0 selects the one-barrier-per-tile loop for A/B runs
+        // conv1 folded into conv2's A gather (default for the batched engines); OZ_H2_LUT=0 runs the conv1 kernel instead
+        static const bool lut_env = !(getenv("OZ_H2_LUT") && atoi(getenv("OZ_H2_LUT")) == 0);
+        const bool use_lut = pp && lut_env && lut_ok && max_batch > 32;
+        if (use_lut) {
+            const long long threads = (long long)max_count * n * n;
+            hipLaunchKernelGGL(k_lut_ids, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, d_lut_ids);
+        } else {
+            const long long threads = (long long)max_count * n * (C / 8);       // one thread per (board row, 8 channels)
+            hipLaunchKernelGGL(k_conv1_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, C,
+                               d_w1, d_scale[0], d_shift[0], (uint4*)act1, d_flag);
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && pending.size() > 4096) { if (int rc = collect_profile()) return rc; }
         if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); OZ_HIP(hipEventRecord(e0, s)); }
@@ -481,12 +497,12 @@ struct OnnNet : oz_net {
             OZ_HIP(hipGetLastError());
             return OZ_OK;
         }
-        static const bool pp = !(getenv("OZ_H2_PP") && atoi(getenv("OZ_H2_PP")) == 0);    // ping-pong main loop (default); OZ_H2_PP=0 selects the one-barrier-per-tile loop for A/B runs
         // medium networks (arenas, evaluation batches, the loop's 100 episodes): a convolution whose grid would leave most
         // CUs idle splits its k loop (conv_ksplit: from max_batch, a per-network constant; 1 at the bench's 4096 games)
         const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), 192), k4 = conv_ksplit((n - 4) * (n - 4), 256);
-        if (int rc = pp ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)
-                        : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)) return rc;
+        if (int rc = use_lut ? launch_gemm_h2<H2BigPPLut>(d_lut, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2, d_lut_ids)
+                     : pp    ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)
+                             : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)) return rc;
         if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
         if (int rc = pp ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                         : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
@@ -693,6 +709,22 @@ OZ_API int oz_net_commit(oz_net* net) {
         if (!o->d_partial) { if (int rc = o->alloc(&o->d_partial, o->partial_floats())) return rc; }
         if (!o->d_zero) { if (int rc = o->alloc(&o->d_zero, 16)) return rc; }
         OZ_HIP(hipMemset(o->d_zero, 0, 256));
+        if (o->max_batch > 32) {
+            // conv1 pattern table (k_lut_build): OZ_LUT_ROWS rows of C channels in the h2 layout; a table entry beyond the
+            // fp16 range disables the table for this network (the conv1 kernel then raises the flag on real positions)
+            const size_t row_q = (size_t)C / 4;                                  // uint4 per row
+            if (!o->d_lut) { if (int rc = o->alloc(&o->d_lut, (size_t)OZ_LUT_ROWS * row_q)) return rc; }
+            if (!o->d_lut_ids) { if (int rc = o->alloc(&o->d_lut_ids, (size_t)o->max_batch * n * n)) return rc; }
+            OZ_HIP(hipMemset(o->d_lut + (size_t)OZ_LUT_PATTERNS * row_q, 0, row_q * sizeof(uint4)));
+            const long long threads = (long long)OZ_LUT_PATTERNS * (C / 8);
+            hipLaunchKernelGGL(k_lut_build, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, C, o->d_w1, o->d_scale[0], o->d_shift[0],
+                               o->d_lut, o->d_flag);
+            OZ_HIP(hipGetLastError());
+            int over = 0;
+            OZ_HIP(hipMemcpy(&over, o->d_flag, sizeof(int), hipMemcpyDeviceToHost));
+            o->lut_ok = !over;
+            OZ_HIP(hipMemset(o->d_flag, 0, sizeof(int)));
+        }
     }
     if (int rc = upload(o, &o->d_wpi, o->w[36])) return rc;
     if (int rc = upload(o, &o->d_bpi, o->w[37])) return rc;

@@ -74,12 +74,20 @@ template <int NWM, int NWN, int NTI, int NTJ> struct H2Cfg {
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
     static_assert(NW * SLICE <= LDS, "epilogue slices must fit in the staging buffers");
     static constexpr bool PP = false;     // main loop: false = one barrier per k-tile; true = 4-phase ping-pong (H2BigPP)
+    static constexpr bool LUT = false;    // A rows gathered from the conv1 pattern table (H2BigPPLut), see k_lut_build
 };
 typedef H2Cfg<2, 4, 4, 2> H2Big;      // conv2, conv4: 256 x 256
 // the same tile with the ping-pong main loop: the two wave rows (= the two waves of every SIMD) run half a phase
 // apart, so one of them is in its MFMA cluster while the other issues LDS reads and LDS-DMA (see k_gemm_h2)
 struct H2BigPP : H2Cfg<2, 4, 4, 2> { static constexpr bool PP = true; };
 struct H2MidPP : H2Cfg<2, 4, 3, 2> { static constexpr bool PP = true; };
+// conv2 with conv1 folded into a lookup: the conv1 + BN + ReLU output of a pixel depends only on the 3 x 3 neighbourhood
+// of the position (9 cells, each empty / own / opponent: 3^9 = 19683 patterns), so conv2's A rows are LDS-DMA'd straight
+// from a table of the 19683 possible rows (+ one zero row for taps outside the board) instead of from a conv1 output
+// buffer: no conv1 kernel, no act1 round trip, and the 40 MB table is re-read from L2 / MALL instead of streamed.
+struct H2BigPPLut : H2BigPP { static constexpr bool LUT = true; };
+#define OZ_LUT_PATTERNS 19683
+#define OZ_LUT_ROWS (OZ_LUT_PATTERNS + 1)  // row OZ_LUT_PATTERNS = zeros
 typedef H2Cfg<2, 4, 3, 2> H2Mid;      // conv3 (M = B*36): 192 x 256 -> 1536 blocks = 6.0 rounds of 256 CUs (256 x 256: 4.5)
 typedef H2Cfg<2, 2, 2, 2> H2Small;    // 128 x 128
 typedef H2Cfg<1, 2, 2, 2> H2Thin;     // dense layers (M = batch): 64 x 128, 2 waves -> 512 / 256 blocks at B = 4096
@@ -224,13 +232,78 @@ __global__ __launch_bounds__(256) void k_conv1_h2(const uint64_t* __restrict__ o
     if (over) atomicOr(flag, 1);
 }
 
+// pattern id of every pixel: sum over the 3 x 3 neighbourhood (ky, kx) of 3^(ky*3+kx) * {0 empty or off the board, 1 own, 2 opponent}
+__global__ __launch_bounds__(256) void k_lut_ids(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
+                                                 const int* __restrict__ d_count, int n, unsigned short* __restrict__ ids) {
+    const int P = n * n;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)(*d_count) * P) return;
+    const int b = (int)(idx / P), pix = (int)(idx % P), y = pix / n, x = pix % n;
+    const uint64_t o = own[b], p = opp[b];
+    unsigned id = 0, pw = 1;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = y + ky - 1, ix = x + kx - 1;
+            if (iy >= 0 && iy < n && ix >= 0 && ix < n) {
+                const int bit = iy * 8 + ix;
+                id += pw * ((unsigned)((o >> bit) & 1) + 2u * (unsigned)((p >> bit) & 1));
+            }
+            pw *= 3;
+        }
+    ids[idx] = (unsigned short)id;
+}
+
+// table[id] = the h2 row k_conv1_h2 writes for a pixel whose neighbourhood is pattern id: the same fmaf sequence (taps in
+// ky, kx order, own plane then opponent plane; a tap k_conv1_h2 skips as off-board is an exact no-op fmaf(0, w, acc) here),
+// the same scale / shift / ReLU / split -- bit-identical rows.  One thread per (pattern, 8 channels).
+__global__ __launch_bounds__(256) void k_lut_build(int C, const float* __restrict__ W /*[9][2][C]*/, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, uint4* __restrict__ table, int* __restrict__ flag) {
+    const int cg = C >> 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long id = idx / cg;
+    if (id >= OZ_LUT_PATTERNS) return;
+    const int c8 = (int)(idx % cg) * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    unsigned rest = (unsigned)id;
+    for (int t = 0; t < 9; ++t) {
+        const unsigned cell = rest % 3; rest /= 3;
+        const float a0 = cell == 1 ? 1.f : 0.f, a1 = cell == 2 ? 1.f : 0.f;
+        const float* w0 = W + (size_t)(t * 2 + 0) * C + c8;
+        const float* w1 = W + (size_t)(t * 2 + 1) * C + c8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(a0, w0[j], acc[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(a1, w1[j], acc[j]);
+    }
+    f16x8 h1, h2;
+    bool over = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = fmaxf(fmaf(acc[j], scale[c8 + j], shift[c8 + j]), 0.f);
+        over |= v > H2_F16_MAX;
+        _Float16 a, bb;
+        h2_split(v, a, bb);
+        h1[j] = a; h2[j] = bb;
+    }
+    uint4* dst = table + ((size_t)id * cg + (c8 >> 3)) * 2;
+    dst[0] = *reinterpret_cast<uint4*>(&h1);
+    dst[1] = *reinterpret_cast<uint4*>(&h2);
+    if (over) atomicOr(flag, 1);
+}
+
 // out[M][N] = act((A[M][K] . W[N][K]^T) * scale + shift); A and W in the h2 layout; M = *d_count * Hout^2.
+// CF::LUT: `in` is the pattern table, lut_ids the per-pixel pattern ids [batch][Hin^2] (k_lut_ids).
 // zero_line: >= 128 B of zeros in global memory (source of out-of-image taps and of rows beyond M).
 template <typename CF>
 __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__ in, const uint4* __restrict__ Wh,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        void* __restrict__ out, const int* __restrict__ d_count, H2Geom g,
-                                                       int num_mt, const uint4* __restrict__ zero_line, int* __restrict__ flag) {
+                                                       int num_mt, const uint4* __restrict__ zero_line, int* __restrict__ flag,
+                                                       const unsigned short* __restrict__ lut_ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = CF::BM, BN = CF::BN, IA = CF::IA, IB = CF::IB;
     constexpr int RI = CF::TI * 2, RJ = CF::TJ * 2;           // 16-row / 16-column MFMA tiles per wave
@@ -271,8 +344,29 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     long long aidx[IA];      // uint4 index of (row's input pixel at tap (0,0), logical chunk)
     unsigned amask[IA];
     unsigned bidx[IB];
+    // CF::LUT: lut[tap * BM + row] = table row of (tile row, tap) -- the pattern id of the tap's pixel, or the zero row
+    unsigned short* lut = reinterpret_cast<unsigned short*>(smem + CF::LDS);
+    const int l8 = lane >> 3, lcb = (lane & 7) ^ ((l8 >> 1) & 1);   // piece rows start at multiples of 8: h2_swz(row0 + l8) = (row0 & 8 ? 6 : 0) | (l8 >> 1 & 1)
+    if constexpr (CF::LUT) {
+        for (int e = tid; e < 9 * BM; e += CF::NT) {
+            const int tap = e / BM, row = e - tap * BM;
+            const long long m = (long long)mt * BM + row;
+            unsigned id = OZ_LUT_PATTERNS;
+            if (m < M) {
+                const int b = (int)(m / P), pix = (int)(m % P), iy = pix / g.Hout - g.pad + tap / 3, ix = pix % g.Hout - g.pad + tap % 3;
+                if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Hin) id = lut_ids[(size_t)b * g.Hin * g.Hin + iy * g.Hin + ix];
+            }
+            lut[e] = (unsigned short)id;
+        }
+        __syncthreads();
+    }
+    // source of A piece i for (tap, channel slice) given the piece's table row (LUT configs)
+    auto lut_src = [&](int i, unsigned id, int slice) -> const uint4* {
+        return in + (id * (unsigned)rowq + (unsigned)(lcb ^ (((a_row0(i) >> 3) & 1) * 6)) + (unsigned)(slice * 8));
+    };
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
+        if constexpr (CF::LUT) { aidx[i] = 0; amask[i] = 0; continue; }
         const int row = a_row0(i) + (lane >> 3);
         const int lc = (lane & 7) ^ h2_swz(row);
         const long long m = (long long)mt * BM + row;
@@ -308,7 +402,9 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
 #endif
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            const uint4* ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + toff) : zsrc;
+            const uint4* ga;
+            if constexpr (CF::LUT) ga = lut_src(i, lut[tap * BM + a_row0(i) + l8], slice);
+            else ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + toff) : zsrc;
             __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la + a_row0(i) * 128), 16, 0, 0);
         }
 #pragma unroll
@@ -355,6 +451,7 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         f16x8 fa1[HA], fa2[HA], fb1[4], fb2[4];
+        unsigned aid[IA] = {};
         {   // B n0 of the first tile (later tiles get it in phase 4 of the tile before)
             const unsigned char* Bt0 = smem + CF::TILEA + (wn * RJ * 16 + r16) * 128;
 #pragma unroll
@@ -382,8 +479,17 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
             const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * RI * 16 + r16) * 128;
             const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
             auto dma_a = [&](int i) {
-                const uint4* ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + toff) : zsrc;
+                const uint4* ga;
+                if constexpr (CF::LUT) ga = lut_src(i, aid[i], slice);
+                else ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + toff) : zsrc;
                 __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la + a_row0(i) * 128), 16, 0, 0);
+            };
+            // LUT: the table rows of the tile being staged, read in phase 1 (retired by its lgkmcnt(0)), used in phases 2 and 4
+            auto ld_ids = [&]() {
+                if constexpr (CF::LUT) {
+#pragma unroll
+                    for (int i = 0; i < IA; ++i) aid[i] = lut[tap * BM + a_row0(i) + l8];
+                }
             };
             auto dma_b = [&](int i) {
                 __builtin_amdgcn_global_load_lds((h2_gptr)(Wh + bidx[i] + ktc * 8), (h2_lptr)(lb + b_row0(i) * 128), 16, 0, 0);
@@ -458,7 +564,7 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
             ldb(0, Btn);                                     // after M_B: quadrant (m1, n0) is done; retired by the vmcnt of L_B
 #else
             constexpr int KEEP = IA == 4 ? 4 : 3;
-            lda(0); dma_b(0); dma_b(1); l_end(integral_constant<int, KEEP>{}); mma(0, 0); m_end();               // phase 1
+            lda(0); ld_ids(); dma_b(0); dma_b(1); l_end(integral_constant<int, KEEP>{}); mma(0, 0); m_end();     // phase 1
             ldb(1, Bt); dma_a_early(); l_end(integral_constant<int, KEEP>{}); mma(0, 1); m_end();                // phase 2
             lda(1); dma_b(2); dma_b(3); l_end(integral_constant<int, KEEP>{}); mma(1, 0); m_end();               // phase 3
             ldb(0, Btn); dma_a_late(); l_end(integral_constant<int, KEEP>{}); mma(1, 1); m_end();                // phase 4 (B n0 of the next tile)

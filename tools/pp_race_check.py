@@ -1,6 +1,7 @@
 """Race / equivalence screen of the ping-pong conv loop: the one-barrier loop (OZ_H2_PP=0) and the ping-pong loop accumulate
 every output in the same order, so their (pi, v) must be BIT-identical; a DMA-visibility race would show up as a rare
-mismatch.  Runs each loop in its own process over several batch sizes / boards, many repetitions, and compares.
+mismatch.  The same holds for conv1 as a pattern-table lookup inside conv2's gather (default) against the conv1 kernel
+(OZ_H2_LUT=0): the table rows are the rows the kernel would write.  Runs each loop in its own process over several batch sizes / boards, many repetitions, and compares.
     python tools/pp_race_check.py            (on the GPU box)"""
 import os, subprocess, sys
 import numpy as np
@@ -8,27 +9,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = r'''
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
-from othellozero_amd.NNet import NNetWrapper
+from othellozero_amd.NNet import NNetWrapper, NeuralNets
 from othellozero_amd.weights import init_weights
 out = {}
-for n, C, B, reps in ((8, 512, 4096, 12), (8, 512, 1000, 8), (8, 256, 257, 8), (6, 512, 4096, 8), (6, 256, 33, 8), (8, 512, 1, 4)):
-    net = NNetWrapper((n, n), num_channels_1=C, max_batch=B, precision="f16x2",
-                      weights=init_weights(n, seed=3, channels=C, randomize_all=True))
+for n, C, B, reps, cin in ((8, 512, 4096, 12, 2), (8, 512, 1000, 8, 2), (8, 256, 257, 8, 2), (6, 512, 4096, 8, 2), (6, 256, 33, 8, 2),
+                           (8, 512, 1, 4, 2), (8, 512, 777, 4, 1), (6, 512, 100, 4, 1)):
+    net = NNetWrapper((n, n), num_channels_1=C, max_batch=B, precision="f16x2", network=NeuralNets.ONN if cin == 2 else NeuralNets.BNN,
+                      weights=init_weights(n, seed=3, channels=C, randomize_all=True, in_channels=cin))
     rs = np.random.RandomState(n * 1000 + B)
     valid = np.uint64(sum(1 << (r * 8 + c) for r in range(n) for c in range(n)))
     for rep in range(reps):
         own = rs.randint(0, 2**63, size=B, dtype=np.uint64) & valid
         opp = rs.randint(0, 2**63, size=B, dtype=np.uint64) & valid & ~own
         pi, v = net.predict_batch(own, opp)
-        out[f"{n}_{C}_{B}_{rep}_pi"] = pi
-        out[f"{n}_{C}_{B}_{rep}_v"] = v
+        out[f"{n}_{C}_{B}_{cin}_{rep}_pi"] = pi
+        out[f"{n}_{C}_{B}_{cin}_{rep}_v"] = v
 np.savez(sys.argv[2], **out)
 '''
 res = []
-for tag, extra in (("simple", {"OZ_H2_PP": "0"}), ("pingpong", {"OZ_H2_PP": "1"}), ("pingpong_fc1small", {"OZ_H2_PP": "1", "OZ_H2_FC1PP": "0"})):
+for tag, extra in (("simple", {"OZ_H2_PP": "0"}), ("pingpong", {"OZ_H2_PP": "1"}), ("pingpong_fc1small", {"OZ_H2_PP": "1", "OZ_H2_FC1PP": "0"}),
+                   ("pingpong_conv1kernel", {"OZ_H2_PP": "1", "OZ_H2_LUT": "0"})):
     path = f"/tmp/pp_race_{tag}.npz"
     subprocess.run([sys.executable, "-c", WORKER, ROOT, path], env=dict(os.environ, **extra), check=True, timeout=600)
     res.append(np.load(path))
-bad = [k for k in res[0].files if not (np.array_equal(res[0][k], res[1][k]) and np.array_equal(res[0][k], res[2][k]))]
-print(f"{len(res[0].files)} arrays x 3 loop configurations compared, {len(bad)} differ", bad[:5])
+bad = [k for k in res[0].files if not all(np.array_equal(res[0][k], r[k]) for r in res[1:])]
+print(f"{len(res[0].files)} arrays x {len(res)} loop configurations compared, {len(bad)} differ", bad[:5])
 sys.exit(1 if bad else 0)
