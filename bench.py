@@ -30,35 +30,43 @@ FLOP_PER_EXPANSION = {8: 566428672, 6: 270185472}          # SURVEY.md 8(d), who
 PEAK_F32_MATRIX_TFLOPS = 157.3                             # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 
 
-def conv2_flop_per_leaf(n, C):
-    return 2 * (n * n) * (9 * C) * C                       # 8x8: 301 989 888 FLOP
+def conv_flop_per_leaf(layer, n, C):
+    """implicit-GEMM FLOP of conv2 (layer 2: n x n outputs) / conv3 (layer 3: (n-2) x (n-2) outputs) per leaf"""
+    px = n * n if layer == 2 else (n - 2) * (n - 2)
+    return 2 * px * (9 * C) * C                            # 8x8: conv2 301 989 888, conv3 169 869 312 FLOP
 
 
 PEAK_F16_MATRIX_TFLOPS = 2500.0                            # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16 MFMA
 
 
-def roofline(precision, achieved, conv2_ms, launches, expansions, n, channels):
-    """Dominant kernel = the conv2 launch (53 % of the network's FLOPs).  `achieved` is ALGORITHMIC fp32 TFLOP/s
-    (2*M*K*N per launch / HIP-event time on the launch stream).  precision f32: v_mfma_f32_32x32x2_f32, peak 157.3.
-    precision f16x2: every fp32 product costs 3 fp16 MFMA products, so the matrix pipe executes 3x `achieved`;
-    both fractions are reported against the 2.5 PFLOP/s dense fp16 peak."""
+def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, channels):
+    """Dominant kernel.  precision f32: the conv2 implicit GEMM (53 % of the network's FLOPs).  precision f16x2 (default):
+    conv1 + conv2 run as a table gather-sum (k_conv2_lut, ~0.15 ms), so the dominant launch is the conv3 implicit GEMM
+    (64 % of the FLOPs that are left).  `achieved` is ALGORITHMIC fp32 TFLOP/s (2*M*K*N per launch / HIP-event time on
+    the launch stream).  f32: v_mfma_f32_32x32x2_f32, peak 157.3.  f16x2: every fp32 product costs 3 fp16 MFMA
+    products, so the matrix pipe executes 3x `achieved`; both fractions are reported against the 2.5 PFLOP/s dense fp16 peak."""
     hbm = None
     try:      # HBM-side bytes per leaf from the committed PMC profile of this kernel (profiles/), scaled per launch
-        tj = json.load(open(os.path.join(ROOT, "profiles", f"conv2_traffic_{precision}.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", f"conv{layer}_traffic_{precision}.json")))
         hbm = tj["hbm_bytes_per_leaf"] * expansions / max(launches, 1)
     except Exception:
         pass
     r = {"bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "traffic": hbm, "launches": int(launches),
-         "avg_launch_ms": conv2_ms / max(launches, 1), "flop_per_leaf": conv2_flop_per_leaf(n, channels)}
+         "avg_launch_ms": layer_ms / max(launches, 1), "flop_per_leaf": conv_flop_per_leaf(layer, n, channels)}
     if precision == "f32":
         r.update(kernel="k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)",
                  peak=PEAK_F32_MATRIX_TFLOPS, frac=achieved / PEAK_F32_MATRIX_TFLOPS)
     else:
-        lut = os.environ.get("OZ_H2_LUT", "1") != "0" and os.environ.get("OZ_H2_PP", "1") != "0"
-        r.update(kernel=("k_gemm_h2<H2BigPPLut> (conv2: 3x3 same, 512->512, implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, "
-                         "4-phase ping-pong loop; A rows gathered from the conv1 pattern table)") if lut else
-                 "k_gemm_h2<H2BigPP> (conv2: 3x3 same, 512->512, implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, 4-phase ping-pong loop)",
-                 peak=PEAK_F16_MATRIX_TFLOPS, frac=achieved / PEAK_F16_MATRIX_TFLOPS,
+        pp = os.environ.get("OZ_H2_PP", "1") != "0"
+        lut = os.environ.get("OZ_H2_LUT", "1") != "0" and pp
+        tail = "implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, " + ("4-phase ping-pong loop" if pp else "one barrier per k-tile")
+        if layer == 3:
+            kernel = f"k_gemm_h2<{'H2MidPP' if pp else 'H2Mid'}> (conv3: 3x3 valid, 512->512, 8x8 -> 6x6, {tail}); conv1 + conv2 = k_conv2_lut table gather-sum"
+        elif lut:
+            kernel = f"k_gemm_h2<H2BigPPLut> (conv2: 3x3 same, 512->512, {tail}; A rows gathered from the conv1 pattern table)"
+        else:
+            kernel = f"k_gemm_h2<{'H2BigPP' if pp else 'H2Big'}> (conv2: 3x3 same, 512->512, {tail})"
+        r.update(kernel=kernel, peak=PEAK_F16_MATRIX_TFLOPS, frac=achieved / PEAK_F16_MATRIX_TFLOPS,
                  mfma_products_per_fp32_product=3, matrix_pipe_tflops=3 * achieved,
                  matrix_pipe_frac=3 * achieved / PEAK_F16_MATRIX_TFLOPS,
                  vs_fp32_matrix_peak=achieved / PEAK_F32_MATRIX_TFLOPS)
@@ -183,7 +191,8 @@ def main():
     dt = time.perf_counter() - t0
     s1 = eng.stats()
     ev1 = eng.eval_time()
-    conv2_ms, conv2_launches = net.profile_read()
+    conv2_ms, conv2_launches = net.profile_read()               # the dominant launch: conv2, or conv3 when conv2 is a gather-sum
+    layer = net.profiled_layer()
 
     d = {k: s1[k] - s0[k] for k in ("simulations", "expansions", "terminal_hits", "node_visits", "moves", "games_completed")}
     vec = torch.tensor([d["expansions"], d["simulations"], d["games_completed"], d["moves"], d["node_visits"]],
@@ -196,8 +205,11 @@ def main():
     exp_all, sims_all, games_all, moves_all, visits_all = (float(x) for x in vec.tolist())
 
     if rank == 0:
-        flop_conv2 = d["expansions"] * conv2_flop_per_leaf(n, args.channels)
+        flop_conv2 = d["expansions"] * conv_flop_per_leaf(layer, n, args.channels)
         achieved = flop_conv2 / (conv2_ms * 1e-3) / 1e12 if conv2_ms > 0 else 0.0
+        # FLOP the GPU executes per expansion: the reference network's, minus conv1 + conv2 when they run as table lookups
+        flop_ref = FLOP_PER_EXPANSION.get(n, 0)
+        flop_exec = flop_ref - (conv_flop_per_leaf(2, n, args.channels) + 2 * n * n * 18 * args.channels if layer == 3 else 0)
         nn_ms = ev1["ms"] - ev0["ms"]
         out = {
             "metric": "mcts_node_expansions_per_sec", "value": exp_all / dt, "unit": "node-expansions/s",
@@ -218,8 +230,10 @@ def main():
             "expansions_per_sim": exp_all / max(sims_all, 1), "node_visits_per_sim": visits_all / max(sims_all, 1),
             "pooled_records": int(pooled.shape[0]),
             "nn_forward_ms_total_rank0": nn_ms, "nn_fraction_of_wall_rank0": nn_ms * 1e-3 / dt,
-            "whole_net_tflops_rank0": d["expansions"] * FLOP_PER_EXPANSION.get(n, 0) / max(nn_ms * 1e-3, 1e-9) / 1e12,
-            "roofline": roofline(args.precision, achieved, conv2_ms, conv2_launches, d["expansions"], n, args.channels),
+            "whole_net_tflops_rank0": d["expansions"] * flop_exec / max(nn_ms * 1e-3, 1e-9) / 1e12,
+            "flop_per_expansion": {"reference_network": flop_ref, "executed": flop_exec,
+                                   "note": "executed < reference when conv1 + conv2 are evaluated as pattern-table lookups (exact refactoring, no GEMM)"},
+            "roofline": roofline(args.precision, layer, achieved, conv2_ms, conv2_launches, d["expansions"], n, args.channels),
             # the tree / rules side is latency-bound integer work, ~1.3 KB of algorithmic HBM bytes per simulation
             "tree_side_hbm": {"bytes_per_sim": 1300, "achieved_GBps": sims_all / dt * 1300 / 1e9, "peak_GBps": 8000.0,
                               "frac": sims_all / dt * 1300 / 8e12, "note": "not the binding roof; reported per SURVEY 8(d)"},

@@ -88,9 +88,11 @@ int oz_net_commit(oz_net* net);
 int oz_net_predict(oz_net* net, const uint64_t* own, const uint64_t* opp, int count, float* pi, float* v);
 /* timing hook for bench.py: run the forward `iters` times on `count` resident boards, return avg ms per forward (HIP events) */
 int oz_net_time_forward(oz_net* net, int count, int iters, float* ms_avg);
-/* HIP-event timing of the dominant launch (conv2 implicit GEMM) on the stream it is launched on */
+/* HIP-event timing of the dominant launch on the stream it is launched on: the conv2 implicit GEMM, or -- precision
+ * f16x2, where conv1 + conv2 run as a table gather-sum -- the conv3 implicit GEMM; oz_net_profiled_layer says which (2 / 3) */
 int oz_net_profile(oz_net* net, int enable);
 int oz_net_profile_read(oz_net* net, double* conv2_ms_total, int64_t* conv2_launches);
+int oz_net_profiled_layer(oz_net* net, int* layer);
 
 /* ------------------------------------------------------------------ search
  * OthelloMCTS / MCTS (othelo_mcts.py:9-88, MCTS/__init__.py:19-187): num_games independent

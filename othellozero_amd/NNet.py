@@ -187,6 +187,12 @@ class NNetWrapper(_NetHandle):
         _lib.check(_lib.load().oz_net_profile_read(self._h, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def profiled_layer(self):
+        """which launch profile_read() timed: 2 = the conv2 GEMM, 3 = the conv3 GEMM (f16x2: conv1 + conv2 are a table gather-sum)"""
+        layer = C.c_int()
+        _lib.check(_lib.load().oz_net_profiled_layer(self._h, C.byref(layer)))
+        return layer.value
+
 
 class StubNetWrapper(_NetHandle):
     """Device-side deterministic test network (integer hash of the board; formula: oracle/oz_oracle.c

@@ -364,12 +364,15 @@ struct OnnNet : oz_net {
     uint4* d_lut = nullptr;
     unsigned short* d_lut_ids = nullptr;
     bool lut_ok = false;
+    float* d_t2 = nullptr;           // conv2 as a gather-sum (k_conv2_lut): [9][OZ_LUT_PATTERNS][C]
+    bool t2_ok = false;
     bool h2_attr_set = false;
     std::vector<void*> allocs;
     // profiling of the dominant launch (conv2)
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double conv2_ms = 0; long long conv2_launches = 0;
+    int profiled_layer = 2;          // 2 = conv2 GEMM, 3 = conv3 GEMM (when conv2 runs as the table gather-sum)
 
     template <typename T> int alloc(T** p, size_t count) {
         OZ_HIP(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
@@ -423,9 +426,10 @@ struct OnnNet : oz_net {
     template <typename CF>
     int launch_gemm_h2(const void* in, int layer, void* out, int out_h2, const int* d_count, int max_count, int Hin,
                        int Hout, int pad, int Cin, int taps, int N, hipStream_t s, int ksplit = 1,
-                       const unsigned short* lut_ids = nullptr) {
+                       const unsigned short* lut_ids = nullptr, const uint4* w_alt = nullptr, const float* scale_alt = nullptr,
+                       const float* shift_alt = nullptr, int relu = 1) {
         H2Geom g;
-        g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.out_h2 = out_h2; g.relu = 1;
+        g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.out_h2 = out_h2; g.relu = relu;
         g.ksplit = ksplit; g.slab = (long long)max_batch * Hout * Hout * N;
         const long long Mmax = (long long)max_count * Hout * Hout;
         const int num_mt = (int)((Mmax + CF::BM - 1) / CF::BM);
@@ -444,7 +448,8 @@ struct OnnNet : oz_net {
             h2_attr_set = true;
         }
         hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS + (CF::LUT ? 9 * CF::BM * 2 : 0), s, (const uint4*)in,
-                           (const uint4*)d_wh[layer - 1], d_scale_h2[layer - 1], d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag, lut_ids);
+                           w_alt ? w_alt : (const uint4*)d_wh[layer - 1], scale_alt ? scale_alt : d_scale_h2[layer - 1],
+                           shift_alt ? shift_alt : d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag, lut_ids);
         if (ksplit > 1) {
             const long long threads = (long long)max_count * Hout * Hout * (N / 8);
             hipLaunchKernelGGL(k_splitk_reduce_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)d_partial,
@@ -452,6 +457,45 @@ struct OnnNet : oz_net {
         }
         OZ_HIP(hipGetLastError());
         return OZ_OK;
+    }
+
+    // T2[t] = table . W_t^T (raw k-sums, scaled 2^kexp like the convolution's): nine GEMMs M = OZ_LUT_PATTERNS, K = N = C
+    int build_t2() {
+        const auto& src = w[6];                                  // conv2 kernel (3,3,C,C): [tap*C + ci][co]
+        float mx = 0.f;
+        for (float x : src) mx = fmaxf(mx, fabsf(x));
+        const int kexp = mx > 0.f ? (int)floorf(log2f(1000.0f / mx)) : 0;     // the same power of two as d_wh[0]
+        std::vector<uint16_t> h((size_t)9 * C * C * 2);
+        for (int t = 0; t < 9; ++t)
+            for (int co = 0; co < C; ++co)
+                for (int ci = 0; ci < C; ++ci) {
+                    const float x = ldexpf(src[((size_t)t * C + ci) * C + co], kexp);
+                    const _Float16 h1 = (_Float16)x, h2 = (_Float16)(x - (float)h1);
+                    const size_t base = (((size_t)t * C + co) * (C / 8) + (ci >> 3)) * 16 + (ci & 7);
+                    memcpy(&h[base], &h1, 2); memcpy(&h[base + 8], &h2, 2);
+                }
+        uint4* d_wtap = nullptr;
+        float *d_one = nullptr, *d_nul = nullptr;
+        int* d_rows = nullptr;
+        OZ_HIP(hipMalloc((void**)&d_wtap, h.size() * 2));
+        OZ_HIP(hipMalloc((void**)&d_one, sizeof(float) * C));
+        OZ_HIP(hipMalloc((void**)&d_nul, sizeof(float) * C));
+        OZ_HIP(hipMalloc((void**)&d_rows, sizeof(int)));
+        std::vector<float> one((size_t)C, 1.0f);
+        const int rows = OZ_LUT_PATTERNS;
+        OZ_HIP(hipMemcpy(d_wtap, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        OZ_HIP(hipMemcpy(d_one, one.data(), sizeof(float) * C, hipMemcpyHostToDevice));
+        OZ_HIP(hipMemset(d_nul, 0, sizeof(float) * C));
+        OZ_HIP(hipMemcpy(d_rows, &rows, sizeof(int), hipMemcpyHostToDevice));
+        if (!d_t2) { if (int rc = alloc(&d_t2, (size_t)9 * OZ_LUT_PATTERNS * C)) return rc; }
+        int rc = OZ_OK;
+        for (int t = 0; t < 9 && rc == OZ_OK; ++t)
+            rc = launch_gemm_h2<H2BigPP>(d_lut, 1, d_t2 + (size_t)t * OZ_LUT_PATTERNS * C, 0, d_rows, rows, 1, 1, 0, C, 1, C, 0, 1, nullptr,
+                                         d_wtap + (size_t)t * C * (C / 4), d_one, d_nul, 0);
+        hipDeviceSynchronize();
+        hipFree(d_wtap); hipFree(d_one); hipFree(d_nul); hipFree(d_rows);
+        if (rc == OZ_OK) t2_ok = true;
+        return rc;
     }
 
     int check() override {
@@ -469,10 +513,15 @@ struct OnnNet : oz_net {
     int forward_h2(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi, float* d_v,
                    hipStream_t s) {
         static const bool pp = !(getenv("OZ_H2_PP") && atoi(getenv("OZ_H2_PP")) == 0);    // ping-pong main loop (default); OZ_H2_PP=0 selects the one-barrier-per-tile loop for A/B runs
-        // conv1 folded into conv2's A gather (default for the batched engines); OZ_H2_LUT=0 runs the conv1 kernel instead
+        // The input planes are discrete, so conv1 (and conv2 behind it) are functions of small neighbourhood patterns:
+        //   OZ_H2_T2  (default on): conv1 + conv2 as a gather-sum over the per-tap tables T2 (k_conv2_lut) -- no GEMM for conv2
+        //   OZ_H2_LUT (default on): when T2 is off, conv1 as a table lookup inside conv2's operand gather (H2BigPPLut; bit-identical
+        //                           to the conv1 kernel); OZ_H2_LUT=0 also implies no T2: conv1 kernel + conv2 GEMM
         static const bool lut_env = !(getenv("OZ_H2_LUT") && atoi(getenv("OZ_H2_LUT")) == 0);
-        const bool use_lut = pp && lut_env && lut_ok && max_batch > 32;
-        if (use_lut) {
+        static const bool t2_env = !(getenv("OZ_H2_T2") && atoi(getenv("OZ_H2_T2")) == 0);
+        const bool use_t2 = lut_env && t2_env && t2_ok;
+        const bool use_lut = !use_t2 && pp && lut_env && lut_ok && max_batch > 32;
+        if (use_t2 || use_lut) {
             const long long threads = (long long)max_count * n * n;
             hipLaunchKernelGGL(k_lut_ids, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, d_lut_ids);
         } else {
@@ -480,40 +529,49 @@ struct OnnNet : oz_net {
             hipLaunchKernelGGL(k_conv1_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, C,
                                d_w1, d_scale[0], d_shift[0], (uint4*)act1, d_flag);
         }
+        // HIP events around the dominant launch: the conv2 GEMM, or conv3 when conv2 is the gather-sum
+        profiled_layer = use_t2 ? 3 : 2;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && pending.size() > 4096) { if (int rc = collect_profile()) return rc; }
-        if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); OZ_HIP(hipEventRecord(e0, s)); }
-        if (max_batch <= 32) {
-            // small networks (the drop-in OthelloMCTS / agents path, one position per call): latency, not throughput --
-            // 128 x 128 tiles with the k loop split 16 ways over otherwise idle CUs, fixed-order reduce (keyed on max_batch,
-            // a per-network constant, so a position's result does not depend on the size of the call)
-            if (int rc = launch_gemm_h2<H2Small>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, 16)) return rc;
-            if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
-            if (int rc = launch_gemm_h2<H2Small>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, 16)) return rc;
-            if (int rc = launch_gemm_h2<H2Small>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, 16)) return rc;
-            if (int rc = launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)) return rc;
-            if (int rc = launch_gemm_h2<H2Thin>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
-            hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
-            OZ_HIP(hipGetLastError());
+        if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); }
+        auto mark = [&](int layer, bool begin) -> int {
+            if (!profile || layer != profiled_layer) return OZ_OK;
+            OZ_HIP(hipEventRecord(begin ? e0 : e1, s));
+            if (!begin) pending.push_back({e0, e1});
             return OZ_OK;
-        }
+        };
+        const bool small = max_batch <= 32;
+        // small networks (the drop-in OthelloMCTS / agents path, one position per call): latency, not throughput --
+        // 128 x 128 tiles with the k loop split 16 ways over otherwise idle CUs, fixed-order reduce (keyed on max_batch,
+        // a per-network constant, so a position's result does not depend on the size of the call)
         // medium networks (arenas, evaluation batches, the loop's 100 episodes): a convolution whose grid would leave most
         // CUs idle splits its k loop (conv_ksplit: from max_batch, a per-network constant; 1 at the bench's 4096 games)
         const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), 192), k4 = conv_ksplit((n - 4) * (n - 4), 256);
-        if (int rc = use_lut ? launch_gemm_h2<H2BigPPLut>(d_lut, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2, d_lut_ids)
-                     : pp    ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)
-                             : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)) return rc;
-        if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
-        if (int rc = pp ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
-                        : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
-        if (int rc = pp ? launch_gemm_h2<H2BigPP>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
-                        : launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)) return rc;
-        // fc1: K = 8192 but only batch x 1024 outputs -> 4-way split-K (fixed-order reduce) to fill the chip
+        if (int rc = mark(2, true)) return rc;
+        if (use_t2) {
+            const long long threads = (long long)max_count * n * n * (C / 8);
+            hipLaunchKernelGGL(k_conv2_lut, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_lut_ids, d_count, n, C, d_t2,
+                               d_scale_h2[0], d_shift[1], (uint4*)act2, d_flag);
+        } else if (int rc = small     ? launch_gemm_h2<H2Small>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, 16)
+                            : use_lut ? launch_gemm_h2<H2BigPPLut>(d_lut, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2, d_lut_ids)
+                            : pp      ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)
+                                      : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)) return rc;
+        if (int rc = mark(2, false)) return rc;
+        if (int rc = mark(3, true)) return rc;
+        if (int rc = small ? launch_gemm_h2<H2Small>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, 16)
+                     : pp  ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
+                           : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
+        if (int rc = mark(3, false)) return rc;
+        if (int rc = small ? launch_gemm_h2<H2Small>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, 16)
+                     : pp  ? launch_gemm_h2<H2BigPP>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
+                           : launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)) return rc;
+        // fc1: K = 8192 but only batch x 1024 outputs -> split-K (fixed-order reduce) to fill the chip
         // (large batches: on the 256 x 256 ping-pong tile, 16 x 4 tiles x 4 k-slices = one block per CU; bit-identical to
         //  the 128 x 128 tile because the k-slices and the order inside them are the same -- tools/pp_race_check.py)
         static const bool fc1pp = !(getenv("OZ_H2_FC1PP") && atoi(getenv("OZ_H2_FC1PP")) == 0);
-        if (int rc = (fc1pp && pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
-                                                        : launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
+        if (int rc = small ? launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)
+                     : (fc1pp && pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
+                                                          : launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
         if (int rc = launch_gemm_h2<H2Thin>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
         hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
         OZ_HIP(hipGetLastError());
@@ -709,7 +767,7 @@ OZ_API int oz_net_commit(oz_net* net) {
         if (!o->d_partial) { if (int rc = o->alloc(&o->d_partial, o->partial_floats())) return rc; }
         if (!o->d_zero) { if (int rc = o->alloc(&o->d_zero, 16)) return rc; }
         OZ_HIP(hipMemset(o->d_zero, 0, 256));
-        if (o->max_batch > 32) {
+        {
             // conv1 pattern table (k_lut_build): OZ_LUT_ROWS rows of C channels in the h2 layout; a table entry beyond the
             // fp16 range disables the table for this network (the conv1 kernel then raises the flag on real positions)
             const size_t row_q = (size_t)C / 4;                                  // uint4 per row
@@ -724,6 +782,8 @@ OZ_API int oz_net_commit(oz_net* net) {
             OZ_HIP(hipMemcpy(&over, o->d_flag, sizeof(int), hipMemcpyDeviceToHost));
             o->lut_ok = !over;
             OZ_HIP(hipMemset(o->d_flag, 0, sizeof(int)));
+            o->t2_ok = false;
+            if (o->lut_ok) { if (int rc = o->build_t2()) return rc; }
         }
     }
     if (int rc = upload(o, &o->d_wpi, o->w[36])) return rc;
@@ -852,6 +912,14 @@ OZ_API int oz_debug_h2_stamps(unsigned long long* out48) {
     return OZ_OK;
 }
 #endif
+
+OZ_API int oz_net_profiled_layer(oz_net* net, int* layer) {
+    OnnNet* o = as_onn(net);
+    OZ_REQUIRE(o && layer, "not an OthelloNN network / null argument");
+    std::lock_guard<std::mutex> lk(o->mu);
+    *layer = o->precision == 1 ? o->profiled_layer : 2;
+    return OZ_OK;
+}
 
 OZ_API int oz_net_profile_read(oz_net* net, double* conv2_ms_total, int64_t* conv2_launches) {
     OnnNet* o = as_onn(net);

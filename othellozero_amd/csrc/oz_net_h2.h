@@ -295,6 +295,49 @@ __global__ __launch_bounds__(256) void k_lut_build(int C, const float* __restric
     if (over) atomicOr(flag, 1);
 }
 
+// conv2 as a gather-sum (conv1 AND conv2 folded into tables).  With act1[q] = table[id(q)], conv2's pre-activation at
+// pixel p is sum over taps t of W_t . table[id(p + t)] = sum_t T2[t][id(p + t)], where T2[t][id] = W_t . table[id] is a
+// C-vector that depends on the weights only: 9 x 19683 rows of C floats (363 MB at C = 512), built at commit by nine
+// [19683 x C] x [C x C] GEMMs on k_gemm_h2 (same arithmetic as the convolution: fp32 as 2 x fp16, fp32 accumulate).
+// The layer is then 9 row reads + 8 fp32 adds per pixel -- 18 KB of (mostly L2 / MALL resident) table per pixel instead
+// of 4.7 MFLOP: HBM/L2-bound byte work.  One thread per (pixel, 8 channels): a wavefront reads one whole 2 KB row.
+// Taps are added in order t = 0..8 (taps off the board skipped): a fixed order, independent of batch size and position.
+__global__ __launch_bounds__(256) void k_conv2_lut(const unsigned short* __restrict__ ids, const int* __restrict__ d_count, int n, int C,
+                                                   const float* __restrict__ T2 /*[9][OZ_LUT_PATTERNS][C]*/,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   uint4* __restrict__ out, int* __restrict__ flag) {
+    const int cg = C >> 3, P = n * n;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long pixel = idx / cg;
+    if (pixel >= (long long)(*d_count) * P) return;
+    const int c8 = (int)(idx % cg) * 8;
+    const int pix = (int)(pixel % P), y = pix / n, x = pix % n;
+    const unsigned short* idp = ids + (pixel - pix);
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+        if (iy < 0 || iy >= n || ix < 0 || ix >= n) continue;
+        const float* row = T2 + ((size_t)t * OZ_LUT_PATTERNS + idp[iy * n + ix]) * C + c8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(row), b = *reinterpret_cast<const f32x4*>(row + 4);
+        lo += a; hi += b;
+    }
+    f16x8 h1, h2;
+    bool over = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = fmaxf(fmaf(j < 4 ? lo[j] : hi[j - 4], scale[c8 + j], shift[c8 + j]), 0.f);
+        over |= v > H2_F16_MAX;
+        _Float16 a, bb;
+        h2_split(v, a, bb);
+        h1[j] = a; h2[j] = bb;
+    }
+    uint4* dst = out + ((size_t)pixel * cg + (c8 >> 3)) * 2;
+    dst[0] = *reinterpret_cast<uint4*>(&h1);
+    dst[1] = *reinterpret_cast<uint4*>(&h2);
+    if (over) atomicOr(flag, 1);
+}
+
 // out[M][N] = act((A[M][K] . W[N][K]^T) * scale + shift); A and W in the h2 layout; M = *d_count * Hout^2.
 // CF::LUT: `in` is the pattern table, lut_ids the per-pixel pattern ids [batch][Hin^2] (k_lut_ids).
 // zero_line: >= 128 B of zeros in global memory (source of out-of-image taps and of rows beyond M).

@@ -26,12 +26,22 @@ for n, C, B, reps, cin in ((8, 512, 4096, 12, 2), (8, 512, 1000, 8, 2), (8, 256,
         out[f"{n}_{C}_{B}_{cin}_{rep}_v"] = v
 np.savez(sys.argv[2], **out)
 '''
-res = []
-for tag, extra in (("simple", {"OZ_H2_PP": "0"}), ("pingpong", {"OZ_H2_PP": "1"}), ("pingpong_fc1small", {"OZ_H2_PP": "1", "OZ_H2_FC1PP": "0"}),
-                   ("pingpong_conv1kernel", {"OZ_H2_PP": "1", "OZ_H2_LUT": "0"})):
+def run(tag, extra):
     path = f"/tmp/pp_race_{tag}.npz"
     subprocess.run([sys.executable, "-c", WORKER, ROOT, path], env=dict(os.environ, **extra), check=True, timeout=600)
-    res.append(np.load(path))
-bad = [k for k in res[0].files if not all(np.array_equal(res[0][k], r[k]) for r in res[1:])]
-print(f"{len(res[0].files)} arrays x {len(res)} loop configurations compared, {len(bad)} differ", bad[:5])
-sys.exit(1 if bad else 0)
+    return np.load(path)
+
+
+# group A: conv2 as a GEMM (OZ_H2_T2=0) -- every loop / staging variant must agree to the bit
+A = [run(tag, dict(extra, OZ_H2_T2="0")) for tag, extra in (
+    ("simple", {"OZ_H2_PP": "0"}), ("pingpong", {"OZ_H2_PP": "1"}), ("pingpong_fc1small", {"OZ_H2_PP": "1", "OZ_H2_FC1PP": "0"}),
+    ("pingpong_conv1kernel", {"OZ_H2_PP": "1", "OZ_H2_LUT": "0"}))]
+# group B: the default (conv1 + conv2 as the table gather-sum): the two loops still agree to the bit (conv3, conv4, fc1),
+# and the gather-sum agrees with the GEMM to rounding (another summation order of the same products)
+B = [run(tag, extra) for tag, extra in (("t2_simple", {"OZ_H2_PP": "0"}), ("t2_pingpong", {"OZ_H2_PP": "1"}))]
+bad = [k for k in A[0].files if not all(np.array_equal(A[0][k], r[k]) for r in A[1:])]
+bad += [k for k in B[0].files if not np.array_equal(B[0][k], B[1][k])]
+gap = max(float(np.abs(A[0][k] - B[0][k]).max()) for k in A[0].files)
+print(f"{len(A[0].files)} arrays x {len(A)} + {len(B)} loop configurations compared, {len(bad)} differ", bad[:5])
+print(f"gather-sum vs GEMM conv2: max |difference| of (pi, v) = {gap:.3g}")
+sys.exit(1 if bad or gap > 2e-6 else 0)
