@@ -11,5 +11,6 @@ net.time_forward(B, 2)
 net.profile(True)
 ms = net.time_forward(B, iters)
 c2, n = net.profile_read()
-flop = B * 2 * 64 * 4608 * 512
-print(f"{prec}: forward {ms:.3f} ms  ({B*566428672/ms/1e9:.1f} TF-eq)   conv2 {c2/n:.3f} ms ({flop/(c2/n)/1e9:.1f} TF-eq, n={n})", flush=True)
+layer = net.profiled_layer()                 # 2 = conv2 GEMM, 3 = conv3 GEMM (conv1 + conv2 as the table gather-sum)
+flop = B * 2 * (64 if layer == 2 else 36) * 4608 * 512
+print(f"{prec} B={B}: forward {ms:.3f} ms  ({B*566428672/ms/1e9:.1f} TF-eq of the reference network)   conv{layer} {c2/n:.3f} ms ({flop/(c2/n)/1e9:.1f} TF-eq, n={n})", flush=True)

@@ -2,7 +2,7 @@
 
   python tools/summarize_prof.py trace  <rocprof_dir> <out_csv>  "<header comment>"
   python tools/summarize_prof.py pmc    <out_csv> "<header comment>" <rocprof_dir> [<rocprof_dir> ...]
-  python tools/summarize_prof.py traffic <pmc_by_shape_csv> <out_json> <precision> <conv2 kernel substring> <grid_threads>
+  python tools/summarize_prof.py traffic <pmc_by_shape_csv> <out_json> <precision> <kernel substring> <grid_threads> [layer=conv2]
 
 `trace`   : per (kernel, grid) averages from *_kernel_trace.csv; the OthelloNN layers are recognised by grid size
             (4096 leaves per launch) and get their algorithmic fp32 TFLOP/s.
@@ -47,11 +47,19 @@ def trace(d, out, header):
             wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
             rows[(k, grid, wg, int(r["LDS_Block_Size"]), int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"]),
                   int(r["Scratch_Size"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    # name the GEMM launches: order the gemm shapes by total time -> conv2 > conv3 > conv4 > fc1 > fc2 holds for this net
-    gemm = sorted((k for k in rows if "k_gemm" in k[0] and len(rows[k]) >= 50), key=lambda k: -sum(rows[k]))
+    # name the GEMM launches.  precision f16x2 (k_gemm_h2): by tile configuration and grid at 4096 leaves per launch;
+    # precision f32: the gemm shapes ordered by total time (conv2 > conv3 > conv4 > fc1 > fc2 holds for this net)
     names = {}
-    for k, lay in zip(gemm, ("conv2", "conv3", "conv4", "fc1", "fc2")):
-        names[k] = lay
+    h2 = {("H2BigPPLut", 1048576): "conv2", ("H2BigPP>", 1048576): "conv2", ("H2MidPP", 786432): "conv3", ("H2BigPP>", 262144): "conv4",
+          ("H2BigPP>", 131072): "fc1", ("H2Cfg<1, 2, 2, 2>", 32768): "fc2"}
+    for k in rows:
+        for (sub, grid), lay in h2.items():
+            if "k_gemm_h2" in k[0] and sub in k[0] and k[1] == grid and len(rows[k]) >= 50:
+                names[k] = lay
+    if not names:
+        gemm = sorted((k for k in rows if "k_gemm" in k[0] and len(rows[k]) >= 50), key=lambda k: -sum(rows[k]))
+        for k, lay in zip(gemm, ("conv2", "conv3", "conv4", "fc1", "fc2")):
+            names[k] = lay
     with open(out, "w") as f:
         f.write(f"# {header}\n")
         f.write("# per (kernel, grid) averages from the kernel trace; 4096 leaves per launch; TFLOP_per_s = ALGORITHMIC fp32 FLOP "
@@ -86,7 +94,7 @@ def pmc(out, header, dirs):
             f.write(f"\"{k}\",{g},{c},{s / n:.6g},{n}\n")
 
 
-def traffic(src, out, precision, kernel_sub, grid):
+def traffic(src, out, precision, kernel_sub, grid, layer="conv2"):
     vals = {}
     with open(src) as f:
         for r in csv.DictReader(l for l in f if not l.startswith("#")):
@@ -94,10 +102,12 @@ def traffic(src, out, precision, kernel_sub, grid):
                 vals[r["counter"]] = float(r["avg_per_launch"])
     fetch = vals["FETCH_SIZE"] * 1024 * 2
     write = vals["WRITE_SIZE"] * 1024
-    j = {"round": 1, "precision": precision, "kernel": f"{kernel_sub} conv2", "leaves_per_launch": LEAVES,
+    # algorithmic bytes per leaf (h2 activations are 4 B per value, like fp32): input pixels + output pixels + the layer's weights once per launch
+    alg = {"conv2": 64 * 2048 + 64 * 2048 + 9 * 512 * 512 * 4 / LEAVES, "conv3": 64 * 2048 + 36 * 2048 + 9 * 512 * 512 * 4 / LEAVES}[layer]
+    j = {"round": 1, "precision": precision, "kernel": f"{kernel_sub} {layer}", "leaves_per_launch": LEAVES,
          "fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
          "hbm_bytes_per_leaf": (fetch + write) / LEAVES,
-         "algorithmic_bytes_per_leaf": 264448.0 if precision == "f16x2" else 262144.0 + 18 * 512 * 512 * 4 / LEAVES,
+         "algorithmic_bytes_per_leaf": alg if precision == "f16x2" else 262144.0 + 18 * 512 * 512 * 4 / LEAVES,
          "source": src}
     if "GRBM_GUI_ACTIVE" in vals:                  # summed over the 8 XCDs
         j["gpu_cycles_per_launch"] = vals["GRBM_GUI_ACTIVE"] / 8
@@ -117,6 +127,6 @@ if __name__ == "__main__":
     elif mode == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4:])
     elif mode == "traffic":
-        traffic(*sys.argv[2:7])
+        traffic(*sys.argv[2:8])
     else:
         raise SystemExit(__doc__)
