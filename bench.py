@@ -126,6 +126,11 @@ def main():
     ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x2"],
                     help="conv arithmetic: exact fp32 matrix cores, or f32 via 2 x fp16 split (same 1e-5 parity tolerance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dedup", default="off", choices=["off", "on"],
+                    help="cross-game leaf de-duplication in the timed region.  off (default for the headline): the network evaluates "
+                         "every expansion -- no output is shared or cached; on: the library default (a board reached by several "
+                         "games in the same step is evaluated once).  With off, the on-rate is measured afterwards and reported "
+                         "next to it (N = 1 only)")
     ap.add_argument("--driver", default="lockstep", choices=["free", "lockstep"],
                     help="free: oz_selfplay_run_steps (every game runs on by itself, full leaf batches; identical records); "
                          "lockstep: oz_selfplay_run (one simulation per game per step, moves aligned)")
@@ -160,9 +165,12 @@ def main():
 
     n, G = args.board, args.games
     net = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0, precision=args.precision)   # same weights on every rank
-    eng = SelfPlayEngine(net, n, G, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * G,
-                         game_id_stride=world * G, q_mode=_lib.QMODE_F64, refill=True,
-                         record_cap=int(G * (args.steps + args.warmup + 2) * 1.25))
+    def make_engine(dedup):
+        os.environ["OZ_DEDUP"] = "1" if dedup else "0"          # read when the engine's search object is created
+        return SelfPlayEngine(net, n, G, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * G,
+                              game_id_stride=world * G, q_mode=_lib.QMODE_F64, refill=True,
+                              record_cap=int(G * (args.steps + args.warmup + 2) * 1.25))
+    eng = make_engine(args.dedup == "on")
 
     def barrier():
         if world > 1:
@@ -172,7 +180,7 @@ def main():
     # one bench step = `sims` network batches of up to G leaves: a move round in lock step; in free-running mode the same
     # number of batches, each full (network-free simulations and moves ride along).  Measured: no throughput difference --
     # a batch's cost is proportional to its leaves, so filling the ~8 % empty slots buys nothing
-    def advance(k, sync):
+    def advance(k, sync, eng=eng):
         if args.driver == "free":
             eng.run_steps(k * args.sims, sync=sync)
         else:
@@ -194,7 +202,7 @@ def main():
     conv2_ms, conv2_launches = net.profile_read()               # the dominant launch: conv2, or conv3 when conv2 is a gather-sum
     layer = net.profiled_layer()
 
-    d = {k: s1[k] - s0[k] for k in ("simulations", "expansions", "terminal_hits", "node_visits", "moves", "games_completed")}
+    d = {k: s1[k] - s0[k] for k in ("simulations", "expansions", "terminal_hits", "node_visits", "moves", "games_completed", "leaves_evaluated")}
     vec = torch.tensor([d["expansions"], d["simulations"], d["games_completed"], d["moves"], d["node_visits"]],
                        dtype=torch.float64, device=dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -205,7 +213,8 @@ def main():
     exp_all, sims_all, games_all, moves_all, visits_all = (float(x) for x in vec.tolist())
 
     if rank == 0:
-        flop_conv2 = d["expansions"] * conv_flop_per_leaf(layer, n, args.channels)
+        # network work is counted per position actually evaluated (a board reached by several games in one step is evaluated once)
+        flop_conv2 = d["leaves_evaluated"] * conv_flop_per_leaf(layer, n, args.channels)
         achieved = flop_conv2 / (conv2_ms * 1e-3) / 1e12 if conv2_ms > 0 else 0.0
         # FLOP the GPU executes per expansion: the reference network's, minus conv1 + conv2 when they run as table lookups
         flop_ref = FLOP_PER_EXPANSION.get(n, 0)
@@ -224,16 +233,20 @@ def main():
                             f"finished games refilled; leaf evaluator = the reference's OthelloNN ({args.channels} filters), random init seed 0",
                 "games_per_gpu": G, "sims_per_move": args.sims, "board": n,
                 "q_mode": "float64 (NumPy 1.18.5 promotion)", "driver": args.driver, "parallelism": f"games sharded x{world}, all-gather of move records",
+                "leaf_dedup": ("on: a board reached by several games in the same step is evaluated once (library default)" if args.dedup == "on" else
+                               "off: the network evaluates every expansion, nothing is shared or cached between games "
+                               "(the library default is on -- see cross_game_dedup for that rate)"),
             },
             "games_per_s": games_all / dt, "sims_per_s": sims_all / dt, "moves_per_s": moves_all / dt,
             "games_completed": int(games_all), "expansions": int(exp_all), "simulations": int(sims_all),
             "expansions_per_sim": exp_all / max(sims_all, 1), "node_visits_per_sim": visits_all / max(sims_all, 1),
             "pooled_records": int(pooled.shape[0]),
             "nn_forward_ms_total_rank0": nn_ms, "nn_fraction_of_wall_rank0": nn_ms * 1e-3 / dt,
-            "whole_net_tflops_rank0": d["expansions"] * flop_exec / max(nn_ms * 1e-3, 1e-9) / 1e12,
+            "leaves_evaluated_rank0": int(d["leaves_evaluated"]),
+            "whole_net_tflops_rank0": d["leaves_evaluated"] * flop_exec / max(nn_ms * 1e-3, 1e-9) / 1e12,
             "flop_per_expansion": {"reference_network": flop_ref, "executed": flop_exec,
                                    "note": "executed < reference when conv1 + conv2 are evaluated as pattern-table lookups (exact refactoring, no GEMM)"},
-            "roofline": roofline(args.precision, layer, achieved, conv2_ms, conv2_launches, d["expansions"], n, args.channels),
+            "roofline": roofline(args.precision, layer, achieved, conv2_ms, conv2_launches, d["leaves_evaluated"], n, args.channels),
             # the tree / rules side is latency-bound integer work, ~1.3 KB of algorithmic HBM bytes per simulation
             "tree_side_hbm": {"bytes_per_sim": 1300, "achieved_GBps": sims_all / dt * 1300 / 1e9, "peak_GBps": 8000.0,
                               "frac": sims_all / dt * 1300 / 8e12, "note": "not the binding roof; reported per SURVEY 8(d)"},
@@ -241,6 +254,24 @@ def main():
         out["dtype"] = "f32" if args.precision == "f32" else "f32 (2xf16 split)"
         out["dtype_detail"] = ("fp32 operands and accumulators on v_mfma_f32_32x32x2_f32" if args.precision == "f32" else
                                "fp32 values carried as two fp16 planes, 3 fp16 MFMA products per fp32 product, fp32 accumulate; pi, v within 1e-5 of float64")
+        if world == 1 and args.dedup == "off":
+            # the same K steps with the library default (cross-game de-duplication on): identical records, fewer evaluations
+            eng2 = make_engine(True)
+            advance(args.warmup, True, eng2)
+            eng2.sync()
+            q0 = eng2.stats()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            advance(args.steps, False, eng2)
+            eng2.sync()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            q1 = eng2.stats()
+            out["cross_game_dedup"] = {
+                "value": (q1["expansions"] - q0["expansions"]) / dt2, "unit": "node-expansions/s", "ms_per_step": dt2 / args.steps * 1e3,
+                "expansions": int(q1["expansions"] - q0["expansions"]), "leaves_evaluated": int(q1["leaves_evaluated"] - q0["leaves_evaluated"]),
+                "note": "same games, same records; concurrent games that reach the same board in a step share one network evaluation "
+                        "(k_compact). Not the headline: `value` above evaluates every expansion"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.channels, args.sims)
         print(json.dumps(out), flush=True)

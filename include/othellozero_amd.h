@@ -159,6 +159,8 @@ typedef struct {
     int64_t simulations, node_visits, expansions, terminal_hits, fallbacks;
     int64_t moves, games_completed, records;
     int32_t live_games, overflow;
+    int64_t leaves_evaluated;   /* positions handed to the network: <= expansions, because a board that several games reach in
+                                 * the same step is evaluated once (results are identical either way; OZ_DEDUP=0 disables) */
 } oz_selfplay_stats;
 
 int oz_selfplay_create(oz_selfplay** out, const oz_selfplay_config* cfg, oz_net* net);

@@ -43,6 +43,7 @@ class SelfplayStats(C.Structure):
         ("terminal_hits", C.c_int64), ("fallbacks", C.c_int64),
         ("moves", C.c_int64), ("games_completed", C.c_int64), ("records", C.c_int64),
         ("live_games", C.c_int32), ("overflow", C.c_int32),
+        ("leaves_evaluated", C.c_int64),
     ]
 
 

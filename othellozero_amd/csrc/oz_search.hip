@@ -52,6 +52,8 @@ struct MctsDev {
     int* last_vtype;
     unsigned long long* stat;  // [G][OZ_NSTAT]
     int* error_flag;
+    unsigned long long* eval_leaves;    // positions handed to the network so far (after cross-game de-duplication)
+    int dedup;                 // k_compact: evaluate a board reached by several games in the same step once
 };
 
 // ---------------------------------------------------------------- wave helpers (wave = 64 lanes)
@@ -175,15 +177,56 @@ __global__ __launch_bounds__(64) void k_select(MctsDev t) { select_body(t, block
 
 // ---------------------------------------------------------------- K13: leaf compaction
 // ballot + prefix sum over the games; slot order = game order (deterministic).
+// Leaves are also de-duplicated ACROSS games (G <= OZ_DEDUP_MAX_G): a board that several games reach in the same step
+// is evaluated once and every one of those games reads the same (pi, v) row.  The network's output for a position does
+// not depend on its slot or on the batch (oz_net.hip), so results are bit-identical with or without this; it removes the
+// evaluations of the opening plies, where thousands of concurrent games still walk the same few positions.
+// The table (LDS, open addressing) holds the LOWEST game index with a given board: slots are the first occurrences in game order.
+#define OZ_DEDUP_MAX_G 8192
+#define OZ_DEDUP_SLOTS 16384
+__device__ __forceinline__ unsigned dedup_hash(uint64_t own, uint64_t opp) {
+    return (unsigned)(((own * 0x9E3779B97F4A7C15ull) ^ (opp * 0xC2B2AE3D27D4EB4Full)) >> 40) & (OZ_DEDUP_SLOTS - 1);
+}
 __global__ __launch_bounds__(1024) void k_compact(MctsDev t) {
     __shared__ int wtot[16];
     __shared__ int base_s;
+    __shared__ int tab[OZ_DEDUP_SLOTS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool dedup = t.dedup && t.G <= OZ_DEDUP_MAX_G;
     if (tid == 0) base_s = 0;
+    if (dedup) {
+        for (int i = tid; i < OZ_DEDUP_SLOTS; i += 1024) tab[i] = -1;
+        __syncthreads();
+        for (int g = tid; g < t.G; g += 1024) {
+            if (t.leaf_status[g] != OZ_LEAF_EVAL) continue;
+            const uint64_t own = t.leaf_own[g], opp = t.leaf_opp[g];
+            unsigned h = dedup_hash(own, opp);
+            for (;;) {
+                int cur = atomicCAS(&tab[h], -1, g);
+                if (cur == -1) break;                                      // claimed an empty slot
+                if (t.leaf_own[cur] == own && t.leaf_opp[cur] == opp) {    // same board: keep the lowest game index
+                    atomicMin(&tab[h], g);
+                    break;
+                }
+                h = (h + 1) & (OZ_DEDUP_SLOTS - 1);
+            }
+        }
+    }
     __syncthreads();
     for (int start = 0; start < t.G; start += 1024) {
         const int g = start + tid;
-        const bool flag = g < t.G && t.leaf_status[g] == OZ_LEAF_EVAL;
+        const bool leaf = g < t.G && t.leaf_status[g] == OZ_LEAF_EVAL;
+        int first = g;
+        if (leaf && dedup) {
+            const uint64_t own = t.leaf_own[g], opp = t.leaf_opp[g];
+            unsigned h = dedup_hash(own, opp);
+            for (;;) {
+                first = tab[h];
+                if (t.leaf_own[first] == own && t.leaf_opp[first] == opp) break;
+                h = (h + 1) & (OZ_DEDUP_SLOTS - 1);
+            }
+        }
+        const bool flag = leaf && first == g;                              // first occurrence: gets a slot
         const uint64_t b = __ballot(flag);
         const int pre = oz_popc(b & ((1ULL << lane) - 1ULL));
         if (lane == 0) wtot[w] = oz_popc(b);
@@ -196,12 +239,20 @@ __global__ __launch_bounds__(1024) void k_compact(MctsDev t) {
             t.leaf_slot[g] = slot;
             t.batch_own[slot] = t.leaf_own[g];
             t.batch_opp[slot] = t.leaf_opp[g];
+        } else if (leaf) {
+            t.leaf_slot[g] = -1 - first;                                   // resolved below: first < g, but maybe in this chunk
         }
         __syncthreads();
         if (tid == 0) base_s = base + total;
         __syncthreads();
     }
-    if (tid == 0) *t.batch_count = base_s;
+    if (dedup) {
+        __threadfence_block();
+        __syncthreads();
+        for (int g = tid; g < t.G; g += 1024)
+            if (t.leaf_status[g] == OZ_LEAF_EVAL && t.leaf_slot[g] < 0) t.leaf_slot[g] = t.leaf_slot[-1 - t.leaf_slot[g]];
+    }
+    if (tid == 0) { *t.batch_count = base_s; *t.eval_leaves += (unsigned long long)base_s; }
 }
 
 // ---------------------------------------------------------------- K5 + K6: expand and backup
@@ -354,12 +405,14 @@ static int mcts_create(oz_mcts** out, int n, int G, int node_cap, int edge_cap, 
     A(batch_own, G); A(batch_opp, G); A(batch_count, 1);
     A(pi, (size_t)G * d.n2); A(v, G);
     A(last_value, G); A(last_vtype, G);
-    A(stat, (size_t)G * OZ_NSTAT); A(error_flag, 1);
+    A(stat, (size_t)G * OZ_NSTAT); A(error_flag, 1); A(eval_leaves, 1);
 #undef A
+    { const char* e = getenv("OZ_DEDUP"); d.dedup = !(e && atoi(e) == 0); }      // OZ_DEDUP=0: one evaluation per game and step (A/B runs, tests)
     if (!rc && hipStreamCreate(&m->stream) != hipSuccess) { oz_set_error("hipStreamCreate failed"); rc = OZ_ERR_HIP; }
     if (!rc) {
         hipMemsetAsync(d.stat, 0, sizeof(unsigned long long) * (size_t)G * OZ_NSTAT, m->stream);
         hipMemsetAsync(d.error_flag, 0, sizeof(int), m->stream);
+        hipMemsetAsync(d.eval_leaves, 0, sizeof(unsigned long long), m->stream);
         hipMemsetAsync(d.active, 0, G, m->stream);
         hipMemsetAsync(d.leaf_status, 0, sizeof(int) * G, m->stream);
         hipMemsetAsync(d.batch_count, 0, sizeof(int), m->stream);
@@ -989,6 +1042,9 @@ OZ_API int oz_selfplay_get_stats(oz_selfplay* sp, oz_selfplay_stats* out) {
     int live = 0;
     for (uint8_t f : fin) live += f ? 0 : 1;
     out->live_games = live; out->overflow = ef;
+    unsigned long long ev = 0;
+    OZ_HIP(hipMemcpy(&ev, sp->m->d.eval_leaves, sizeof ev, hipMemcpyDeviceToHost));
+    out->leaves_evaluated = (int64_t)ev;
     return OZ_OK;
 }
 

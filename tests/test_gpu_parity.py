@@ -781,3 +781,29 @@ def test_free_running_selfplay_equals_lock_step(oz, n, sims, T, keep):
     # the free-running driver wastes no batch slot on network-free simulations
     ev = free.eval_time()
     assert sf["expansions"] / max(ev["launches"], 1) > 0.9 * G or sf["live_games"] < G
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["stub", "onn"])
+def test_cross_game_leaf_dedup_changes_nothing_but_the_work(oz, kind, monkeypatch):
+    """k_compact evaluates a board that several games reach in the same step once (default) -- records, visit counts and
+    per-game statistics are those of one evaluation per game (OZ_DEDUP=0), and the opening plies cost far fewer evaluations"""
+    from othellozero_amd.NNet import NNetWrapper, StubNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    n, G, sims = 6, 96, 12
+    def run(dedup):
+        monkeypatch.setenv("OZ_DEDUP", "1" if dedup else "0")
+        net = (StubNetWrapper((n, n), 5, 0, max_batch=G) if kind == "stub" else
+               NNetWrapper((n, n), num_channels_1=256, max_batch=G, seed=4, precision="f16x2"))
+        eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=77, first_game_id=0, game_id_stride=G, refill=False,
+                             record_cap=G * n * n)
+        eng.run(n * n)
+        return eng.records(), eng.stats(), eng.last_counts()
+    r1, s1, c1 = run(True)
+    r0, s0, c0 = run(False)
+    assert r1.tobytes() == r0.tobytes() and np.array_equal(c1, c0)
+    for k in ("simulations", "node_visits", "expansions", "terminal_hits", "moves", "games_completed"):
+        assert s1[k] == s0[k], k
+    assert s0["leaves_evaluated"] == s0["expansions"]
+    assert s1["leaves_evaluated"] < s1["expansions"]             # all games share the opening positions
+    assert s1["overflow"] == 0
