@@ -440,6 +440,7 @@ struct OnnNet : oz_net {
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Big>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Big::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2BigPP::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2MidPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2MidPP::LDS));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2MidPP3>, hipFuncAttributeMaxDynamicSharedMemorySize, H2MidPP3::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPPLut>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        H2BigPPLut::LDS + 9 * H2BigPPLut::BM * 2));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Mid>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Mid::LDS));
@@ -558,7 +559,11 @@ struct OnnNet : oz_net {
                                       : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)) return rc;
         if (int rc = mark(2, false)) return rc;
         if (int rc = mark(3, true)) return rc;
+        // 3-phase loop on the 192-row tile (24-MFMA clusters): bit-identical, measured 0 .. +2 % on conv3 -- the layer is clock / power
+        // bound, not load-section bound -- so the 4-phase loop stays the default; OZ_H2_PP3=1 selects it
+        static const bool pp3 = getenv("OZ_H2_PP3") && atoi(getenv("OZ_H2_PP3")) != 0;
         if (int rc = small ? launch_gemm_h2<H2Small>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, 16)
+                     : pp && pp3 ? launch_gemm_h2<H2MidPP3>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                      : pp  ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                            : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
         if (int rc = mark(3, false)) return rc;

@@ -75,12 +75,14 @@ template <int NWM, int NWN, int NTI, int NTJ> struct H2Cfg {
     static_assert(NW * SLICE <= LDS, "epilogue slices must fit in the staging buffers");
     static constexpr bool PP = false;     // main loop: false = one barrier per k-tile; true = 4-phase ping-pong (H2BigPP)
     static constexpr bool LUT = false;    // A rows gathered from the conv1 pattern table (H2BigPPLut), see k_lut_build
+    static constexpr bool PP3 = false;    // 192-row tile: 3-phase ping-pong (thirds of the A rows x all four B blocks, 24-MFMA clusters)
 };
 typedef H2Cfg<2, 4, 4, 2> H2Big;      // conv2, conv4: 256 x 256
 // the same tile with the ping-pong main loop: the two wave rows (= the two waves of every SIMD) run half a phase
 // apart, so one of them is in its MFMA cluster while the other issues LDS reads and LDS-DMA (see k_gemm_h2)
 struct H2BigPP : H2Cfg<2, 4, 4, 2> { static constexpr bool PP = true; };
 struct H2MidPP : H2Cfg<2, 4, 3, 2> { static constexpr bool PP = true; };
+struct H2MidPP3 : H2Cfg<2, 4, 3, 2> { static constexpr bool PP3 = true; };
 // conv2 with conv1 folded into a lookup: the conv1 + BN + ReLU output of a pixel depends only on the 3 x 3 neighbourhood
 // of the position (9 cells, each empty / own / opponent: 3^9 = 19683 patterns), so conv2's A rows are LDS-DMA'd straight
 // from a table of the 19683 possible rows (+ one zero row for taps outside the board) instead of from a conv1 output
@@ -373,7 +375,8 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     // (192-row tile: 3 A pieces per wave -- piece 0 early, piece 2 late, piece 1 early for waves 0-3 and late for waves 4-7)
     auto a_late = [&](int i) -> int { return IA == 4 ? (i >> 1) : (i == 0 ? 0 : i == 2 ? 1 : (wave >= 4 ? 1 : 0)); };
     auto a_row0 = [&](int i) -> int {
-        if constexpr (!CF::PP) return (wave * IA + i) * 8;
+        if constexpr (CF::PP3) return (wave >> 2) * (BM / 2) + i * (BM / 6) + (wave & 3) * 8;    // piece i = third i of both wave rows
+        else if constexpr (!CF::PP) return (wave * IA + i) * 8;
         else {
             constexpr int HR = BM / 4, HBLK = HR / 8;            // rows / 8-row blocks in one half of a wave row
             const int hb = IA == 4 ? 2 * wave + (i & 1) : (i == 1 ? 8 + (wave & 3) : wave);
@@ -469,6 +472,106 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     const int swz = h2_swz(r16);                             // tile bases are multiples of 16 rows
     const int oh1 = ((2 * kg) ^ swz) * 16, oh2 = ((2 * kg + 1) ^ swz) * 16;
 
+    if constexpr (CF::PP3) {
+        // ---- 3-phase ping-pong main loop for the 192 x 256 tile (8 waves = 2 wave rows x 4 wave columns, wave tile 96 x 64).
+        // MEASURED: bit-identical to the other loops, conv3 1.320 -> 1.305 / 1.319 ms at 4096 leaves (0 .. +1 %): the layer is
+        // clock / power bound, not load-section bound.  Kept as an option (OZ_H2_PP3=1), the 4-phase loop stays the default.
+        // The 4-phase loop gives this tile 18-MFMA clusters, shorter than the load section they are meant to cover; here
+        // a k-tile is three thirds of the A rows (2 x 16 rows each) times ALL four B blocks = 24 MFMAs per phase:
+        //   phase q: L section: ds_read A third q (4 reads; phase 1 also the tile's 8 B reads), LDS-DMA pieces, counted
+        //            s_waitcnt vmcnt, s_barrier;  M section: lgkmcnt(0), 24 MFMAs, s_barrier.
+        // Wave row 1 runs one barrier behind wave row 0 (as in the 4-phase loop).  Phases are numbered Q = 3 * tile + q.
+        //   visibility: a piece read in L_Q is retired (vmcnt) by every issuing wave in L_{Q-1} or earlier;
+        //   reuse:      a region read in L_Q is DMA-overwritten from L_{Q+2} on (row 1's reads of L_Q finish before the
+        //               barrier that opens row 0's L_{Q+2}).
+        // Per wave and tile k: L1 issues A third 1 of tile k+1, B pieces 2,3 of tile k+1; L2: A third 2 of k+1;
+        // L3: A third 3 of k+1 and B pieces 0,1 of tile k+2 (into the buffer whose B was read in L1 of tile k).
+        // Every piece is issued two phases before the vmcnt that retires it; in-order retirement gives vmcnt(6), (6), (4).
+        static_assert(IA == 3 && IB == 4 && RI == 6 && RJ == 4, "3-phase loop: 192 x 256 tile, 8 waves");
+        stage(kbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        f16x8 fa1[2], fa2[2], fb1[4], fb2[4];
+        int kt1 = kbeg + 1 < nk ? kbeg + 1 : nk - 1;         // tile k+1 (past the end: the last tile again)
+        int kt2 = kt1 + 1 < nk ? kt1 + 1 : nk - 1;           // tile k+2
+        int slice1 = kt1 / g.taps, tap1 = kt1 - slice1 * g.taps;
+        auto dma_b_to = [&](int i, int ktile, int bufi) {
+            unsigned char* lb = smem + (size_t)bufi * CF::BUF + CF::TILEA;
+            __builtin_amdgcn_global_load_lds((h2_gptr)(Wh + bidx[i] + ktile * 8), (h2_lptr)(lb + b_row0(i) * 128), 16, 0, 0);
+        };
+        dma_b_to(0, kt1, 1); dma_b_to(1, kt1, 1);            // what L3 of the tile before the first would have issued
+        if (wm == 1) __builtin_amdgcn_s_barrier();           // stagger: wave row 1 is one barrier behind
+        for (int kt = kbeg; kt < nk; ++kt) {
+            const int buf = (kt - kbeg) & 1;
+            const int dy = (tap1 * 11) >> 5, dx = tap1 - 3 * dy;
+            const long long toff = ((long long)dy * g.Hin + dx) * rowq + slice1 * 8;
+            const int tapn = tap1, k1 = kt1, k2 = kt2;
+            unsigned char* la = smem + (size_t)(buf ^ 1) * CF::BUF;
+            const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * RI * 16 + r16) * 128;
+            const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+            auto dma_a = [&](int i) {
+                const uint4* ga = ((amask[i] >> tapn) & 1) ? in + (aidx[i] + toff) : zsrc;
+                __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la + a_row0(i) * 128), 16, 0, 0);
+            };
+            auto lda = [&](int third) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa1[i] = *reinterpret_cast<const f16x8*>(At + (third * 2 + i) * 16 * 128 + oh1);
+                    fa2[i] = *reinterpret_cast<const f16x8*>(At + (third * 2 + i) * 16 * 128 + oh2);
+                }
+            };
+            auto l_end = [&](auto keep) {
+                constexpr int K = decltype(keep)::value;
+                if constexpr (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto mma = [&](int third) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4v& c = acc[third * 2 + i][j];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? fa2[i] : fa1[i], p == 1 ? fb2[j] : fb1[j], c, 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto m_end = [&]() {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using std::integral_constant;
+            // phase 1
+            lda(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                fb1[j] = *reinterpret_cast<const f16x8*>(Bt + j * 16 * 128 + oh1);
+                fb2[j] = *reinterpret_cast<const f16x8*>(Bt + j * 16 * 128 + oh2);
+            }
+            dma_a(0); dma_b_to(2, k1, buf ^ 1); dma_b_to(3, k1, buf ^ 1);
+            l_end(integral_constant<int, 6>{}); mma(0); m_end();
+            // phase 2
+            lda(1); dma_a(1);
+            l_end(integral_constant<int, 6>{}); mma(1); m_end();
+            // phase 3
+            lda(2); dma_a(2); dma_b_to(0, k2, buf); dma_b_to(1, k2, buf);
+            l_end(integral_constant<int, 4>{}); mma(2); m_end();
+            // advance (k+1, k+2) incrementally: no integer division in the loop
+            if (kt1 + 1 < nk) { ++kt1; if (++tap1 == g.taps) { tap1 = 0; ++slice1; } }
+            kt2 = kt1 + 1 < nk ? kt1 + 1 : nk - 1;
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave rows
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every piece has landed before the epilogue reuses the LDS
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else
     if constexpr (CF::PP) {
         // ---- 4-phase ping-pong main loop (block 256 x 256, 8 waves = 2 wave rows x 4 wave columns).
         // A k-tile is processed as four quadrants of the 128 x 64 wave tile, (m0,n0) (m0,n1) (m1,n0) (m1,n1); phase q =
