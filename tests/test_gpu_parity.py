@@ -807,3 +807,33 @@ def test_cross_game_leaf_dedup_changes_nothing_but_the_work(oz, kind, monkeypatc
     assert s0["leaves_evaluated"] == s0["expansions"]
     assert s1["leaves_evaluated"] < s1["expansions"]             # all games share the opening positions
     assert s1["overflow"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cin,C,B", [(8, 2, 512, 130), (6, 2, 256, 70), (8, 1, 256, 40), (6, 1, 512, 33)])
+def test_conv_pattern_tables_vs_float64(oz, n, cin, C, B):
+    """precision f16x2 evaluates conv1 + conv2 as lookups in tables indexed by the 3^9 neighbourhood patterns of the
+    discrete input planes (k_lut_ids / k_conv2_lut, tables built at commit): within 1e-5 of the float64 oracle on random
+    boards AND on the corner cases of the pattern index (empty board, one colour everywhere, full board, single discs on
+    edges and corners), for both networks and both board sizes; a position's result does not depend on the batch"""
+    from othellozero_amd.NNet import NNetWrapper, NeuralNets
+    from othellozero_amd.weights import init_weights
+    w = init_weights(n, seed=31 + n + cin, channels=C, randomize_all=True, in_channels=cin)
+    net = NNetWrapper((n, n), num_channels_1=C, max_batch=B, precision="f16x2", weights=w,
+                      network=NeuralNets.ONN if cin == 2 else NeuralNets.BNN)
+    rs = np.random.RandomState(1000 * n + cin)
+    valid = np.uint64(sum(1 << (r * 8 + c) for r in range(n) for c in range(n)))
+    own = rs.randint(0, 2**63, size=B, dtype=np.uint64) & valid
+    opp = rs.randint(0, 2**63, size=B, dtype=np.uint64) & valid & ~own
+    bit = lambda r, c: np.uint64(1 << (r * 8 + c))
+    special = [(0, 0), (valid, 0), (0, valid), (own[0], valid & ~own[0]),
+               (bit(0, 0), bit(n - 1, n - 1)), (bit(0, n - 1), bit(n - 1, 0)), (bit(n // 2, 0), bit(0, n // 2)),
+               (bit(n - 1, n // 2) | bit(n // 2, n - 1), 0)]
+    for i, (o, p) in enumerate(special):
+        own[i + 1], opp[i + 1] = np.uint64(o), np.uint64(p)
+    pi, v = net.predict_batch(own, opp)
+    pi64, v64 = nn_numpy.forward(w, own, opp, n)
+    assert np.abs(pi.reshape(B, -1) - pi64).max() <= 1e-5 and np.abs(v - v64).max() <= 1e-5
+    order = rs.permutation(B)[: B // 2]                          # another batch: other slots, other neighbours, other size
+    p2, v2 = net.predict_batch(own[order], opp[order])
+    assert np.array_equal(p2, pi[order]) and np.array_equal(v2, v[order])
