@@ -365,6 +365,10 @@ struct OnnNet : oz_net {
     unsigned short* d_lut_ids = nullptr;
     bool lut_ok = false;
     float* d_t2 = nullptr;           // conv2 as a gather-sum (k_conv2_lut): [9][OZ_LUT_PATTERNS][C]
+    uint4* d_wtap = nullptr;         // build_t2 staging: conv2's kernel as nine [C][C] matrices in the h2 layout
+    float* d_raw = nullptr;          // oz_net_commit staging: one Keras kernel as stored
+    float *d_one = nullptr, *d_nul = nullptr;
+    int* d_rows = nullptr;
     bool t2_ok = false;
     bool h2_attr_set = false;
     std::vector<void*> allocs;
@@ -462,39 +466,23 @@ struct OnnNet : oz_net {
 
     // T2[t] = table . W_t^T (raw k-sums, scaled 2^kexp like the convolution's): nine GEMMs M = OZ_LUT_PATTERNS, K = N = C
     int build_t2() {
-        const auto& src = w[6];                                  // conv2 kernel (3,3,C,C): [tap*C + ci][co]
-        float mx = 0.f;
-        for (float x : src) mx = fmaxf(mx, fabsf(x));
-        const int kexp = mx > 0.f ? (int)floorf(log2f(1000.0f / mx)) : 0;     // the same power of two as d_wh[0]
-        std::vector<uint16_t> h((size_t)9 * C * C * 2);
-        for (int t = 0; t < 9; ++t)
-            for (int co = 0; co < C; ++co)
-                for (int ci = 0; ci < C; ++ci) {
-                    const float x = ldexpf(src[((size_t)t * C + ci) * C + co], kexp);
-                    const _Float16 h1 = (_Float16)x, h2 = (_Float16)(x - (float)h1);
-                    const size_t base = (((size_t)t * C + co) * (C / 8) + (ci >> 3)) * 16 + (ci & 7);
-                    memcpy(&h[base], &h1, 2); memcpy(&h[base + 8], &h2, 2);
-                }
-        uint4* d_wtap = nullptr;
-        float *d_one = nullptr, *d_nul = nullptr;
-        int* d_rows = nullptr;
-        OZ_HIP(hipMalloc((void**)&d_wtap, h.size() * 2));
-        OZ_HIP(hipMalloc((void**)&d_one, sizeof(float) * C));
-        OZ_HIP(hipMalloc((void**)&d_nul, sizeof(float) * C));
-        OZ_HIP(hipMalloc((void**)&d_rows, sizeof(int)));
-        std::vector<float> one((size_t)C, 1.0f);
-        const int rows = OZ_LUT_PATTERNS;
-        OZ_HIP(hipMemcpy(d_wtap, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-        OZ_HIP(hipMemcpy(d_one, one.data(), sizeof(float) * C, hipMemcpyHostToDevice));
-        OZ_HIP(hipMemset(d_nul, 0, sizeof(float) * C));
-        OZ_HIP(hipMemcpy(d_rows, &rows, sizeof(int), hipMemcpyHostToDevice));
+        // d_wtap (conv2's kernel as nine [C][C] matrices in the h2 layout, same power-of-two scale as d_wh[0]) was written by oz_net_commit
+        if (!d_one) {
+            if (int rc = alloc(&d_one, (size_t)C)) return rc;
+            if (int rc = alloc(&d_nul, (size_t)C)) return rc;
+            if (int rc = alloc(&d_rows, (size_t)1)) return rc;
+            std::vector<float> one((size_t)C, 1.0f);
+            const int rows = OZ_LUT_PATTERNS;
+            OZ_HIP(hipMemcpy(d_one, one.data(), sizeof(float) * C, hipMemcpyHostToDevice));
+            OZ_HIP(hipMemset(d_nul, 0, sizeof(float) * C));
+            OZ_HIP(hipMemcpy(d_rows, &rows, sizeof(int), hipMemcpyHostToDevice));
+        }
         if (!d_t2) { if (int rc = alloc(&d_t2, (size_t)9 * OZ_LUT_PATTERNS * C)) return rc; }
         int rc = OZ_OK;
         for (int t = 0; t < 9 && rc == OZ_OK; ++t)
-            rc = launch_gemm_h2<H2BigPP>(d_lut, 1, d_t2 + (size_t)t * OZ_LUT_PATTERNS * C, 0, d_rows, rows, 1, 1, 0, C, 1, C, 0, 1, nullptr,
+            rc = launch_gemm_h2<H2BigPP>(d_lut, 1, d_t2 + (size_t)t * OZ_LUT_PATTERNS * C, 0, d_rows, OZ_LUT_PATTERNS, 1, 1, 0, C, 1, C, 0, 1, nullptr,
                                          d_wtap + (size_t)t * C * (C / 4), d_one, d_nul, 0);
-        hipDeviceSynchronize();
-        hipFree(d_wtap); hipFree(d_one); hipFree(d_nul); hipFree(d_rows);
+        OZ_HIP(hipDeviceSynchronize());
         if (rc == OZ_OK) t2_ok = true;
         return rc;
     }
@@ -725,47 +713,50 @@ OZ_API int oz_net_commit(oz_net* net) {
             for (int c = 0; c < C; ++c) { w2[(size_t)(t * 2) * C + c] = o->w[0][(size_t)t * C + c]; w2[(size_t)(t * 2 + 1) * C + c] = -o->w[0][(size_t)t * C + c]; }
         if (int rc = upload(o, &o->d_w1, w2)) return rc;
     }
-    // conv2..4 kernels (3,3,Cin,Cout) -> [Cout][K], k = tap*Cin + ci ; dense (in,out) -> [out][in]
+    // conv2..4 kernels (3,3,Cin,Cout) and dense kernels (in,out) are uploaded as stored ([K][N], k = tap*Cin + ci) and
+    // re-laid out on the device: [N][K] fp32 for precision f32; the h2 layout [N][K/8][h1 x8 | h2 x8] in the GEMM's k order,
+    // pre-scaled by an exact power of two, for precision f16x2 (k_w_transpose / k_w_to_h2; the host loops took 0.4 s per commit)
     const int gl[5] = {6, 12, 18, 24, 30};
     const int Ks[5] = {9 * C, 9 * C, 9 * C, o->F, 1024}, Ns[5] = {C, C, C, 1024, 512};
-    for (int i = 0; i < 5; ++i) {
-        const auto& src = o->w[gl[i]];
-        std::vector<float> t((size_t)Ks[i] * Ns[i]);
-        for (int k = 0; k < Ks[i]; ++k)
-            for (int c = 0; c < Ns[i]; ++c) t[(size_t)c * Ks[i] + k] = src[(size_t)k * Ns[i] + c];
-        if (int rc = upload(o, &o->d_wt[i], t)) return rc;
+    {
+        size_t raw_max = 0;
+        for (int i = 0; i < 5; ++i) raw_max = std::max(raw_max, (size_t)Ks[i] * Ns[i]);
+        if (!o->d_raw) { if (int rc = o->alloc(&o->d_raw, raw_max)) return rc; }
     }
     if (o->precision == 0 && !o->d_part32 && o->part32_mult() > 0) {
         if (int rc = o->alloc(&o->d_part32, (size_t)o->part32_mult() * o->max_batch * 64 * 512)) return rc;
     }
-    if (o->precision == 1) {
-        // conv2..4 in the h2 layout [Cout][K/8][h1 x8 | h2 x8], k = tap*Cin + ci, pre-scaled by an exact power of two
-        for (int i = 0; i < 5; ++i) {
-            const auto& src = o->w[gl[i]];
-            const int K = Ks[i], N = Ns[i];
+    for (int i = 0; i < 5; ++i) {
+        const auto& src = o->w[gl[i]];
+        const int K = Ks[i], N = Ns[i];
+        OZ_REQUIRE(src.size() == (size_t)K * N, "weight %d has %zu values, expected %zu", gl[i], src.size(), (size_t)K * N);
+        OZ_HIP(hipMemcpy(o->d_raw, src.data(), sizeof(float) * src.size(), hipMemcpyHostToDevice));
+        if (o->precision == 0) {
+            if (!o->d_wt[i]) { if (int rc = o->alloc(&o->d_wt[i], (size_t)K * N)) return rc; }
+            hipLaunchKernelGGL(k_w_transpose, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, 0, o->d_raw, K, N, o->d_wt[i]);
+        } else {
             float mx = 0.f;
             for (float x : src) mx = fmaxf(mx, fabsf(x));
             const int kexp = mx > 0.f ? (int)floorf(log2f(1000.0f / mx)) : 0;
-            std::vector<uint16_t> h((size_t)N * K * 2);
-            // kernel k order (oz_net_h2.h): k' = (slice*taps + tap)*32 + c32  <->  keras k = tap*Cin + slice*32 + c32
-            const int taps = i < 3 ? 9 : 1, Cin = K / taps;
-            for (int c = 0; c < N; ++c)
-                for (int kp = 0; kp < K; ++kp) {
-                    const int tile = kp >> 5, c32 = kp & 31, slice = tile / taps, tap = tile - slice * taps;
-                    const int k = tap * Cin + slice * 32 + c32;
-                    const float x = ldexpf(src[(size_t)k * N + c], kexp);
-                    const _Float16 h1 = (_Float16)x, h2 = (_Float16)(x - (float)h1);
-                    const size_t base = ((size_t)c * (K / 8) + (kp >> 3)) * 16 + (kp & 7);
-                    memcpy(&h[base], &h1, 2); memcpy(&h[base + 8], &h2, 2);
-                }
-            if (!o->d_wh[i]) { if (int rc = o->alloc(&o->d_wh[i], h.size() / 8)) return rc; }
-            OZ_HIP(hipMemcpy(o->d_wh[i], h.data(), h.size() * 2, hipMemcpyHostToDevice));
-            std::vector<float> sc(N);
-            std::vector<float> host_scale(N);
+            const int taps = i < 3 ? 9 : 1;
+            if (!o->d_wh[i]) { if (int rc = o->alloc(&o->d_wh[i], (size_t)N * K / 4)) return rc; }
+            const long long threads = (long long)N * (K / 8);
+            hipLaunchKernelGGL(k_w_to_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, o->d_raw, K, N, taps, kexp, o->d_wh[i]);
+            if (i == 0) {     // conv2 once more as nine [C][C] matrices (taps = 1) for the T2 tables (build_t2)
+                if (!o->d_wtap) { if (int rc = o->alloc(&o->d_wtap, (size_t)9 * C * C / 4)) return rc; }
+                for (int t = 0; t < 9; ++t)
+                    hipLaunchKernelGGL(k_w_to_h2, dim3((unsigned)(((long long)C * (C / 8) + 255) / 256)), dim3(256), 0, 0,
+                                       o->d_raw + (size_t)t * C * C, C, C, 1, kexp, o->d_wtap + (size_t)t * C * (C / 4));
+            }
+            std::vector<float> sc(N), host_scale(N);
             OZ_HIP(hipMemcpy(host_scale.data(), o->d_scale[i + 1], sizeof(float) * N, hipMemcpyDeviceToHost));
             for (int c = 0; c < N; ++c) sc[c] = ldexpf(host_scale[c], -kexp);
             if (int rc = upload(o, &o->d_scale_h2[i], sc)) return rc;
         }
+        OZ_HIP(hipGetLastError());
+        OZ_HIP(hipDeviceSynchronize());                       // d_raw is reused by the next layer
+    }
+    if (o->precision == 1) {
         if (!o->d_flag) { if (int rc = o->alloc(&o->d_flag, 1)) return rc; }
         OZ_HIP(hipMemset(o->d_flag, 0, sizeof(int)));
         // split-K slabs: fc1 (4 x max_batch x 1024); small networks also split the convolutions 16 ways (latency path)

@@ -234,6 +234,39 @@ __global__ __launch_bounds__(256) void k_conv1_h2(const uint64_t* __restrict__ o
     if (over) atomicOr(flag, 1);
 }
 
+// ---- weight preparation on the device (oz_net_commit): the Keras kernels are uploaded as stored, [K][N] with k = tap * Cin + ci
+// [N][K] fp32 for the precision-f32 GEMM
+__global__ __launch_bounds__(256) void k_w_transpose(const float* __restrict__ src, int K, int N, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8 threads
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < K && c0 + tx < N) tile[r][tx] = src[(size_t)(k0 + r) * N + c0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (c0 + r < N && k0 + tx < K) out[(size_t)(c0 + r) * K + k0 + tx] = tile[tx][r];
+}
+// h2 layout [N][K/8][h1 x 8 | h2 x 8] of w * 2^kexp, in the GEMM's k order k' = (slice * taps + tap) * 32 + c32.
+// One thread per (output channel c, group of 8 k'); adjacent threads = adjacent c (coalesced reads of the [K][N] source).
+__global__ __launch_bounds__(256) void k_w_to_h2(const float* __restrict__ src, int K, int N, int taps, int kexp, uint4* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(idx % N);
+    const int grp = (int)(idx / N);
+    if (grp >= (K >> 3)) return;
+    const int Cin = K / taps;
+    f16x8 h1, h2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kp = grp * 8 + j, tile = kp >> 5, c32 = kp & 31, slice = tile / taps, tap = tile - slice * taps;
+        const int k = tap * Cin + slice * 32 + c32;
+        const float x = ldexpf(src[(size_t)k * N + c], kexp);
+        const _Float16 a = (_Float16)x;
+        h1[j] = a; h2[j] = (_Float16)(x - (float)a);
+    }
+    uint4* dst = out + ((size_t)c * (K >> 3) + grp) * 2;
+    dst[0] = *reinterpret_cast<uint4*>(&h1);
+    dst[1] = *reinterpret_cast<uint4*>(&h2);
+}
+
 // pattern id of every pixel: sum over the 3 x 3 neighbourhood (ky, kx) of 3^(ky*3+kx) * {0 empty or off the board, 1 own, 2 opponent}
 __global__ __launch_bounds__(256) void k_lut_ids(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
                                                  const int* __restrict__ d_count, int n, unsigned short* __restrict__ ids) {
