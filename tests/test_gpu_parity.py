@@ -837,3 +837,29 @@ def test_conv_pattern_tables_vs_float64(oz, n, cin, C, B):
     order = rs.permutation(B)[: B // 2]                          # another batch: other slots, other neighbours, other size
     p2, v2 = net.predict_batch(own[order], opp[order])
     assert np.array_equal(p2, pi[order]) and np.array_equal(v2, v[order])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py's N > 1 control flow (sharded game ids, barrier, max-over-ranks time, all-gather of records, one JSON line
+    on rank 0) with two ranks on this one GPU over gloo -- the driver runs the real thing over RCCL on 8 GPUs"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "36", "--warmup", "1",
+           "--board", "6", "--games", "64", "--sims", "6", "--backend", "gloo", "--same-device"]       # 6x6 games end within the run
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 36 and out["scaling"] == "weak" and out["value"] > 0
+    # records leave the engines when a game ends: both ranks' finished games (>= 28 moves each) are in the pooled tensor
+    assert out["games_completed"] >= 2 * 48 and out["pooled_records"] >= 28 * out["games_completed"]
+    assert "cpu_baseline" not in out and "cross_game_dedup" not in out
+    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
