@@ -128,7 +128,8 @@ def main():
     ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x2"],
                     help="conv arithmetic: exact fp32 matrix cores, or f32 via 2 x fp16 split (same 1e-5 parity tolerance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-dedup-compare", action="store_true", help="skip the second measurement (library default, de-duplication on)")
+    ap.add_argument("--no-dedup-compare", "--no-compare", dest="no_dedup_compare", action="store_true",
+                    help="skip the secondary measurements (de-duplication on; conv2 as a GEMM): profiling runs")
     ap.add_argument("--dedup", default="off", choices=["off", "on"],
                     help="cross-game leaf de-duplication in the timed region.  off (default for the headline): the network evaluates "
                          "every expansion -- no output is shared or cached; on: the library default (a board reached by several "
@@ -275,6 +276,28 @@ def main():
                 "expansions": int(q1["expansions"] - q0["expansions"]), "leaves_evaluated": int(q1["leaves_evaluated"] - q0["leaves_evaluated"]),
                 "note": "same games, same records; concurrent games that reach the same board in a step share one network evaluation "
                         "(k_compact). Not the headline: `value` above evaluates every expansion"}
+        if world == 1 and args.precision == "f16x2" and layer == 3 and not args.no_dedup_compare:
+            # the same K steps with conv1 / conv2 evaluated the plain way (conv1 kernel + conv2 as an MFMA implicit GEMM,
+            # no pattern tables): what the table form buys, and a number for readers who want every layer as a GEMM
+            net.profile(False)
+            net.set_tables(0)
+            eng3 = make_engine(args.dedup == "on")
+            advance(args.warmup, True, eng3)
+            eng3.sync()
+            g0 = eng3.stats()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            advance(args.steps, False, eng3)
+            eng3.sync()
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t2
+            g1 = eng3.stats()
+            net.set_tables(-1)
+            out["all_layers_as_gemm"] = {
+                "value": (g1["expansions"] - g0["expansions"]) / dt3, "unit": "node-expansions/s", "ms_per_step": dt3 / args.steps * 1e3,
+                "flop_per_expansion_executed": flop_ref,
+                "note": "same games, conv1 as a kernel and conv2 as the 256x256 ping-pong MFMA GEMM (oz_net_set_tables(net, 0)); "
+                        "(pi, v) agree with the table form to 5e-7"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.channels, args.sims)
         print(json.dumps(out), flush=True)

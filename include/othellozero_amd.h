@@ -93,6 +93,10 @@ int oz_net_time_forward(oz_net* net, int count, int iters, float* ms_avg);
 int oz_net_profile(oz_net* net, int enable);
 int oz_net_profile_read(oz_net* net, double* conv2_ms_total, int64_t* conv2_launches);
 int oz_net_profiled_layer(oz_net* net, int* layer);
+/* precision f16x2 only: how conv1 / conv2 are evaluated.  2 (default): both from tables over the 3^9 neighbourhood patterns
+ * of the discrete input planes (no GEMM for conv2); 1: conv1 from its table inside conv2's operand gather, conv2 an MFMA
+ * GEMM (bit-identical to 0); 0: conv1 kernel + conv2 MFMA GEMM; -1: back to the default.  Takes effect at the next forward. */
+int oz_net_set_tables(oz_net* net, int mode);
 
 /* ------------------------------------------------------------------ search
  * OthelloMCTS / MCTS (othelo_mcts.py:9-88, MCTS/__init__.py:19-187): num_games independent

@@ -187,6 +187,10 @@ class NNetWrapper(_NetHandle):
         _lib.check(_lib.load().oz_net_profile_read(self._h, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def set_tables(self, mode):
+        """f16x2: 2 = conv1 + conv2 from pattern tables (default), 1 = conv1 table + conv2 GEMM, 0 = conv1 kernel + conv2 GEMM"""
+        _lib.check(_lib.load().oz_net_set_tables(self._h, int(mode)))
+
     def profiled_layer(self):
         """which launch profile_read() timed: 2 = the conv2 GEMM, 3 = the conv3 GEMM (f16x2: conv1 + conv2 are a table gather-sum)"""
         layer = C.c_int()

@@ -76,7 +76,7 @@ SIGNATURES = {
     "oz_net_predict": [_vp, _u64p, _u64p, C.c_int, _f32p, _f32p],
     "oz_net_time_forward": [_vp, C.c_int, C.c_int, _f32p],
     "oz_net_profile": [_vp, C.c_int], "oz_net_profile_read": [_vp, _f64p, _i64p],
-    "oz_net_profiled_layer": [_vp, C.POINTER(C.c_int)],
+    "oz_net_profiled_layer": [_vp, C.POINTER(C.c_int)], "oz_net_set_tables": [_vp, C.c_int],
     "oz_mcts_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int],
     "oz_mcts_destroy": [_vp], "oz_mcts_reset": [_vp, C.c_int],
     "oz_mcts_set_roots": [_vp, _u64p, _u64p, _u8p],

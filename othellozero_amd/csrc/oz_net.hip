@@ -376,6 +376,7 @@ struct OnnNet : oz_net {
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double conv2_ms = 0; long long conv2_launches = 0;
+    int tables_mode = -1;            // oz_net_set_tables: -1 = environment default, 0 / 1 / 2 see forward_h2
     int profiled_layer = 2;          // 2 = conv2 GEMM, 3 = conv3 GEMM (when conv2 runs as the table gather-sum)
 
     template <typename T> int alloc(T** p, size_t count) {
@@ -508,8 +509,11 @@ struct OnnNet : oz_net {
         //                           to the conv1 kernel); OZ_H2_LUT=0 also implies no T2: conv1 kernel + conv2 GEMM
         static const bool lut_env = !(getenv("OZ_H2_LUT") && atoi(getenv("OZ_H2_LUT")) == 0);
         static const bool t2_env = !(getenv("OZ_H2_T2") && atoi(getenv("OZ_H2_T2")) == 0);
-        const bool use_t2 = lut_env && t2_env && t2_ok;
-        const bool use_lut = !use_t2 && pp && lut_env && lut_ok && max_batch > 32;
+        // tables_mode (oz_net_set_tables): -1 = the environment switches above, 0 = none, 1 = conv1 table only, 2 = both
+        const bool want_lut = tables_mode < 0 ? lut_env : tables_mode >= 1;
+        const bool want_t2 = tables_mode < 0 ? (lut_env && t2_env) : tables_mode >= 2;
+        const bool use_t2 = want_t2 && t2_ok;
+        const bool use_lut = !use_t2 && pp && want_lut && lut_ok && max_batch > 32;
         if (use_t2 || use_lut) {
             const long long threads = (long long)max_count * n * n;
             hipLaunchKernelGGL(k_lut_ids, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, d_lut_ids);
@@ -908,6 +912,15 @@ OZ_API int oz_debug_h2_stamps(unsigned long long* out48) {
     return OZ_OK;
 }
 #endif
+
+OZ_API int oz_net_set_tables(oz_net* net, int mode) {
+    OnnNet* o = as_onn(net);
+    OZ_REQUIRE(o, "not an OthelloNN network");
+    OZ_REQUIRE(mode >= -1 && mode <= 2, "tables mode must be -1 (default), 0 (none), 1 (conv1) or 2 (conv1 + conv2)");
+    std::lock_guard<std::mutex> lk(o->mu);
+    o->tables_mode = mode;
+    return OZ_OK;
+}
 
 OZ_API int oz_net_profiled_layer(oz_net* net, int* layer) {
     OnnNet* o = as_onn(net);
