@@ -353,14 +353,29 @@ __global__ __launch_bounds__(256) void k_conv2_lut(const unsigned short* __restr
     const int c8 = (int)(idx % cg) * 8;
     const int pix = (int)(pixel % P), y = pix / n, x = pix % n;
     const unsigned short* idp = ids + (pixel - pix);
-    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    // memory-level parallelism: all 9 pattern ids first, then all 18 row loads in flight together, then the sum in tap order
+    // (the straightforward loop compiled to 18 dependent round trips per thread: id, wait, row, wait, add, ...)
+    unsigned id[9];
+    bool ok[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-        if (iy < 0 || iy >= n || ix < 0 || ix >= n) continue;
-        const float* row = T2 + ((size_t)t * OZ_LUT_PATTERNS + idp[iy * n + ix]) * C + c8;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(row), b = *reinterpret_cast<const f32x4*>(row + 4);
-        lo += a; hi += b;
+        ok[t] = iy >= 0 && iy < n && ix >= 0 && ix < n;
+        id[t] = idp[ok[t] ? iy * n + ix : pix];              // off-board taps: the centre's id (a valid address)
+    }
+    f32x4 ra[9], rb[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {                            // branch-free: an off-board tap re-reads the centre tap's row (an L1 hit) and is not added
+        const float* row = T2 + ((size_t)(ok[t] ? t : 4) * OZ_LUT_PATTERNS + id[t]) * C + c8;
+        ra[t] = *reinterpret_cast<const f32x4*>(row);
+        rb[t] = *reinterpret_cast<const f32x4*>(row + 4);
+    }
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        lo += ok[t] ? ra[t] : z;
+        hi += ok[t] ? rb[t] : z;
     }
     f16x8 h1, h2;
     bool over = false;
