@@ -117,6 +117,7 @@ def cpu_baseline(n, channels, sims, budget_s=12.0):
 
 
 def main():
+    t_proc = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -189,6 +190,7 @@ def main():
             eng.run_steps(k * args.sims, sync=sync)
         else:
             eng.run(k, sync=sync)
+    t_setup = time.perf_counter() - t_proc                      # imports, network + table build, engine allocation
     advance(args.warmup, True)
     eng.sync()
     net.profile(True)
@@ -258,7 +260,10 @@ def main():
         out["dtype"] = "f32" if args.precision == "f32" else "f32 (2xf16 split)"
         out["dtype_detail"] = ("fp32 operands and accumulators on v_mfma_f32_32x32x2_f32" if args.precision == "f32" else
                                "fp32 values carried as two fp16 planes, 3 fp16 MFMA products per fp32 product, fp32 accumulate; pi, v within 1e-5 of float64")
+        wall = {"setup_s": round(t_setup, 2), "timed_region_s": round(dt, 2)}      # where this process's wall time goes (the driver clocks the whole run)
+        out["wall_breakdown"] = wall
         if world == 1 and args.dedup == "off" and not args.no_dedup_compare:
+            t_sec = time.perf_counter()
             # the same K steps with the library default (cross-game de-duplication on): identical records, fewer evaluations
             eng2 = make_engine(True)
             advance(args.warmup, True, eng2)
@@ -276,9 +281,11 @@ def main():
                 "expansions": int(q1["expansions"] - q0["expansions"]), "leaves_evaluated": int(q1["leaves_evaluated"] - q0["leaves_evaluated"]),
                 "note": "same games, same records; concurrent games that reach the same board in a step share one network evaluation "
                         "(k_compact). Not the headline: `value` above evaluates every expansion"}
+            wall["dedup_compare_s"] = round(time.perf_counter() - t_sec, 2)
         if world == 1 and args.precision == "f16x2" and layer == 3 and not args.no_dedup_compare:
             # the same K steps with conv1 / conv2 evaluated the plain way (conv1 kernel + conv2 as an MFMA implicit GEMM,
             # no pattern tables): what the table form buys, and a number for readers who want every layer as a GEMM
+            t_sec = time.perf_counter()
             net.profile(False)
             net.set_tables(0)
             eng3 = make_engine(args.dedup == "on")
@@ -298,8 +305,11 @@ def main():
                 "flop_per_expansion_executed": flop_ref,
                 "note": "same games, conv1 as a kernel and conv2 as the 256x256 ping-pong MFMA GEMM (oz_net_set_tables(net, 0)); "
                         "(pi, v) agree with the table form to 5e-7"}
+            wall["gemm_compare_s"] = round(time.perf_counter() - t_sec, 2)
         if world == 1 and not args.no_cpu_baseline:
+            t_sec = time.perf_counter()
             out["cpu_baseline"] = cpu_baseline(n, args.channels, args.sims)
+            wall["cpu_baseline_s"] = round(time.perf_counter() - t_sec, 2)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
