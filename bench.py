@@ -56,7 +56,8 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
     r = {"bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "traffic": hbm, "launches": int(launches),
          "avg_launch_ms": layer_ms / max(launches, 1), "flop_per_leaf": conv_flop_per_leaf(layer, n, channels)}
     if precision == "f32":
-        r.update(kernel="k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)",
+        r.update(kernel=("k_gemm_f32 (conv3: 3x3 valid, 512->512, 8x8 -> 6x6, implicit GEMM, v_mfma_f32_32x32x2_f32); conv1 + conv2 = k_conv2_lut_f32 table gather-sum"
+                         if layer == 3 else "k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)"),
                  peak=PEAK_F32_MATRIX_TFLOPS, frac=achieved / PEAK_F32_MATRIX_TFLOPS)
     else:
         pp = os.environ.get("OZ_H2_PP", "1") != "0"
@@ -282,7 +283,7 @@ def main():
                 "note": "same games, same records; concurrent games that reach the same board in a step share one network evaluation "
                         "(k_compact). Not the headline: `value` above evaluates every expansion"}
             wall["dedup_compare_s"] = round(time.perf_counter() - t_sec, 2)
-        if world == 1 and args.precision == "f16x2" and layer == 3 and not args.no_dedup_compare:
+        if world == 1 and layer == 3 and not args.no_dedup_compare:
             # the same K steps with conv1 / conv2 evaluated the plain way (conv1 kernel + conv2 as an MFMA implicit GEMM,
             # no pattern tables): what the table form buys, and a number for readers who want every layer as a GEMM
             t_sec = time.perf_counter()
@@ -303,7 +304,7 @@ def main():
             out["all_layers_as_gemm"] = {
                 "value": (g1["expansions"] - g0["expansions"]) / dt3, "unit": "node-expansions/s", "ms_per_step": dt3 / args.steps * 1e3,
                 "flop_per_expansion_executed": flop_ref,
-                "note": "same games, conv1 as a kernel and conv2 as the 256x256 ping-pong MFMA GEMM (oz_net_set_tables(net, 0)); "
+                "note": "same games, conv1 as a kernel and conv2 as an MFMA implicit GEMM (oz_net_set_tables(net, 0)); "
                         "(pi, v) agree with the table form to 5e-7"}
             wall["gemm_compare_s"] = round(time.perf_counter() - t_sec, 2)
         if world == 1 and not args.no_cpu_baseline:

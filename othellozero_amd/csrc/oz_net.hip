@@ -367,6 +367,9 @@ struct OnnNet : oz_net {
     float* d_t2 = nullptr;           // conv2 as a gather-sum (k_conv2_lut): [9][OZ_LUT_PATTERNS][C]
     uint4* d_wtap = nullptr;         // build_t2 staging: conv2's kernel as nine [C][C] matrices in the h2 layout
     float* d_raw = nullptr;          // oz_net_commit staging: one Keras kernel as stored
+    float* d_lut32 = nullptr;        // precision f32: conv1 pattern table [OZ_LUT_PATTERNS][C] fp32
+    float* d_wtap32 = nullptr;       // precision f32: conv2's kernel as nine [C(out)][C(in)] matrices
+    bool t2f_ok = false;             // precision f32: d_t2 holds the fp32 T2 tables
     float *d_one = nullptr, *d_nul = nullptr;
     int* d_rows = nullptr;
     bool t2_ok = false;
@@ -488,6 +491,33 @@ struct OnnNet : oz_net {
         return rc;
     }
 
+    // precision f32: the same tables in exact fp32 arithmetic (rows by k_lut_build_f32, T2 by nine fp32 MFMA GEMMs)
+    int build_t2_f32() {
+        if (!d_lut32) { if (int rc = alloc(&d_lut32, (size_t)OZ_LUT_PATTERNS * C)) return rc; }
+        if (!d_lut_ids) { if (int rc = alloc(&d_lut_ids, (size_t)max_batch * n * n)) return rc; }
+        if (!d_wtap32) { if (int rc = alloc(&d_wtap32, (size_t)9 * C * C)) return rc; }
+        if (!d_one) {
+            if (int rc = alloc(&d_one, (size_t)C)) return rc;
+            if (int rc = alloc(&d_nul, (size_t)C)) return rc;
+            if (int rc = alloc(&d_rows, (size_t)1)) return rc;
+            std::vector<float> one((size_t)C, 1.0f);
+            const int rows = OZ_LUT_PATTERNS;
+            OZ_HIP(hipMemcpy(d_one, one.data(), sizeof(float) * C, hipMemcpyHostToDevice));
+            OZ_HIP(hipMemset(d_nul, 0, sizeof(float) * C));
+            OZ_HIP(hipMemcpy(d_rows, &rows, sizeof(int), hipMemcpyHostToDevice));
+        }
+        if (!d_t2) { if (int rc = alloc(&d_t2, (size_t)9 * OZ_LUT_PATTERNS * C)) return rc; }
+        const long long threads = (long long)OZ_LUT_PATTERNS * C;
+        hipLaunchKernelGGL(k_lut_build_f32, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, C, d_w1, d_scale[0], d_shift[0], d_lut32);
+        OZ_HIP(hipGetLastError());
+        for (int t = 0; t < 9; ++t)
+            if (int rc = oz_gemm_f32_launch(d_lut32, d_wtap32 + (size_t)t * C * C, d_one, d_nul, d_t2 + (size_t)t * OZ_LUT_PATTERNS * C, d_rows,
+                                            OZ_LUT_PATTERNS, 1, 1, 0, C, 1, C, 0, 0, nullptr, 0, 0)) return rc;
+        OZ_HIP(hipDeviceSynchronize());
+        t2f_ok = true;
+        return OZ_OK;
+    }
+
     int check() override {
         if (!d_flag) return OZ_OK;
         int f = 0;
@@ -581,17 +611,29 @@ struct OnnNet : oz_net {
         if (max_count > max_batch) { oz_set_error("batch %d exceeds max_batch %d", max_count, max_batch); return OZ_ERR_ARG; }
         if (precision == 1) return forward_h2(d_own, d_opp, d_count, max_count, d_pi, d_v, s);
         const int P = n * n;
-        {
+        // precision f32: conv1 + conv2 from the fp32 pattern tables (default), or conv1 kernel + conv2 GEMM (oz_net_set_tables 0 / 1, OZ_H2_T2=0)
+        static const bool t2f_env = !(getenv("OZ_H2_T2") && atoi(getenv("OZ_H2_T2")) == 0) && !(getenv("OZ_H2_LUT") && atoi(getenv("OZ_H2_LUT")) == 0);
+        const bool use_t2f = (tables_mode < 0 ? t2f_env : tables_mode >= 2) && t2f_ok;
+        profiled_layer = use_t2f ? 3 : 2;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile && pending.size() > 4096) { if (int rc = collect_profile()) return rc; }
+        if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); }
+        if (use_t2f) {
+            const long long pixels = (long long)max_count * P, threads = pixels * (C / 8);
+            hipLaunchKernelGGL(k_lut_ids, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, d_lut_ids);
+            hipLaunchKernelGGL(k_conv2_lut_f32, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_lut_ids, d_count, n, C, d_t2,
+                               d_scale[1], d_shift[1], act2);
+            if (profile) OZ_HIP(hipEventRecord(e0, s));
+        } else {
             const long long threads = (long long)max_count * P * (C / 4);
             hipLaunchKernelGGL(k_conv1, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, C,
                                d_w1, d_scale[0], d_shift[0], act1);
+            if (profile) OZ_HIP(hipEventRecord(e0, s));
+            if (int rc = launch_gemm(act1, d_wt[0], 1, act2, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
+            if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
         }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (profile && pending.size() > 4096) { if (int rc = collect_profile()) return rc; }
-        if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); OZ_HIP(hipEventRecord(e0, s)); }
-        if (int rc = launch_gemm(act1, d_wt[0], 1, act2, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
-        if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
         if (int rc = launch_gemm(act2, d_wt[1], 2, act3, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
+        if (profile && use_t2f) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
         if (int rc = launch_gemm(act3, d_wt[2], 3, act4, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
         if (int rc = launch_gemm(act4, d_wt[3], 4, f1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
         if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
@@ -738,6 +780,12 @@ OZ_API int oz_net_commit(oz_net* net) {
         if (o->precision == 0) {
             if (!o->d_wt[i]) { if (int rc = o->alloc(&o->d_wt[i], (size_t)K * N)) return rc; }
             hipLaunchKernelGGL(k_w_transpose, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, 0, o->d_raw, K, N, o->d_wt[i]);
+            if (i == 0) {     // conv2 once more as nine [C(out)][C(in)] matrices for the fp32 T2 tables (build_t2_f32)
+                if (!o->d_wtap32) { if (int rc = o->alloc(&o->d_wtap32, (size_t)9 * C * C)) return rc; }
+                for (int t = 0; t < 9; ++t)
+                    hipLaunchKernelGGL(k_w_transpose, dim3((C + 31) / 32, (C + 31) / 32), dim3(256), 0, 0, o->d_raw + (size_t)t * C * C, C, C,
+                                       o->d_wtap32 + (size_t)t * C * C);
+            }
         } else {
             float mx = 0.f;
             for (float x : src) mx = fmaxf(mx, fabsf(x));
@@ -760,6 +808,9 @@ OZ_API int oz_net_commit(oz_net* net) {
         OZ_HIP(hipGetLastError());
         OZ_HIP(hipDeviceSynchronize());                       // d_raw is reused by the next layer
     }
+    o->t2f_ok = false;
+    o->t2_ok = false;
+    if (o->precision == 0) { if (int rc = o->build_t2_f32()) return rc; }
     if (o->precision == 1) {
         if (!o->d_flag) { if (int rc = o->alloc(&o->d_flag, 1)) return rc; }
         OZ_HIP(hipMemset(o->d_flag, 0, sizeof(int)));
@@ -926,7 +977,7 @@ OZ_API int oz_net_profiled_layer(oz_net* net, int* layer) {
     OnnNet* o = as_onn(net);
     OZ_REQUIRE(o && layer, "not an OthelloNN network / null argument");
     std::lock_guard<std::mutex> lk(o->mu);
-    *layer = o->precision == 1 ? o->profiled_layer : 2;
+    *layer = o->profiled_layer;
     return OZ_OK;
 }
 

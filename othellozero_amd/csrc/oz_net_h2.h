@@ -395,6 +395,68 @@ __global__ __launch_bounds__(256) void k_conv2_lut(const unsigned short* __restr
     if (over) atomicOr(flag, 1);
 }
 
+// ---- the same two tables for precision f32 (exact fp32 arithmetic: rows and sums in fp32, T2 built by the fp32 MFMA GEMM)
+// table32[id][C] = the row k_conv1 writes for a pixel with neighbourhood pattern id (same fmaf sequence; off-board taps
+// that k_conv1 skips are exact no-ops here)
+__global__ __launch_bounds__(256) void k_lut_build_f32(int C, const float* __restrict__ W /*[9][2][C]*/, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ table) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long id = idx / C;
+    if (id >= OZ_LUT_PATTERNS) return;
+    const int c = (int)(idx % C);
+    float acc = 0.f;
+    unsigned rest = (unsigned)id;
+    for (int t = 0; t < 9; ++t) {
+        const unsigned cell = rest % 3; rest /= 3;
+        acc = fmaf(cell == 1 ? 1.f : 0.f, W[(size_t)(t * 2 + 0) * C + c], acc);
+        acc = fmaf(cell == 2 ? 1.f : 0.f, W[(size_t)(t * 2 + 1) * C + c], acc);
+    }
+    table[(size_t)id * C + c] = fmaxf(fmaf(acc, scale[c], shift[c]), 0.f);
+}
+// conv2 = gather-sum over T2 (fp32), BN + ReLU, fp32 rows [pixel][C]
+__global__ __launch_bounds__(256) void k_conv2_lut_f32(const unsigned short* __restrict__ ids, const int* __restrict__ d_count, int n, int C,
+                                                       const float* __restrict__ T2, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ out) {
+    const int cg = C >> 3, P = n * n;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long pixel = idx / cg;
+    if (pixel >= (long long)(*d_count) * P) return;
+    const int c8 = (int)(idx % cg) * 8;
+    const int pix = (int)(pixel % P), y = pix / n, x = pix % n;
+    const unsigned short* idp = ids + (pixel - pix);
+    unsigned id[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+        ok[t] = iy >= 0 && iy < n && ix >= 0 && ix < n;
+        id[t] = idp[ok[t] ? iy * n + ix : pix];
+    }
+    f32x4 ra[9], rb[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float* row = T2 + ((size_t)(ok[t] ? t : 4) * OZ_LUT_PATTERNS + id[t]) * C + c8;
+        ra[t] = *reinterpret_cast<const f32x4*>(row);
+        rb[t] = *reinterpret_cast<const f32x4*>(row + 4);
+    }
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        lo += ok[t] ? ra[t] : z;
+        hi += ok[t] ? rb[t] : z;
+    }
+    f32x4 r0, r1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r0[j] = fmaxf(fmaf(lo[j], scale[c8 + j], shift[c8 + j]), 0.f);
+        r1[j] = fmaxf(fmaf(hi[j], scale[c8 + 4 + j], shift[c8 + 4 + j]), 0.f);
+    }
+    float* dst = out + (size_t)pixel * C + c8;
+    __builtin_nontemporal_store(r0, reinterpret_cast<f32x4*>(dst));
+    __builtin_nontemporal_store(r1, reinterpret_cast<f32x4*>(dst + 4));
+}
+
 // out[M][N] = act((A[M][K] . W[N][K]^T) * scale + shift); A and W in the h2 layout; M = *d_count * Hout^2.
 // CF::LUT: `in` is the pattern table, lut_ids the per-pixel pattern ids [batch][Hin^2] (k_lut_ids).
 // zero_line: >= 128 B of zeros in global memory (source of out-of-image taps and of rows beyond M).

@@ -810,8 +810,9 @@ def test_cross_game_leaf_dedup_changes_nothing_but_the_work(oz, kind, monkeypatc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
 @pytest.mark.parametrize("n,cin,C,B", [(8, 2, 512, 130), (6, 2, 256, 70), (8, 1, 256, 40), (6, 1, 512, 33)])
-def test_conv_pattern_tables_vs_float64(oz, n, cin, C, B):
+def test_conv_pattern_tables_vs_float64(oz, n, cin, C, B, precision):
     """precision f16x2 evaluates conv1 + conv2 as lookups in tables indexed by the 3^9 neighbourhood patterns of the
     discrete input planes (k_lut_ids / k_conv2_lut, tables built at commit): within 1e-5 of the float64 oracle on random
     boards AND on the corner cases of the pattern index (empty board, one colour everywhere, full board, single discs on
@@ -819,7 +820,7 @@ def test_conv_pattern_tables_vs_float64(oz, n, cin, C, B):
     from othellozero_amd.NNet import NNetWrapper, NeuralNets
     from othellozero_amd.weights import init_weights
     w = init_weights(n, seed=31 + n + cin, channels=C, randomize_all=True, in_channels=cin)
-    net = NNetWrapper((n, n), num_channels_1=C, max_batch=B, precision="f16x2", weights=w,
+    net = NNetWrapper((n, n), num_channels_1=C, max_batch=B, precision=precision, weights=w,
                       network=NeuralNets.ONN if cin == 2 else NeuralNets.BNN)
     rs = np.random.RandomState(1000 * n + cin)
     valid = np.uint64(sum(1 << (r * 8 + c) for r in range(n) for c in range(n)))
@@ -837,6 +838,13 @@ def test_conv_pattern_tables_vs_float64(oz, n, cin, C, B):
     order = rs.permutation(B)[: B // 2]                          # another batch: other slots, other neighbours, other size
     p2, v2 = net.predict_batch(own[order], opp[order])
     assert np.array_equal(p2, pi[order]) and np.array_equal(v2, v[order])
+    net.set_tables(0)                                            # conv1 kernel + conv2 GEMM: the same network, another summation order
+    p0, v0 = net.predict_batch(own, opp)
+    assert np.abs(p0 - pi).max() <= 2e-6 and np.abs(v0 - v).max() <= 2e-6
+    assert net.profiled_layer() == 2
+    net.set_tables(-1)
+    p3, v3 = net.predict_batch(own, opp)
+    assert np.array_equal(p3, pi) and np.array_equal(v3, v) and net.profiled_layer() == 3
 
 
 @pytest.mark.gpu
