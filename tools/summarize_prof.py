@@ -51,10 +51,13 @@ def trace(d, out, header):
     # precision f32: the gemm shapes ordered by total time (conv2 > conv3 > conv4 > fc1 > fc2 holds for this net)
     names = {}
     h2 = {("H2BigPPLut", 1048576): "conv2", ("H2BigPP>", 1048576): "conv2", ("H2MidPP", 786432): "conv3", ("H2BigPP>", 262144): "conv4",
-          ("H2BigPP>", 131072): "fc1", ("H2Cfg<1, 2, 2, 2>", 32768): "fc2"}
+          ("H2BigPP>", 131072): "fc1", ("H2Cfg<1, 2, 2, 2>", 32768): "fc2",
+          # precision f32: k_gemm_f32, 128 x 128 tiles, 256 threads
+          ("k_gemm_f32", 2097152): "conv2", ("k_gemm_f32", 1179648): "conv3", ("k_gemm_f32", 524288): "conv4",
+          ("k_gemm_f32", 65536): "fc1", ("k_gemm_f32", 32768): "fc2"}
     for k in rows:
         for (sub, grid), lay in h2.items():
-            if "k_gemm_h2" in k[0] and sub in k[0] and k[1] == grid and len(rows[k]) >= 50:
+            if "k_gemm" in k[0] and sub in k[0] and k[1] == grid and len(rows[k]) >= 50:
                 names[k] = lay
     if not names:
         gemm = sorted((k for k in rows if "k_gemm" in k[0] and len(rows[k]) >= 50), key=lambda k: -sum(rows[k]))
@@ -104,10 +107,12 @@ def traffic(src, out, precision, kernel_sub, grid, layer="conv2"):
     write = vals["WRITE_SIZE"] * 1024
     # algorithmic bytes per leaf (h2 activations are 4 B per value, like fp32): input pixels + output pixels + the layer's weights once per launch
     alg = {"conv2": 64 * 2048 + 64 * 2048 + 9 * 512 * 512 * 4 / LEAVES, "conv3": 64 * 2048 + 36 * 2048 + 9 * 512 * 512 * 4 / LEAVES}[layer]
+    if precision == "f32" and layer == "conv2":
+        alg = 262144.0 + 18 * 512 * 512 * 4 / LEAVES           # as first committed: the transposed copy of the kernel counted too
     j = {"round": 1, "precision": precision, "kernel": f"{kernel_sub} {layer}", "leaves_per_launch": LEAVES,
          "fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
          "hbm_bytes_per_leaf": (fetch + write) / LEAVES,
-         "algorithmic_bytes_per_leaf": alg if precision == "f16x2" else 262144.0 + 18 * 512 * 512 * 4 / LEAVES,
+         "algorithmic_bytes_per_leaf": alg,
          "source": src}
     if "GRBM_GUI_ACTIVE" in vals:                  # summed over the 8 XCDs
         j["gpu_cycles_per_launch"] = vals["GRBM_GUI_ACTIVE"] / 8
