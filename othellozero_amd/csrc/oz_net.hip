@@ -228,7 +228,8 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
         // the split is chosen from `sizing_count` when given (a per-network constant: results then do not depend on the
         // size of an individual call), else from this launch's own grid
         const long long Ms = (long long)(sizing_count > 0 ? sizing_count : max_count) * Hout * Hout;
-        const int grid_s = ((int)((Ms + GM_BM - 1) / GM_BM) + 7) / 8 * 8 * (N / GM_BN);
+        // blocks that have rows to work on (the grid is padded to a multiple of 8 row tiles for the XCD mapping; padding blocks exit at once)
+        const int grid_s = (int)((Ms + GM_BM - 1) / GM_BM) * (N / GM_BN);
         while (ksplit < 16 && grid_s * ksplit < 256 && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * (Ms > Mmax ? Ms : Mmax) * N <= partial_floats) ksplit *= 2;
     }
     g.ksplit = ksplit; g.slab = Mmax * N;

@@ -706,7 +706,7 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
             const int wblocks = taps[l] * (Cin[l] / 128) * (Cc / 128);
             const long long wcount = (long long)taps[l] * Cin[l] * Cc, wtiles = ((long long)B * P + 31) / 32;
             int msplit = 1;
-            while (msplit < 16 && wblocks * msplit < 512 && wtiles / (msplit * 2) >= 16 && wcount * msplit * 2 <= t->gpartial_floats) msplit *= 2;
+            while (msplit < 16 && wblocks * msplit < 512 && wtiles / (msplit * 2) >= 8 && wcount * msplit * 2 <= t->gpartial_floats) msplit *= 2;
             hipLaunchKernelGGL(k_wgrad_f32, dim3(wblocks, msplit), dim3(256), 0, s, t->a[l - 1], t->dz[l], t->d_count, g, t->grad(6 * l), msplit,
                                t->gpartial, wcount);
             if (msplit > 1)
