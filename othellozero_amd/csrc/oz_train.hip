@@ -431,6 +431,10 @@ struct oz_trainer {
     float *dA[2] = {}, *sums = nullptr, *partial = nullptr, *ones = nullptr, *zeros = nullptr;
     float *p = nullptr, *v = nullptr, *dlogit = nullptr, *dvpre = nullptr, *loss = nullptr, *losses = nullptr;
     float* gpartial = nullptr;           // split-K scratch of the small-batch GEMMs
+    float* wpartial = nullptr;           // row-split scratch of the weight-gradient launches (they run on s2, beside the data-gradient chain)
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_dz[6] = {}, ev_w = nullptr;
+    bool overlap = true;                 // env OZ_TRAIN_OVERLAP=0: weight gradients on the main stream
     long long gpartial_floats = 16LL << 20;
     int split_mask = 7;                  // diagnostic (env OZ_TRAIN_SPLIT_MASK): 1 forward, 2 dense dgrad, 4 conv dgrad GEMMs may split K
     int P_[6], Co[6], Hout[6], Hz[6], zoff[6];
@@ -441,6 +445,9 @@ struct oz_trainer {
     ~oz_trainer() {
         hipSetDevice(device);
         for (void* q : allocs) hipFree(q);
+        for (hipEvent_t e : ev_dz) if (e) hipEventDestroy(e);
+        if (ev_w) hipEventDestroy(ev_w);
+        if (s2) hipStreamDestroy(s2);
         if (s) hipStreamDestroy(s);
     }
     float* param(int idx) { return toff[idx] >= 0 ? P + toff[idx] : stats[idx]; }
@@ -524,6 +531,11 @@ OZ_API int oz_trainer_create(oz_trainer** out, int n, int channels, int in_chann
         T_ALLOC(t->p, (size_t)max_batch * A); T_ALLOC(t->v, max_batch); T_ALLOC(t->dlogit, (size_t)max_batch * A); T_ALLOC(t->dvpre, max_batch);
         T_ALLOC(t->loss, 2 * (size_t)max_batch); T_ALLOC(t->losses, 4);
         T_ALLOC(t->gpartial, t->gpartial_floats);
+        T_ALLOC(t->wpartial, t->gpartial_floats);
+        OZ_HIP(hipStreamCreateWithFlags(&t->s2, hipStreamNonBlocking));
+        for (int l = 0; l < 6; ++l) OZ_HIP(hipEventCreateWithFlags(&t->ev_dz[l], hipEventDisableTiming));
+        OZ_HIP(hipEventCreateWithFlags(&t->ev_w, hipEventDisableTiming));
+        { const char* e = getenv("OZ_TRAIN_OVERLAP"); t->overlap = !(e && atoi(e) == 0); }
         OZ_HIP(hipStreamSynchronize(t->s));
         return OZ_OK;
     }();
@@ -707,10 +719,19 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
             const long long wcount = (long long)taps[l] * Cin[l] * Cc, wtiles = ((long long)B * P + 31) / 32;
             int msplit = 1;
             while (msplit < 16 && wblocks * msplit < 512 && wtiles / (msplit * 2) >= 8 && wcount * msplit * 2 <= t->gpartial_floats) msplit *= 2;
-            hipLaunchKernelGGL(k_wgrad_f32, dim3(wblocks, msplit), dim3(256), 0, s, t->a[l - 1], t->dz[l], t->d_count, g, t->grad(6 * l), msplit,
-                               t->gpartial, wcount);
+            // the weight gradient only needs a[l - 1] and dz[l]: it runs on the second stream beside the data-gradient chain
+            // (dgrad -> BN backward of the layer below -> ...), whose small-batch launches leave most CUs idle
+            hipStream_t sw = s;
+            float* wp = t->gpartial;
+            if (t->overlap) {
+                OZ_HIP(hipEventRecord(t->ev_dz[l], s));
+                OZ_HIP(hipStreamWaitEvent(t->s2, t->ev_dz[l], 0));
+                sw = t->s2; wp = t->wpartial;
+            }
+            hipLaunchKernelGGL(k_wgrad_f32, dim3(wblocks, msplit), dim3(256), 0, sw, t->a[l - 1], t->dz[l], t->d_count, g, t->grad(6 * l), msplit,
+                               wp, wcount);
             if (msplit > 1)
-                hipLaunchKernelGGL(k_t_sum_partials, dim3((unsigned)((wcount + 255) / 256)), dim3(256), 0, s, t->gpartial, msplit, wcount, t->grad(6 * l));
+                hipLaunchKernelGGL(k_t_sum_partials, dim3((unsigned)((wcount + 255) / 256)), dim3(256), 0, sw, wp, msplit, wcount, t->grad(6 * l));
             OZ_HIP(hipGetLastError());
             // data gradient -> dA[cur ^ 1] = gradient wrt a[l - 1]
             if (l >= 4) {          // dense: dX = dZ . W^T; the Keras kernel [in][out] already is the [N = in][K = out] operand
@@ -722,6 +743,10 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
             }
             cur ^= 1;
         }
+    }
+    if (t->overlap) {                              // every gradient is complete before the caller (Adam, all-reduce, get_grad) sees the arena
+        OZ_HIP(hipEventRecord(t->ev_w, t->s2));
+        OZ_HIP(hipStreamWaitEvent(s, t->ev_w, 0));
     }
     float h[4];
     OZ_HIP(hipMemcpyAsync(h, t->losses, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
