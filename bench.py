@@ -194,6 +194,8 @@ def main():
     t_setup = time.perf_counter() - t_proc                      # imports, network + table build, engine allocation
     advance(args.warmup, True)
     eng.sync()
+    if world > 1:           # warm-up of the exchange step too (communicator channels for both collectives), like the W untimed steps
+        gather_records(torch.zeros((8, 48), dtype=torch.uint8, device=dev))
     net.profile(True)
     s0 = eng.stats()
     ev0 = eng.eval_time()
