@@ -455,6 +455,8 @@ struct OnnNet : oz_net {
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Mid>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Mid::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Thin>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Thin::LDS));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small2::LDS));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Thin2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Thin2::LDS));
             h2_attr_set = true;
         }
         hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS + (CF::LUT ? 9 * CF::BM * 2 : 0), s, (const uint4*)in,
@@ -467,6 +469,15 @@ struct OnnNet : oz_net {
         }
         OZ_HIP(hipGetLastError());
         return OZ_OK;
+    }
+
+    // small tiles (dense layers, latency path): three LDS stages for medium and large networks (-4 .. -6 % per forward at 128 .. 512
+    // positions, +-0 at 4096), the two-stage loop for the 16-way split-K launches of small networks, where the deeper pipeline
+    // measured SLOWER (one position: 0.152 -> 0.186 ms).  Bit-identical either way; OZ_H2_STAGES=2 / 3 forces one (A/B runs).
+    template <typename CF3, typename CF2, typename... Args> int launch_small(Args... args) {
+        static const int forced = getenv("OZ_H2_STAGES") ? atoi(getenv("OZ_H2_STAGES")) : 0;
+        const bool two = forced == 2 || (forced != 3 && max_batch <= 32);
+        return two ? launch_gemm_h2<CF2>(args...) : launch_gemm_h2<CF3>(args...);
     }
 
     // T2[t] = table . W_t^T (raw k-sums, scaled 2^kexp like the convolution's): nine GEMMs M = OZ_LUT_PATTERNS, K = N = C
@@ -576,7 +587,7 @@ struct OnnNet : oz_net {
             const long long threads = (long long)max_count * n * n * (C / 8);
             hipLaunchKernelGGL(k_conv2_lut, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_lut_ids, d_count, n, C, d_t2,
                                d_scale_h2[0], d_shift[1], (uint4*)act2, d_flag);
-        } else if (int rc = small     ? launch_gemm_h2<H2Small>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, 16)
+        } else if (int rc = small     ? launch_small<H2Small, H2Small2>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, 16)
                             : use_lut ? launch_gemm_h2<H2BigPPLut>(d_lut, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2, d_lut_ids)
                             : pp      ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)
                                       : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)) return rc;
@@ -585,22 +596,22 @@ struct OnnNet : oz_net {
         // 3-phase loop on the 192-row tile (24-MFMA clusters): bit-identical, measured 0 .. +2 % on conv3 -- the layer is clock / power
         // bound, not load-section bound -- so the 4-phase loop stays the default; OZ_H2_PP3=1 selects it
         static const bool pp3 = getenv("OZ_H2_PP3") && atoi(getenv("OZ_H2_PP3")) != 0;
-        if (int rc = small ? launch_gemm_h2<H2Small>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, 16)
+        if (int rc = small ? launch_small<H2Small, H2Small2>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, 16)
                      : pp && pp3 ? launch_gemm_h2<H2MidPP3>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                      : pp  ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                            : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
         if (int rc = mark(3, false)) return rc;
-        if (int rc = small ? launch_gemm_h2<H2Small>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, 16)
+        if (int rc = small ? launch_small<H2Small, H2Small2>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, 16)
                      : pp  ? launch_gemm_h2<H2BigPP>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
                            : launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)) return rc;
         // fc1: K = 8192 but only batch x 1024 outputs -> split-K (fixed-order reduce) to fill the chip
         // (large batches: on the 256 x 256 ping-pong tile, 16 x 4 tiles x 4 k-slices = one block per CU; bit-identical to
         //  the 128 x 128 tile because the k-slices and the order inside them are the same -- tools/pp_race_check.py)
         static const bool fc1pp = !(getenv("OZ_H2_FC1PP") && atoi(getenv("OZ_H2_FC1PP")) == 0);
-        if (int rc = small ? launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)
+        if (int rc = small ? launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)
                      : (fc1pp && pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
-                                                          : launch_gemm_h2<H2Small>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
-        if (int rc = launch_gemm_h2<H2Thin>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
+                                                          : launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
+        if (int rc = launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
         hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
         OZ_HIP(hipGetLastError());
         return OZ_OK;

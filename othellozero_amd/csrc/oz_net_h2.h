@@ -69,10 +69,11 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // tile configurations: NWM x NWN waves, each wave NTI x NTJ blocks of 32 x 32 (= 2 x 2 MFMA tiles of 16 x 16)
 //   H2Big   (3x3 convolutions): 2 x 4 waves, wave tile 128 x 64 -> block 256 x 256, 512 threads, 128 KB LDS
 //   H2Small (dense layers):     2 x 2 waves, wave tile  64 x 64 -> block 128 x 128, 256 threads,  64 KB LDS
-template <int NWM, int NWN, int NTI, int NTJ> struct H2Cfg {
+template <int NWM, int NWN, int NTI, int NTJ, int NST = 2> struct H2Cfg {
     static constexpr int WM = NWM, WN = NWN, TI = NTI, TJ = NTJ;
     static constexpr int BM = NWM * NTI * 32, BN = NWN * NTJ * 32, NW = NWM * NWN, NT = NW * 64;
-    static constexpr int TILEA = BM * 128, TILEB = BN * 128, BUF = TILEA + TILEB, LDS = 2 * BUF;
+    static constexpr int STAGES = NST;    // LDS stages of the one-barrier loop (> 2: k-tiles prefetched STAGES - 1 ahead, counted vmcnt)
+    static constexpr int TILEA = BM * 128, TILEB = BN * 128, BUF = TILEA + TILEB, LDS = NST * BUF;
     static constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW);     // LDS-DMA instructions per wave per operand tile
     // h2 epilogue: each wave transposes PB 16-row blocks (x 64 channels) per pass through a private LDS slice
     static constexpr int PB = (NTI % 2 == 0) ? 4 : 2, SLICE = PB * 16 * 256;
@@ -96,8 +97,14 @@ struct H2BigPPLut : H2BigPP { static constexpr bool LUT = true; };
 #define OZ_LUT_PATTERNS 19683
 #define OZ_LUT_ROWS (OZ_LUT_PATTERNS + 1)  // row OZ_LUT_PATTERNS = zeros
 typedef H2Cfg<2, 4, 3, 2> H2Mid;      // conv3 (M = B*36): 192 x 256 -> 1536 blocks = 6.0 rounds of 256 CUs (256 x 256: 4.5)
-typedef H2Cfg<2, 2, 2, 2> H2Small;    // 128 x 128
-typedef H2Cfg<1, 2, 2, 2> H2Thin;     // dense layers (M = batch): 64 x 128, 2 waves -> 512 / 256 blocks at B = 4096
+typedef H2Cfg<2, 2, 2, 2> H2Small2;   // 128 x 128, two LDS stages (kept for A/B runs: OZ_H2_STAGES=2)
+typedef H2Cfg<1, 2, 2, 2> H2Thin2;    // 64 x 128, 2 waves, two stages
+// The small tiles serve launches with few k-tiles of MFMA work per wave: with two stages every k-tile exposes an LDS-DMA
+// round trip; three stages keep two k-tiles in flight (counted vmcnt, one barrier per k-tile).  Same accumulation order,
+// bit-identical results (tools/pp_race_check.py).  Measured: -4 .. -6 % per forward at 128 .. 512 positions, +-0 at 4096,
+// but SLOWER on the 16-way split-K launches of one-position networks (9 k-tiles per block) -- oz_net.hip picks per network.
+typedef H2Cfg<2, 2, 2, 2, 3> H2Small; // 128 x 128, 3 x 32 KB of LDS
+typedef H2Cfg<1, 2, 2, 2, 3> H2Thin;  // dense layers (M = batch): 64 x 128, 2 waves -> 512 / 256 blocks at B = 4096; 3 x 24 KB
 
 struct H2Geom {
     int Hin, Hout, pad, Cin, taps;        // taps 9 (3x3 conv) or 1 (dense, Hin = Hout = 1)
@@ -846,13 +853,28 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     } else {
+    constexpr int S = CF::STAGES;
+    if constexpr (S > 2) {
+#pragma unroll
+        for (int p = 0; p < S - 1; ++p) stage(kbeg + p, p);  // S - 1 k-tiles in flight (past the end: the last tile again, harmless)
+    } else {
     stage(kbeg, 0);
     __syncthreads();                                         // drains the DMA (vmcnt(0)) and publishes the tile
+    }
     for (int kt = kbeg; kt < nk; ++kt) {
-        const int buf = (kt - kbeg) & 1;
+        const int buf = S > 2 ? (kt - kbeg) % S : (kt - kbeg) & 1;
+        if constexpr (S > 2) {
+            // tile kt has landed once at most (S - 2) tiles' worth of younger DMA instructions of this wave are outstanding;
+            // the barrier publishes it and also proves that every wave is done reading the buffer staged next (read in kt - 1)
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S - 2) * (IA + IB)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stage(kt + S - 1, (kt - kbeg + S - 1) % S);
+        } else {
 #ifndef H2_EXP_NODMA                      // H2_EXP_* : timing experiments only (wrong results), see tools/build_variant.sh
         stage(kt + 1, buf ^ 1);
 #endif
+        }
         const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * RI * 16 + r16) * 128;
         const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
         f16x8 b1[RJ], b2[RJ];
@@ -880,9 +902,15 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read (global_load_lds)
             }
         }
+        if constexpr (S == 2) {
 #ifndef H2_EXP_NOBARRIER
         __syncthreads();
 #endif
+        }
+    }
+    if constexpr (S > 2) {                                   // the re-staged tail tiles have landed before the epilogue reuses the LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
     }   // !CF::PP
 

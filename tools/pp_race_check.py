@@ -35,7 +35,8 @@ def run(tag, extra):
 # group A: conv2 as a GEMM (OZ_H2_T2=0) -- every loop / staging variant must agree to the bit
 A = [run(tag, dict(extra, OZ_H2_T2="0")) for tag, extra in (
     ("simple", {"OZ_H2_PP": "0"}), ("pingpong", {"OZ_H2_PP": "1"}), ("pingpong_fc1small", {"OZ_H2_PP": "1", "OZ_H2_FC1PP": "0"}),
-    ("pingpong_conv1kernel", {"OZ_H2_PP": "1", "OZ_H2_LUT": "0"}), ("pingpong_conv3_3phase", {"OZ_H2_PP": "1", "OZ_H2_PP3": "1"}))]
+    ("pingpong_conv1kernel", {"OZ_H2_PP": "1", "OZ_H2_LUT": "0"}), ("pingpong_conv3_3phase", {"OZ_H2_PP": "1", "OZ_H2_PP3": "1"}),
+    ("small_tiles_2stage", {"OZ_H2_PP": "1", "OZ_H2_STAGES": "2"}), ("small_tiles_3stage", {"OZ_H2_PP": "1", "OZ_H2_STAGES": "3"}))]
 # group B: the default (conv1 + conv2 as the table gather-sum): the two loops still agree to the bit (conv3, conv4, fc1),
 # and the gather-sum agrees with the GEMM to rounding (another summation order of the same products)
 B = [run(tag, extra) for tag, extra in (("t2_simple", {"OZ_H2_PP": "0"}), ("t2_pingpong", {"OZ_H2_PP": "1"}))]
