@@ -462,10 +462,15 @@ struct OnnNet : oz_net {
         hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS + (CF::LUT ? 9 * CF::BM * 2 : 0), s, (const uint4*)in,
                            w_alt ? w_alt : (const uint4*)d_wh[layer - 1], scale_alt ? scale_alt : d_scale_h2[layer - 1],
                            shift_alt ? shift_alt : d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag, lut_ids);
-        if (ksplit > 1) {
+        if (ksplit > 1 && out_h2) {
             const long long threads = (long long)max_count * Hout * Hout * (N / 8);
             hipLaunchKernelGGL(k_splitk_reduce_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)d_partial,
                                g.slab, ksplit, N, Hout * Hout, d_count, d_scale_h2[layer - 1], d_shift[layer], 1, (uint4*)out_final, d_flag);
+        } else if (ksplit > 1) {                  // fp32 rows out (fc2): the fp32 path's fixed-order reduce
+            const long long quads = ((long long)max_count * Hout * Hout * N + 3) / 4;
+            hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float*)d_partial, g.slab, ksplit, N,
+                               Hout * Hout, d_count, scale_alt ? scale_alt : d_scale_h2[layer - 1], shift_alt ? shift_alt : d_shift[layer], relu,
+                               (float*)out_final);
         }
         OZ_HIP(hipGetLastError());
         return OZ_OK;
@@ -611,7 +616,8 @@ struct OnnNet : oz_net {
         if (int rc = small ? launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)
                      : (fc1pp && pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
                                                           : launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
-        if (int rc = launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
+        // fc2: one position has 4 blocks of 32 k-tiles -> small networks split k 8 ways too
+        if (int rc = launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, small ? 8 : 1)) return rc;
         hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
