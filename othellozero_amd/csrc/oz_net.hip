@@ -616,8 +616,8 @@ struct OnnNet : oz_net {
         if (int rc = small ? launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)
                      : (fc1pp && pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
                                                           : launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
-        // fc2: one position has 4 blocks of 32 k-tiles -> small networks split k 8 ways too
-        if (int rc = launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, small ? 8 : 1)) return rc;
+        // fc2: one position has 4 blocks of 32 k-tiles -> small networks split k 8 ways too, medium ones 4 ways (from max_batch)
+        if (int rc = launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, small ? 8 : max_batch <= 512 ? 4 : 1)) return rc;
         hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
