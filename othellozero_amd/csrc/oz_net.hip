@@ -535,6 +535,7 @@ struct OnnNet : oz_net {
         return OZ_OK;
     }
 
+    const int* flag_device() override { return d_flag; }
     int check() override {
         if (!d_flag) return OZ_OK;
         int f = 0;
@@ -880,30 +881,35 @@ OZ_API int oz_net_predict(oz_net* net, const uint64_t* own, const uint64_t* opp,
     std::lock_guard<std::mutex> lk(net->mu);
     hipSetDevice(net->device);
     const int n2 = net->n * net->n;
-    uint64_t *d_own = nullptr, *d_opp = nullptr; int* d_count = nullptr; float *d_pi = nullptr, *d_v = nullptr;
-    int rc = OZ_OK;
-    hipError_t e;
-    if ((e = hipMalloc((void**)&d_own, 8ull * count)) != hipSuccess || (e = hipMalloc((void**)&d_opp, 8ull * count)) != hipSuccess ||
-        (e = hipMalloc((void**)&d_count, 4)) != hipSuccess || (e = hipMalloc((void**)&d_pi, 4ull * count * n2)) != hipSuccess ||
-        (e = hipMalloc((void**)&d_v, 4ull * count)) != hipSuccess) {
-        oz_set_error("hipMalloc failed: %s", hipGetErrorString(e)); rc = OZ_ERR_HIP;
+    const size_t B = (size_t)net->max_batch;
+    if (!net->p_in) {           // staging buffers live with the network
+        hipError_t e;
+        if ((e = hipMalloc((void**)&net->p_in, 8 * (2 * B + 1))) != hipSuccess || (e = hipMalloc((void**)&net->p_out, 4 * B * (n2 + 1))) != hipSuccess) {
+            hipFree(net->p_in); hipFree(net->p_out);
+            net->p_in = nullptr; net->p_out = nullptr;
+            oz_set_error("hipMalloc failed: %s", hipGetErrorString(e));
+            return OZ_ERR_HIP;
+        }
+        net->h_in.resize(2 * B + 1);
+        net->h_out.resize(B * (n2 + 1) + 1);
     }
-    if (!rc) {
-        hipMemcpy(d_own, own, 8ull * count, hipMemcpyHostToDevice);
-        hipMemcpy(d_opp, opp, 8ull * count, hipMemcpyHostToDevice);
-        hipMemcpy(d_count, &count, 4, hipMemcpyHostToDevice);
-        rc = net->forward_device(d_own, d_opp, d_count, count, d_pi, d_v, 0);
-    }
-    if (!rc) {
-        if ((e = hipDeviceSynchronize()) != hipSuccess) { oz_set_error("forward failed: %s", hipGetErrorString(e)); rc = OZ_ERR_HIP; }
-    }
-    if (!rc) {
-        hipMemcpy(pi, d_pi, 4ull * count * n2, hipMemcpyDeviceToHost);
-        hipMemcpy(v, d_v, 4ull * count, hipMemcpyDeviceToHost);
-        rc = net->check();
-    }
-    hipFree(d_own); hipFree(d_opp); hipFree(d_count); hipFree(d_pi); hipFree(d_v);
-    return rc;
+    // device image: own[0..count) | opp[count..2 count) | count
+    memcpy(net->h_in.data(), own, 8ull * count);
+    memcpy(net->h_in.data() + count, opp, 8ull * count);
+    net->h_in[2 * count] = (uint64_t)(uint32_t)count;
+    OZ_HIP(hipMemcpyAsync(net->p_in, net->h_in.data(), 8ull * (2 * count + 1), hipMemcpyHostToDevice, 0));
+    float* d_pi = net->p_out;
+    float* d_v = net->p_out + (size_t)count * n2;
+    if (int rc = net->forward_device(net->p_in, net->p_in + count, reinterpret_cast<const int*>(net->p_in + 2 * count), count, d_pi, d_v, 0)) return rc;
+    OZ_HIP(hipMemcpyAsync(net->h_out.data(), net->p_out, 4ull * count * (n2 + 1), hipMemcpyDeviceToHost, 0));
+    int flag = 0;
+    const int* fd = net->flag_device();
+    if (fd) OZ_HIP(hipMemcpyAsync(&flag, fd, sizeof(int), hipMemcpyDeviceToHost, 0));
+    hipError_t e = hipStreamSynchronize(0);
+    if (e != hipSuccess) { oz_set_error("forward failed: %s", hipGetErrorString(e)); return OZ_ERR_HIP; }
+    memcpy(pi, net->h_out.data(), 4ull * count * n2);
+    memcpy(v, net->h_out.data() + (size_t)count * n2, 4ull * count);
+    return flag ? net->check() : OZ_OK;
 }
 
 __global__ void k_fill_boards(uint64_t* own, uint64_t* opp, int count, uint64_t valid) {
