@@ -88,14 +88,15 @@ int oz_net_commit(oz_net* net);
 int oz_net_predict(oz_net* net, const uint64_t* own, const uint64_t* opp, int count, float* pi, float* v);
 /* timing hook for bench.py: run the forward `iters` times on `count` resident boards, return avg ms per forward (HIP events) */
 int oz_net_time_forward(oz_net* net, int count, int iters, float* ms_avg);
-/* HIP-event timing of the dominant launch on the stream it is launched on: the conv2 implicit GEMM, or -- precision
- * f16x2, where conv1 + conv2 run as a table gather-sum -- the conv3 implicit GEMM; oz_net_profiled_layer says which (2 / 3) */
+/* HIP-event timing of the dominant launch on the stream it is launched on: the conv3 implicit GEMM when conv1 + conv2
+ * run as a table gather-sum (the default), else the conv2 implicit GEMM; oz_net_profiled_layer says which (3 / 2) */
 int oz_net_profile(oz_net* net, int enable);
 int oz_net_profile_read(oz_net* net, double* conv2_ms_total, int64_t* conv2_launches);
 int oz_net_profiled_layer(oz_net* net, int* layer);
-/* precision f16x2 only: how conv1 / conv2 are evaluated.  2 (default): both from tables over the 3^9 neighbourhood patterns
- * of the discrete input planes (no GEMM for conv2); 1: conv1 from its table inside conv2's operand gather, conv2 an MFMA
- * GEMM (bit-identical to 0); 0: conv1 kernel + conv2 MFMA GEMM; -1: back to the default.  Takes effect at the next forward. */
+/* how conv1 / conv2 are evaluated.  2 (default): both from tables over the 3^9 neighbourhood patterns of the discrete
+ * input planes (no GEMM for conv2; tables rebuilt by oz_net_commit); 1 (precision f16x2, max_batch > 32): conv1 from its table
+ * inside conv2's operand gather, conv2 an MFMA GEMM (bit-identical to 0); 0: conv1 kernel + conv2 MFMA GEMM; -1: back to the
+ * default.  Takes effect at the next forward. */
 int oz_net_set_tables(oz_net* net, int mode);
 
 /* ------------------------------------------------------------------ search
