@@ -871,3 +871,32 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert out["games_completed"] >= 2 * 48 and out["pooled_records"] >= 28 * out["games_completed"]
     assert "cpu_baseline" not in out and "cross_game_dedup" not in out
     assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_contract(tmp_path):
+    """bench.py prints ONE JSON line with the contract's fields; the secondary measurements ride beside the headline"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--games", "256", "--sims", "16",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in out, k
+    assert out["metric"] == "mcts_node_expansions_per_sec" and out["n_gpus"] == 1 and out["steps"] == 3 and out["vs_baseline"] is None
+    assert "workload" in out["config"] and "model" not in out["config"]
+    rf = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["launches"] == 3 * 16
+    # every expansion is evaluated in the timed region; the de-duplicated and all-GEMM rates are separate objects
+    assert out["leaves_evaluated_rank0"] == out["expansions"]
+    assert out["cross_game_dedup"]["leaves_evaluated"] < out["cross_game_dedup"]["expansions"] == out["expansions"]
+    assert out["all_layers_as_gemm"]["value"] > 0 and out["flop_per_expansion"]["executed"] < out["flop_per_expansion"]["reference_network"]
