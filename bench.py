@@ -4,22 +4,30 @@
 
 One *step* = one move round: every one of the 4096 resident games runs 100 lock-step simulations (select ->
 leaf compaction -> one batched OthelloNN evaluation -> expand/backup, x100), then chooses, records and plays
-one move; a finished game is replaced by a fresh one in the same slot (continuous self-play), so all slots
-stay busy for the whole timed region and completed games are counted exactly.
+one move; a finished game is replaced by a fresh one in the same slot (continuous self-play).  Before the timed
+region the slots are spread over the plies of a game (oz_selfplay_stagger: slot g starts (g*60)/4096 plies into its
+first game, played untimed by the same searched self-play), so the engine is in the steady state of a long-running
+service: every move round completes ~G/60 games, and games/s, sims/s and expansions/s are all measured in any window.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-Prints ONE JSON line on rank 0: value = node expansions per second over all GPUs (the BASELINE metric; the
-same line carries games/s and sims/s), `roofline` for the dominant kernel (precision f16x2: the conv3 implicit-GEMM
-launch -- conv1 + conv2 are table lookups there; precision f32: the conv2 launch; HIP events on the launch stream)
-and `cpu_baseline` (the CPU oracle -- the reference algorithm with batch-1 leaf evaluation -- timed on this host's
-cores on a bounded sample).  In the timed region the network evaluates EVERY expansion (cross-game de-duplication
-off); the rate with the library default (on) is measured afterwards and reported as `cross_game_dedup` (N = 1).
+With N > 1 and no launcher environment (RANK / WORLD_SIZE unset) this process only SPAWNS the N ranks (one child
+process per GPU, RCCL rendezvous on 127.0.0.1) and relays rank 0's JSON line -- it never touches the GPU itself; under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks run directly.  A realised world
+size different from --gpus is an error (exit 2), never a silent 1-GPU run.
+
+Prints ONE JSON line on rank 0: value = node expansions per second over all GPUs (the BASELINE metric; the same line
+carries games/s and sims/s), `roofline` for the dominant kernel (HIP events on the launch stream, in the timed region),
+and -- at N = 1 -- `kernels` (every kernel of a step against its own roof), `exact_fp32` (the same workload in exact fp32
+arithmetic), `config4` (6x6 boards), `cross_game_dedup`, `all_layers_as_gemm`, `dropin_config0` (configs[0] through the
+reference's Python surface), `parity_sample_max_err` and `cpu_baseline` (the CPU oracle -- the reference algorithm with
+batch-1 leaf evaluation -- timed on this host's cores on a bounded sample).  In the timed region the network evaluates
+EVERY expansion (cross-game de-duplication off).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,31 +38,37 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_EXPANSION = {8: 566428672, 6: 270185472}          # SURVEY.md 8(d), whole OthelloNN forward
 PEAK_F32_MATRIX_TFLOPS = 157.3                             # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_F16_MATRIX_TFLOPS = 2500.0                            # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16 MFMA
+PEAK_HBM_GBPS = 8000.0                                     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_L2_GBPS = 34500.0                                     # MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s (8 XCDs x 4 MiB)
+TREE_BYTES_PER_SIM = 1300                                  # algorithmic HBM bytes per simulation on the tree side
 
 
 def conv_flop_per_leaf(layer, n, C):
-    """implicit-GEMM FLOP of conv2 (layer 2: n x n outputs) / conv3 (layer 3: (n-2) x (n-2) outputs) per leaf"""
-    px = n * n if layer == 2 else (n - 2) * (n - 2)
-    return 2 * px * (9 * C) * C                            # 8x8: conv2 301 989 888, conv3 169 869 312 FLOP
-
-
-PEAK_F16_MATRIX_TFLOPS = 2500.0                            # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16 MFMA
+    """implicit-GEMM FLOP per leaf of conv2 (layer 2: n x n outputs), conv3 ((n-2)^2 outputs), conv4 ((n-4)^2 outputs)"""
+    px = {2: n * n, 3: (n - 2) * (n - 2), 4: (n - 4) * (n - 4)}[layer]
+    return 2 * px * (9 * C) * C                            # 8x8: conv2 301 989 888, conv3 169 869 312, conv4 75 497 472 FLOP
 
 
 def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, channels):
-    """Dominant kernel.  precision f32: the conv2 implicit GEMM (53 % of the network's FLOPs).  precision f16x2 (default):
-    conv1 + conv2 run as a table gather-sum (k_conv2_lut, ~0.15 ms), so the dominant launch is the conv3 implicit GEMM
-    (64 % of the FLOPs that are left).  `achieved` is ALGORITHMIC fp32 TFLOP/s (2*M*K*N per launch / HIP-event time on
-    the launch stream).  f32: v_mfma_f32_32x32x2_f32, peak 157.3.  f16x2: every fp32 product costs 3 fp16 MFMA
-    products, so the matrix pipe executes 3x `achieved`; both fractions are reported against the 2.5 PFLOP/s dense fp16 peak."""
-    hbm = None
+    """Dominant kernel.  precision f32 / f16x2 with the pattern tables (default): conv1 + conv2 run as a table gather-sum
+    (k_conv2_lut), so the dominant launch is the conv3 implicit GEMM; without the tables it is the conv2 implicit GEMM.
+    `achieved` is ALGORITHMIC fp32 TFLOP/s (2*M*K*N per launch / HIP-event time on the launch stream).
+    f32: v_mfma_f32_32x32x2_f32, peak 157.3.  f16x2: every fp32 product costs 3 fp16 MFMA products, so the matrix pipe
+    executes 3x `achieved`; both fractions are reported against the 2.5 PFLOP/s dense fp16 peak."""
+    hbm, src = None, None
     try:      # HBM-side bytes per leaf from the committed PMC profile of this kernel (profiles/), scaled per launch
-        tj = json.load(open(os.path.join(ROOT, "profiles", f"conv{layer}_traffic_{precision}.json")))
+        rel = os.path.join("profiles", f"conv{layer}_traffic_{precision}.json")
+        tj = json.load(open(os.path.join(ROOT, rel)))
         hbm = tj["hbm_bytes_per_leaf"] * expansions / max(launches, 1)
+        src = f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel, separate passes, gfx950 x2 read correction) x leaves per launch of this run; not re-measured in this run"
     except Exception:
         pass
-    r = {"bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "traffic": hbm, "launches": int(launches),
-         "avg_launch_ms": layer_ms / max(launches, 1), "flop_per_leaf": conv_flop_per_leaf(layer, n, channels)}
+    r = {"bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "traffic": hbm, "traffic_source": src, "launches": int(launches),
+         "avg_launch_ms": layer_ms / max(launches, 1), "flop_per_leaf": conv_flop_per_leaf(layer, n, channels),
+         "algorithmic_bytes_per_launch": None}
+    px_in, px_out = {2: (n * n, n * n), 3: (n * n, (n - 2) ** 2), 4: ((n - 2) ** 2, (n - 4) ** 2)}[layer]
+    r["algorithmic_bytes_per_launch"] = (expansions / max(launches, 1)) * (px_in + px_out) * channels * 4 + 9 * channels * channels * 4
     if precision == "f32":
         r.update(kernel=("k_gemm_f32 (conv3: 3x3 valid, 512->512, 8x8 -> 6x6, implicit GEMM, v_mfma_f32_32x32x2_f32); conv1 + conv2 = k_conv2_lut_f32 table gather-sum"
                          if layer == 3 else "k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)"),
@@ -74,6 +88,49 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
                  matrix_pipe_frac=3 * achieved / PEAK_F16_MATRIX_TFLOPS,
                  vs_fp32_matrix_peak=achieved / PEAK_F32_MATRIX_TFLOPS)
     return r
+
+
+def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tables):
+    """every kernel of a move round against its own roof.  net_k / tree_k: {name: (ms_total, launches)} over `rounds` move
+    rounds that evaluated `leaves` positions and ran `sims_done` simulations."""
+    peak_mm = PEAK_F32_MATRIX_TFLOPS if precision == "f32" else PEAK_F16_MATRIX_TFLOPS
+    F = (n - 4) * (n - 4) * C
+    flop = {"conv2": conv_flop_per_leaf(2, n, C), "conv3": conv_flop_per_leaf(3, n, C), "conv4": conv_flop_per_leaf(4, n, C),
+            "fc1": 2 * F * 1024, "fc2": 2 * 1024 * 512}
+    out = []
+    for name, (ms, cnt) in net_k.items():
+        if cnt == 0:
+            continue
+        row = {"name": name, "ms_per_step": ms / rounds, "launches_per_step": cnt / rounds}
+        sec = ms * 1e-3
+        if name == "conv2" and tables:
+            # k_conv2_lut: per pixel 9 table rows of C fp32 read (L2 / Infinity Cache: the 363 MB table does not fit in L2,
+            # the pattern distribution is skewed) + one row written (HBM)
+            byts = leaves * n * n * (9 * C * 4 + C * 4)
+            row.update(kernel="k_conv2_lut" + ("_f32" if precision == "f32" else ""), bound="l2", achieved=byts / sec / 1e9, peak=PEAK_L2_GBPS, unit="GB/s")
+        elif name in flop:
+            kern = "k_gemm_f32" if precision == "f32" else "k_gemm_h2"
+            row.update(kernel=f"{kern} ({name})", bound="mfma", achieved=leaves * flop[name] / sec / 1e12, peak=peak_mm, unit="TFLOP/s")
+        elif name == "input":
+            byts = leaves * (16 + n * n * 2) if tables else leaves * (16 + n * n * C * 4)
+            row.update(kernel="k_lut_ids" if tables else "k_conv1", bound="hbm", achieved=byts / sec / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s")
+        elif name == "heads":
+            byts = leaves * (512 * 4 + (n * n + 1) * 4)
+            row.update(kernel="k_heads", bound="hbm", achieved=byts / sec / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s")
+        row["frac"] = row["achieved"] / row["peak"]
+        out.append(row)
+    tree_ms = sum(ms for name, (ms, cnt) in tree_k.items() if name != "network")
+    for name, (ms, cnt) in tree_k.items():
+        if name == "network" or cnt == 0:
+            continue
+        out.append({"name": name, "kernel": {"select": "k_select", "compact": "k_compact", "expand_backup": "k_expand_backup",
+                                             "roots_move": "k_sp_roots + k_sp_move"}[name],
+                    "ms_per_step": ms / rounds, "launches_per_step": cnt / rounds, "bound": "hbm (latency-bound integer work)",
+                    # the tree side as a whole moves ~1.3 KB of algorithmic HBM bytes per simulation (SURVEY 8(d)); this kernel's share of it by time
+                    "achieved": sims_done * TREE_BYTES_PER_SIM / (tree_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": sims_done * TREE_BYTES_PER_SIM / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                    "note": "achieved / frac are those of the four tree kernels together"})
+    return out
 
 
 def cpu_baseline(n, channels, sims, budget_s=12.0):
@@ -111,27 +168,160 @@ def cpu_baseline(n, channels, sims, budget_s=12.0):
         "value": exp / t, "unit": "node-expansions/s", "cores": threads, "kind": "port",
         "sample": f"{plies} plies of {games} sequential {n}x{n} game(s) at {sims} sims/move "
                   f"({exp} expansions, {plies * sims} sims, {t:.1f} s), batch-1 leaf eval, OpenMP x{threads}",
-        "sims_per_s": plies * sims / t,
+        "sims_per_s": plies * sims / t, "games_per_s": games / t,
         "value_1_thread": ep1["stats"]["expansions"] / t1, "sample_1_thread": f"first 2 plies of game 0 ({t1:.1f} s)",
         "cpu_model": model, "host_cpus": os.cpu_count(),
     }
+
+
+def cpu_baseline_config(n, channels, sims, budget_s):
+    """the same port on another config (configs 1, 2 and 4): whole sequential games within budget_s"""
+    import oracle
+    from othellozero_amd.weights import init_weights
+    w = init_weights(n, seed=0, channels=channels)
+    threads = min(oracle.lib().orc_nn_max_threads(), 16)
+    net = oracle.CNet(w, n, channels=channels, nthreads=threads)
+    t, exp, plies, games = 0.0, 0, 0, 0
+    while t < budget_s and games < 64:
+        m = oracle.Mcts(n, 1.0, oracle.QMODE_F64, evaluator=net.evaluator())
+        t0 = time.perf_counter()
+        ep = m.episode(sims, 1.0, 0.9, 1234, games)
+        t += time.perf_counter() - t0
+        exp, plies, games = exp + ep["stats"]["expansions"], plies + ep["n_moves"], games + 1
+    return {"value": exp / t, "unit": "node-expansions/s", "cores": threads, "kind": "port", "games_per_s": games / t,
+            "sample": f"{games} sequential {n}x{n} game(s) at {sims} sims/move ({exp} expansions, {t:.1f} s), batch-1 leaf eval, OpenMP x{threads}"}
+
+
+def dropin_config0(channels, precision):
+    """BASELINE configs[0] through the reference's own Python surface (training.execute_episode -> OthelloMCTS.simulate ->
+    NNetWrapper.predict, one position per call: training.py:26-72) on the GPU library, and the CPU port of the same
+    episode (same RNG streams, so the same game when the two networks agree on every arg-max) beside it."""
+    import random
+    import numpy as np
+    import oracle
+    from othellozero_amd import training
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.weights import init_weights
+    n, sims = 8, 25
+    net = NNetWrapper((n, n), num_channels_1=channels, max_batch=1, seed=0, precision=precision)
+    random.seed(0); np.random.seed(0)
+    training.execute_episode(n, net, 1, 2, 1, 0.9)                 # untimed: first-call allocations, code object load
+    random.seed(1); np.random.seed(1)
+    t0 = time.perf_counter()
+    ex = training.execute_episode(n, net, 1, sims, 1, 0.9)
+    t_gpu = time.perf_counter() - t0
+    moves = len(ex) // 8
+    w = init_weights(n, seed=0, channels=channels)
+    threads = min(oracle.lib().orc_nn_max_threads(), 16)
+    cnet = oracle.CNet(w, n, channels=channels, nthreads=threads)
+    m = oracle.Mcts(n, 1.0, oracle.QMODE_F64, evaluator=cnet.evaluator())
+    t0 = time.perf_counter()
+    ep = m.episode(sims, 1.0, 0.9, 1234, 0)
+    t_cpu = time.perf_counter() - t0
+    return {"workload": "BASELINE configs[0]: one 8x8 self-play game, 25 sims/move, random-init OthelloNN, through the reference's "
+                        "execute_episode / OthelloMCTS / NNetWrapper.predict surface (one position per call)",
+            "gpu_dropin": {"seconds": t_gpu, "moves": moves, "sims": moves * sims, "sims_per_s": moves * sims / t_gpu, "games_per_s": 1.0 / t_gpu,
+                           "path": "Python drop-in over the C ABI: per simulation one select + one predict (latency kernels, 16-way split-K) + one backup call"},
+            "cpu_port": {"seconds": t_cpu, "moves": int(ep["n_moves"]), "sims": int(ep["n_moves"]) * sims, "expansions": int(ep["stats"]["expansions"]),
+                         "sims_per_s": int(ep["n_moves"]) * sims / t_cpu, "games_per_s": 1.0 / t_cpu, "cores": threads, "kind": "port"}}
+
+
+def parity_sample(net, eng, n, channels, count=256):
+    """the checker, after the timed region: `count` of the positions the engine holds right now, evaluated by the network
+    object the timed region used (same kernels, same max_batch) and by the float64 oracle"""
+    import numpy as np
+    from oracle import nn_numpy
+    from othellozero_amd.weights import init_weights
+    st = eng.state()
+    idx = np.linspace(0, st["black"].size - 1, count).astype(np.int64)
+    own = np.where(st["player"][idx] == 1, st["black"][idx], st["white"][idx])
+    opp = np.where(st["player"][idx] == 1, st["white"][idx], st["black"][idx])
+    pi, v = net.predict_batch(own, opp)
+    pi64, v64 = nn_numpy.forward_chunked(init_weights(n, seed=0, channels=channels), own, opp, n, chunk=128)
+    return {"max_abs_err_pi": float(np.abs(pi.reshape(count, -1) - pi64).max()), "max_abs_err_v": float(np.abs(v - v64).max()),
+            "positions": int(count), "plies_sampled": [int(st["ply"][idx].min()), int(st["ply"][idx].max())], "tolerance": 1e-5,
+            "checker": "oracle/nn_numpy.py (float64 restatement of Net/OthelloNN.py:42-56)"}
+
+
+# ---------------------------------------------------------------------------------------------------------------- launcher
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher environment: start the N ranks as child processes of THIS process (which never
+    initialises HIP), relay rank 0's stdout, fail if any rank fails or the realised world size is not N.
+    Replaces the role of WorkerManager fan-out in the reference (workers.py:168-184,298-303)."""
+    import socket
+    import tempfile
+    n = args.gpus
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    out_file = tempfile.TemporaryFile(mode="w+")               # rank 0's stdout (a file, so a long line can never block the rank)
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OZ_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out_file if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    rc = 0
+    try:
+        pending = set(range(n))
+        deadline = time.time() + float(os.environ.get("OZ_BENCH_TIMEOUT", "1500"))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+            if rc != 0 or time.time() > deadline:
+                if rc == 0:
+                    rc = 124
+                    print("bench.py: ranks did not finish in time", file=sys.stderr)
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:                      # the exact children started above, nothing else
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    out_file.seek(0)
+    out0 = out_file.read()
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if rc == 0:
+        if len(lines) != 1:
+            print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+            rc = 3
+        else:
+            got = json.loads(lines[0]).get("n_gpus")
+            if got != n:
+                print(f"bench.py: asked for {n} GPUs, the ranks realised a world of {got}", file=sys.stderr)
+                rc = 2
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
 
 
 def main():
     t_proc = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--board", type=int, default=8)
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x2"],
                     help="conv arithmetic: exact fp32 matrix cores, or f32 via 2 x fp16 split (same 1e-5 parity tolerance)")
+    ap.add_argument("--stagger-sims", type=int, default=-1,
+                    help="simulations per move of the untimed stagger phase that spreads the slots over the plies of a game "
+                         "(-1 = --sims: the staggered plies are ordinary self-play at full strength; 0 = no stagger: all games start "
+                         "at ply 0 and none completes for ~60 move rounds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-dedup-compare", "--no-compare", dest="no_dedup_compare", action="store_true",
-                    help="skip the secondary measurements (de-duplication on; conv2 as a GEMM): profiling runs")
+    ap.add_argument("--no-dedup-compare", "--no-compare", dest="no_compare", action="store_true",
+                    help="skip the secondary measurements (kernels, exact fp32, 6x6, de-duplication on, conv2 as a GEMM, drop-in, parity sample): profiling runs")
     ap.add_argument("--dedup", default="off", choices=["off", "on"],
                     help="cross-game leaf de-duplication in the timed region.  off (default for the headline): the network evaluates "
                          "every expansion -- no output is shared or cached; on: the library default (a board reached by several "
@@ -144,12 +334,18 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))                            # parent: spawns the ranks, never initialises the GPU
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.same_device:
         local_rank = 0
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher realised WORLD_SIZE={world}; refusing to report a {world}-GPU number as {args.gpus}",
+              file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
@@ -159,6 +355,9 @@ def main():
     from othellozero_amd.training import SelfPlayEngine
 
     _lib.require_gpu()
+    if not args.same_device and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible", file=sys.stderr)
+        sys.exit(2)
     _lib.check(_lib.load().oz_set_device(local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -168,14 +367,20 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
 
     n, G = args.board, args.games
+    stagger_sims = args.sims if args.stagger_sims < 0 else args.stagger_sims
+    period = n * n - 4
     net = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0, precision=args.precision)   # same weights on every rank
-    def make_engine(dedup):
+
+    def make_engine(dedup, the_net=net, board=n, games=G, steps=args.steps):
         os.environ["OZ_DEDUP"] = "1" if dedup else "0"          # read when the engine's search object is created
-        return SelfPlayEngine(net, n, G, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * G,
-                              game_id_stride=world * G, q_mode=_lib.QMODE_F64, refill=True,
-                              record_cap=int(G * (args.steps + args.warmup + 2) * 1.25))
+        return SelfPlayEngine(the_net, board, games, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * games,
+                              game_id_stride=world * games, q_mode=_lib.QMODE_F64, refill=True,
+                              record_cap=int(games * (steps + args.warmup + board * board + 2) * 1.25))
     eng = make_engine(args.dedup == "on")
 
     def barrier():
@@ -186,30 +391,57 @@ def main():
     # one bench step = `sims` network batches of up to G leaves: a move round in lock step; in free-running mode the same
     # number of batches, each full (network-free simulations and moves ride along).  Measured: no throughput difference --
     # a batch's cost is proportional to its leaves, so filling the ~8 % empty slots buys nothing
-    def advance(k, sync, eng=eng):
+    def advance(e, k, sync):
         if args.driver == "free":
-            eng.run_steps(k * args.sims, sync=sync)
+            e.run_steps(k * args.sims, sync=sync)
         else:
-            eng.run(k, sync=sync)
+            e.run(k, sync=sync)
+
+    def measure(e, steps, the_net=None):
+        """warm-up + `steps` timed move rounds on engine e (single rank, secondary legs) -> (stats delta, seconds);
+        with the_net: HIP events around its dominant launch during the timed rounds only"""
+        advance(e, args.warmup, True)
+        e.sync()
+        if the_net is not None:
+            the_net.profile_kernels(reset=True)
+            the_net.profile(1)
+        a = e.stats()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        advance(e, steps, False)
+        e.sync()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t
+        b = e.stats()
+        if the_net is not None:
+            the_net.profile(0)
+        return {k: b[k] - a[k] for k in ("simulations", "expansions", "games_completed", "moves", "leaves_evaluated", "node_visits")}, dt_
+
     t_setup = time.perf_counter() - t_proc                      # imports, network + table build, engine allocation
-    advance(args.warmup, True)
+    t_sec = time.perf_counter()
+    if stagger_sims >= 2:
+        eng.stagger(stagger_sims)                               # untimed: slot g is (g * 60) / G plies into its first game
+    t_stagger = time.perf_counter() - t_sec
+    advance(eng, args.warmup, True)
     eng.sync()
     if world > 1:           # warm-up of the exchange step too (communicator channels for both collectives), like the W untimed steps
         gather_records(torch.zeros((8, 48), dtype=torch.uint8, device=dev))
-    net.profile(True)
+    net.profile(1)
     s0 = eng.stats()
     ev0 = eng.eval_time()
     barrier()
     t0 = time.perf_counter()
-    advance(args.steps, False)
+    advance(eng, args.steps, False)
     eng.sync()
-    pooled = gather_records(engine_records_tensor(eng, dev))       # the path's only exchange step
+    # the path's only exchange step: the move records of the games that ended inside the timed region, pooled over the ranks
+    pooled = gather_records(engine_records_tensor(eng, dev)[s0["records"]:])
     barrier()
     dt = time.perf_counter() - t0
     s1 = eng.stats()
     ev1 = eng.eval_time()
-    conv2_ms, conv2_launches = net.profile_read()               # the dominant launch: conv2, or conv3 when conv2 is a gather-sum
+    dom_ms, dom_launches = net.profile_read()                   # the dominant launch: conv3 (conv2 is a gather-sum), or conv2
     layer = net.profiled_layer()
+    net.profile(0)
 
     d = {k: s1[k] - s0[k] for k in ("simulations", "expansions", "terminal_hits", "node_visits", "moves", "games_completed", "leaves_evaluated")}
     vec = torch.tensor([d["expansions"], d["simulations"], d["games_completed"], d["moves"], d["node_visits"]],
@@ -223,15 +455,17 @@ def main():
 
     if rank == 0:
         # network work is counted per position actually evaluated (a board reached by several games in one step is evaluated once)
-        flop_conv2 = d["leaves_evaluated"] * conv_flop_per_leaf(layer, n, args.channels)
-        achieved = flop_conv2 / (conv2_ms * 1e-3) / 1e12 if conv2_ms > 0 else 0.0
+        flop_dom = d["leaves_evaluated"] * conv_flop_per_leaf(layer, n, args.channels)
+        achieved = flop_dom / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         # FLOP the GPU executes per expansion: the reference network's, minus conv1 + conv2 when they run as table lookups
         flop_ref = FLOP_PER_EXPANSION.get(n, 0)
         flop_exec = flop_ref - (conv_flop_per_leaf(2, n, args.channels) + 2 * n * n * 18 * args.channels if layer == 3 else 0)
         nn_ms = ev1["ms"] - ev0["ms"]
+        ply_now = eng.state()["ply"]
         out = {
             "metric": "mcts_node_expansions_per_sec", "value": exp_all / dt, "unit": "node-expansions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": world if (world > 1 and args.backend == "nccl") else (0 if world > 1 else 1),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{G} concurrent {n}x{n} self-play games per GPU, {args.sims} sims/move, batched leaf eval "
@@ -242,6 +476,10 @@ def main():
                             f"finished games refilled; leaf evaluator = the reference's OthelloNN ({args.channels} filters), random init seed 0",
                 "games_per_gpu": G, "sims_per_move": args.sims, "board": n,
                 "q_mode": "float64 (NumPy 1.18.5 promotion)", "driver": args.driver, "parallelism": f"games sharded x{world}, all-gather of move records",
+                "backend": (args.backend if world > 1 else None),
+                "steady_state": (f"untimed oz_selfplay_stagger({stagger_sims}): slot g starts (g*{period})/{G} plies into its first game, those plies "
+                                 f"played by searched self-play at {stagger_sims} sims/move; then {args.warmup} untimed warm-up rounds"
+                                 if stagger_sims >= 2 else "none: all games start at ply 0 together"),
                 "leaf_dedup": ("on: a board reached by several games in the same step is evaluated once (library default)" if args.dedup == "on" else
                                "off: the network evaluates every expansion, nothing is shared or cached between games "
                                "(the library default is on -- see cross_game_dedup for that rate)"),
@@ -250,68 +488,119 @@ def main():
             "games_completed": int(games_all), "expansions": int(exp_all), "simulations": int(sims_all),
             "expansions_per_sim": exp_all / max(sims_all, 1), "node_visits_per_sim": visits_all / max(sims_all, 1),
             "pooled_records": int(pooled.shape[0]),
+            "slot_ply_spread_rank0": [int(ply_now.min()), int(ply_now.max())],
             "nn_forward_ms_total_rank0": nn_ms, "nn_fraction_of_wall_rank0": nn_ms * 1e-3 / dt,
             "leaves_evaluated_rank0": int(d["leaves_evaluated"]),
             "whole_net_tflops_rank0": d["leaves_evaluated"] * flop_exec / max(nn_ms * 1e-3, 1e-9) / 1e12,
             "flop_per_expansion": {"reference_network": flop_ref, "executed": flop_exec,
                                    "note": "executed < reference when conv1 + conv2 are evaluated as pattern-table lookups (exact refactoring, no GEMM)"},
-            "roofline": roofline(args.precision, layer, achieved, conv2_ms, conv2_launches, d["leaves_evaluated"], n, args.channels),
+            "roofline": roofline(args.precision, layer, achieved, dom_ms, dom_launches, d["leaves_evaluated"], n, args.channels),
             # the tree / rules side is latency-bound integer work, ~1.3 KB of algorithmic HBM bytes per simulation
-            "tree_side_hbm": {"bytes_per_sim": 1300, "achieved_GBps": sims_all / dt * 1300 / 1e9, "peak_GBps": 8000.0,
-                              "frac": sims_all / dt * 1300 / 8e12, "note": "not the binding roof; reported per SURVEY 8(d)"},
+            "tree_side_hbm": {"bytes_per_sim": TREE_BYTES_PER_SIM, "bytes_per_sim_source": "SURVEY.md 8(d) algorithmic estimate (not measured in this run)",
+                              "achieved_GBps": sims_all / dt * TREE_BYTES_PER_SIM / 1e9, "peak_GBps": PEAK_HBM_GBPS,
+                              "frac": sims_all / dt * TREE_BYTES_PER_SIM / (PEAK_HBM_GBPS * 1e9), "note": "not the binding roof; reported per SURVEY 8(d)"},
         }
         out["dtype"] = "f32" if args.precision == "f32" else "f32 (2xf16 split)"
         out["dtype_detail"] = ("fp32 operands and accumulators on v_mfma_f32_32x32x2_f32" if args.precision == "f32" else
                                "fp32 values carried as two fp16 planes, 3 fp16 MFMA products per fp32 product, fp32 accumulate; pi, v within 1e-5 of float64")
-        wall = {"setup_s": round(t_setup, 2), "timed_region_s": round(dt, 2)}      # where this process's wall time goes (the driver clocks the whole run)
+        wall = {"setup_s": round(t_setup, 2), "stagger_s": round(t_stagger, 2), "timed_region_s": round(dt, 2)}      # where this process's wall time goes
         out["wall_breakdown"] = wall
-        if world == 1 and args.dedup == "off" and not args.no_dedup_compare:
+        secondary = world == 1 and not args.no_compare
+        cheap_pre = max(2, min(8, args.sims))                   # stagger of the secondary legs: 8 sims/move (a few tenths of a second)
+        if secondary:
+            # ---- every kernel of a step against its own roof: 2 move rounds on the SAME engine with events around every launch
             t_sec = time.perf_counter()
-            # the same K steps with the library default (cross-game de-duplication on): identical records, fewer evaluations
+            rounds = 2
+            eng.profile(True); net.profile(2)
+            eng.profile_read(reset=True); net.profile_kernels(reset=True)
+            a = eng.stats()
+            advance(eng, rounds, True)
+            b = eng.stats()
+            tree_k, net_k = eng.profile_read(), net.profile_kernels()
+            eng.profile(False); net.profile(0)
+            out["kernels"] = kernel_table(net_k, tree_k, rounds, b["leaves_evaluated"] - a["leaves_evaluated"], b["simulations"] - a["simulations"],
+                                          n, args.channels, args.precision, layer == 3)
+            out["kernels_note"] = (f"HIP events around every launch, {rounds} further move rounds of the same engine after the timed region "
+                                   "(events between launches add a few us each: the sum is slightly above ms_per_step)")
+            wall["kernels_s"] = round(time.perf_counter() - t_sec, 2)
+        if secondary and not args.no_cpu_baseline:
+            t_sec = time.perf_counter()
+            ps = parity_sample(net, eng, n, args.channels)
+            out["parity_sample_max_err"] = max(ps["max_abs_err_pi"], ps["max_abs_err_v"])
+            out["parity_sample"] = ps
+            wall["parity_sample_s"] = round(time.perf_counter() - t_sec, 2)
+        del eng
+        if secondary and args.dedup == "off":
+            t_sec = time.perf_counter()
+            # the same workload with the library default (cross-game de-duplication on): identical records, fewer evaluations
             eng2 = make_engine(True)
-            advance(args.warmup, True, eng2)
-            eng2.sync()
-            q0 = eng2.stats()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            advance(args.steps, False, eng2)
-            eng2.sync()
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
-            q1 = eng2.stats()
+            eng2.stagger(cheap_pre)
+            q, dt2 = measure(eng2, args.steps)
             out["cross_game_dedup"] = {
-                "value": (q1["expansions"] - q0["expansions"]) / dt2, "unit": "node-expansions/s", "ms_per_step": dt2 / args.steps * 1e3,
-                "expansions": int(q1["expansions"] - q0["expansions"]), "leaves_evaluated": int(q1["leaves_evaluated"] - q0["leaves_evaluated"]),
-                "note": "same games, same records; concurrent games that reach the same board in a step share one network evaluation "
-                        "(k_compact). Not the headline: `value` above evaluates every expansion"}
+                "value": q["expansions"] / dt2, "unit": "node-expansions/s", "ms_per_step": dt2 / args.steps * 1e3,
+                "games_per_s": q["games_completed"] / dt2, "expansions": int(q["expansions"]), "leaves_evaluated": int(q["leaves_evaluated"]),
+                "note": f"same workload (slots staggered at {cheap_pre} sims/move); concurrent games that reach the same board in a step share one "
+                        "network evaluation (k_compact). Not the headline: `value` above evaluates every expansion"}
+            del eng2
             wall["dedup_compare_s"] = round(time.perf_counter() - t_sec, 2)
-        if world == 1 and layer == 3 and not args.no_dedup_compare:
-            # the same K steps with conv1 / conv2 evaluated the plain way (conv1 kernel + conv2 as an MFMA implicit GEMM,
+        if secondary and layer == 3:
+            # the same steps with conv1 / conv2 evaluated the plain way (conv1 kernel + conv2 as an MFMA implicit GEMM,
             # no pattern tables): what the table form buys, and a number for readers who want every layer as a GEMM
             t_sec = time.perf_counter()
-            net.profile(False)
             net.set_tables(0)
             eng3 = make_engine(args.dedup == "on")
-            advance(args.warmup, True, eng3)
-            eng3.sync()
-            g0 = eng3.stats()
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            advance(args.steps, False, eng3)
-            eng3.sync()
-            torch.cuda.synchronize()
-            dt3 = time.perf_counter() - t2
-            g1 = eng3.stats()
+            eng3.stagger(cheap_pre)
+            g3, dt3 = measure(eng3, max(args.steps // 2, 1))
             net.set_tables(-1)
             out["all_layers_as_gemm"] = {
-                "value": (g1["expansions"] - g0["expansions"]) / dt3, "unit": "node-expansions/s", "ms_per_step": dt3 / args.steps * 1e3,
-                "flop_per_expansion_executed": flop_ref,
-                "note": "same games, conv1 as a kernel and conv2 as an MFMA implicit GEMM (oz_net_set_tables(net, 0)); "
+                "value": g3["expansions"] / dt3, "unit": "node-expansions/s", "ms_per_step": dt3 / max(args.steps // 2, 1) * 1e3,
+                "games_per_s": g3["games_completed"] / dt3, "flop_per_expansion_executed": flop_ref,
+                "note": "same workload, conv1 as a kernel and conv2 as an MFMA implicit GEMM (oz_net_set_tables(net, 0)); "
                         "(pi, v) agree with the table form to 5e-7"}
+            del eng3
             wall["gemm_compare_s"] = round(time.perf_counter() - t_sec, 2)
+        if secondary and args.precision == "f16x2":
+            # ---- exact fp32 arithmetic (what the reference computes in: Net/NNet.py:85), same workload, same run
+            t_sec = time.perf_counter()
+            steps32 = max(args.steps // 4, 2)
+            net32 = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0, precision="f32")
+            e32 = make_engine(args.dedup == "on", the_net=net32)
+            e32.stagger(cheap_pre)
+            q32, dt32 = measure(e32, steps32, net32)
+            ms32, l32 = net32.profile_read()
+            layer32 = net32.profiled_layer()
+            ach32 = q32["leaves_evaluated"] * conv_flop_per_leaf(layer32, n, args.channels) / max(ms32 * 1e-3, 1e-9) / 1e12
+            out["exact_fp32"] = {
+                "value": q32["expansions"] / dt32, "unit": "node-expansions/s", "ms_per_step": dt32 / steps32 * 1e3, "steps": steps32,
+                "games_per_s": q32["games_completed"] / dt32, "sims_per_s": q32["simulations"] / dt32, "dtype": "f32",
+                "dtype_detail": "fp32 operands and accumulators on v_mfma_f32_32x32x2_f32 (conv1 + conv2 from exact-fp32 pattern tables)",
+                "roofline": roofline("f32", layer32, ach32, ms32, l32, q32["leaves_evaluated"], n, args.channels),
+                "note": f"same workload and run as the headline (slots staggered at {cheap_pre} sims/move), precision='f32'"}
+            del e32, net32
+            wall["exact_fp32_s"] = round(time.perf_counter() - t_sec, 2)
+        if secondary and n == 8:
+            # ---- BASELINE configs[3]: 6x6 boards, same network family, same engine
+            t_sec = time.perf_counter()
+            net6 = NNetWrapper((6, 6), num_channels_1=args.channels, max_batch=G, seed=0, precision=args.precision)
+            e6 = make_engine(args.dedup == "on", the_net=net6, board=6)
+            e6.stagger(cheap_pre)
+            q6, dt6 = measure(e6, args.steps)
+            out["config4"] = {
+                "workload": f"{G} concurrent 6x6 self-play games, {args.sims} sims/move (BASELINE configs[3])",
+                "value": q6["expansions"] / dt6, "unit": "node-expansions/s", "ms_per_step": dt6 / args.steps * 1e3,
+                "games_per_s": q6["games_completed"] / dt6, "sims_per_s": q6["simulations"] / dt6,
+                "flop_per_expansion_reference": FLOP_PER_EXPANSION[6]}
+            del e6, net6
+            wall["config4_s"] = round(time.perf_counter() - t_sec, 2)
+        if secondary and n == 8 and not args.no_cpu_baseline:
+            t_sec = time.perf_counter()
+            out["dropin_config0"] = dropin_config0(args.channels, args.precision)
+            wall["dropin_config0_s"] = round(time.perf_counter() - t_sec, 2)
         if world == 1 and not args.no_cpu_baseline:
             t_sec = time.perf_counter()
             out["cpu_baseline"] = cpu_baseline(n, args.channels, args.sims)
+            if secondary and n == 8:
+                out["config4"]["cpu_baseline"] = cpu_baseline_config(6, args.channels, args.sims, 5.0)
             wall["cpu_baseline_s"] = round(time.perf_counter() - t_sec, 2)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -4,7 +4,7 @@
  * Drop-in boundary for the self-play hot path of Galtvam/OthelloZero.  The
  * reference has no FFI layer (its boundary is Python duck typing), so each entry
  * point below cites the reference interface it replaces (file:line under the
- * reference tree); othellozero_amd/*.py binds them with ctypes and re-creates
+ * reference tree); the othellozero_amd Python package binds them with ctypes and re-creates
  * the reference's Python surfaces on top.
  *
  * Conventions: plain pointers and sizes, caller-owned output buffers, int status
@@ -90,8 +90,12 @@ int oz_net_predict(oz_net* net, const uint64_t* own, const uint64_t* opp, int co
 int oz_net_time_forward(oz_net* net, int count, int iters, float* ms_avg);
 /* HIP-event timing of the dominant launch on the stream it is launched on: the conv3 implicit GEMM when conv1 + conv2
  * run as a table gather-sum (the default), else the conv2 implicit GEMM; oz_net_profiled_layer says which (3 / 2) */
-int oz_net_profile(oz_net* net, int enable);
+int oz_net_profile(oz_net* net, int enable /* 0 off, 1 the dominant launch only, 2 every kernel of the forward */);
 int oz_net_profile_read(oz_net* net, double* conv2_ms_total, int64_t* conv2_launches);
+/* per-kernel totals since creation (or the last reset), slots: 0 input (k_lut_ids, or the conv1 kernel) 1 conv2 (table
+ * gather-sum or GEMM) 2 conv3 3 conv4 4 fc1 (+ split-K reduce) 5 fc2 6 heads; only slots enabled by the profile mode advance */
+#define OZ_NET_KERNELS 7
+int oz_net_profile_kernels(oz_net* net, double* ms_total /* [OZ_NET_KERNELS] */, int64_t* launches /* [OZ_NET_KERNELS] */, int reset);
 int oz_net_profiled_layer(oz_net* net, int* layer);
 /* how conv1 / conv2 are evaluated.  2 (default): both from tables over the 3^9 neighbourhood patterns of the discrete
  * input planes (no GEMM for conv2; tables rebuilt by oz_net_commit); 1 (precision f16x2, max_batch > 32): conv1 from its table
@@ -179,6 +183,16 @@ int oz_selfplay_run(oz_selfplay* sp, int rounds);
  * games, every game's simulations / moves / records are exactly those of oz_selfplay_run (training.py:39-67). */
 int oz_selfplay_run_steps(oz_selfplay* sp, int steps);
 int oz_selfplay_sync(oz_selfplay* sp);
+/* continuous self-play (cfg.refill): bring a fresh engine to the steady state of a long-running one before measuring it --
+ * slot g is advanced (g * P) / num_games plies into its first game, P = n*n - 4, by searched self-play moves at `sims_pre`
+ * simulations each (same kernels, same RNG streams, recorded like any move), so that every later move round completes
+ * about num_games / P games instead of none for P - 1 rounds and all of them in one.  First driver call only; asynchronous. */
+int oz_selfplay_stagger(oz_selfplay* sp, int sims_pre);
+/* HIP-event timing of the tree kernels on the launch stream: slots 0 select 1 leaf compaction 2 evaluator (all network
+ * launches) 3 expand + backup 4 roots + move; slot 2 is always timed (oz_selfplay_eval_time), the others while enabled */
+#define OZ_TREE_KERNELS 5
+int oz_selfplay_profile(oz_selfplay* sp, int enable);
+int oz_selfplay_profile_read(oz_selfplay* sp, double* ms_total /* [OZ_TREE_KERNELS] */, int64_t* launches /* [OZ_TREE_KERNELS] */, int reset);
 int oz_selfplay_get_stats(oz_selfplay* sp, oz_selfplay_stats* out);
 /* per-slot view: boards, player to move, finished flag, plies played, global game id */
 int oz_selfplay_state(oz_selfplay* sp, uint64_t* black, uint64_t* white, int8_t* player, uint8_t* finished,

@@ -40,11 +40,26 @@ def _conv3x3(x, k, bias, same):
         Ho, Wo = H, W
     else:
         Ho, Wo = H - 2, W - 2
-    out = np.zeros((B, Ho, Wo, k.shape[3]), dtype=x.dtype)
+    out = np.zeros((B * Ho * Wo, k.shape[3]), dtype=x.dtype)
     for ky in range(3):
         for kx in range(3):
-            out += x[:, ky:ky + Ho, kx:kx + Wo, :] @ k[ky, kx]
-    return out + bias
+            # one (pixels x Cin) @ (Cin x Cout) product per tap on a contiguous copy of the shifted window (so that NumPy
+            # hands it to BLAS: the strided 4-D form of the same product runs ~20x slower), taps summed in (ky, kx) order
+            win = np.ascontiguousarray(x[:, ky:ky + Ho, kx:kx + Wo, :]).reshape(B * Ho * Wo, -1)
+            out += win @ k[ky, kx]
+    return out.reshape(B, Ho, Wo, -1) + bias
+
+
+def forward_chunked(weights, own, opp, n, chunk=512, dtype=np.float64):
+    """forward() over a large batch in slices of `chunk` positions (bounded memory: one slice's activations at a time)"""
+    own = np.asarray(own, dtype=np.uint64).ravel()
+    opp = np.asarray(opp, dtype=np.uint64).ravel()
+    w = [np.asarray(a, dtype=dtype) for a in weights]
+    pis, vs = [], []
+    for s in range(0, own.size, chunk):
+        pi, v = forward(w, own[s:s + chunk], opp[s:s + chunk], n, dtype)
+        pis.append(pi); vs.append(v)
+    return np.concatenate(pis), np.concatenate(vs)
 
 
 def forward(weights, own, opp, n, dtype=np.float64, return_activations=False):

@@ -85,6 +85,7 @@ def lib():
     L.orc_mcts_counts.restype = i32; L.orc_mcts_counts.argtypes = [vp, u64, u64, P(i32), P(u64)]
     L.orc_mcts_policy.restype = i32; L.orc_mcts_policy.argtypes = [vp, u64, u64, dbl, u64, P(dbl), P(i32)]
     L.orc_episode.restype = i32; L.orc_episode.argtypes = [vp, i32, dbl, dbl, u64, u64, i32, P(EpisodeOut)]
+    L.orc_episode_sched.restype = i32; L.orc_episode_sched.argtypes = [vp, i32, i32, i32, dbl, dbl, u64, u64, i32, P(EpisodeOut)]
     L.orc_arena.restype = i32; L.orc_arena.argtypes = [vp, vp, i32, u64, u64, P(ArenaOut)]
     L.orc_symmetry_perms.restype = None; L.orc_symmetry_perms.argtypes = [i32, P(C.c_int32)]
     L.orc_nn_num_weights.restype = i32
@@ -216,9 +217,12 @@ class Mcts:
             raise KeyError("node never selected from")
         return out.reshape(self.n, self.n), arg.value
 
-    def episode(self, sims, T, e_greedy, seed, game_id, max_moves=-1):
+    def episode(self, sims, T, e_greedy, seed, game_id, max_moves=-1, sims_pre=None, pre_plies=0):
+        """execute_episode (training.py:26-72); sims_pre / pre_plies: num_simulations on the first pre_plies plies
+        (a slot of the build's engine after oz_selfplay_stagger)"""
         out = EpisodeOut()
-        rc = self.L.orc_episode(self.h, sims, float(T), float(e_greedy), seed, game_id, max_moves, C.byref(out))
+        rc = self.L.orc_episode_sched(self.h, sims, sims if sims_pre is None else sims_pre, pre_plies, float(T), float(e_greedy),
+                                      seed, game_id, max_moves, C.byref(out))
         if rc < 0:
             raise KeyError("orc_episode: KeyError path (num_simulations too small)")
         k = out.n_moves

@@ -531,8 +531,16 @@ typedef struct {
 
 /* execute_episode, training.py:26-72.  RNG draws come from orc_rng streams
  * keyed (seed, game_id, ply, purpose) instead of random/np.random. */
+/* orc_episode_sched: the same loop with num_simulations = sims_pre on the plies < pre_plies and `sims` afterwards (what a
+ * slot of the build's engine plays after oz_selfplay_stagger); orc_episode = pre_plies 0, the reference's own loop. */
+ORC_API int orc_episode_sched(omcts* m, int sims, int sims_pre, int pre_plies, double T, double e_greedy, uint64_t seed,
+                              uint64_t game_id, int max_moves, orc_episode_out* out);
 ORC_API int orc_episode(omcts* m, int sims, double T, double e_greedy, uint64_t seed, uint64_t game_id,
                         int max_moves, orc_episode_out* out) {
+    return orc_episode_sched(m, sims, sims, 0, T, e_greedy, seed, game_id, max_moves, out);
+}
+ORC_API int orc_episode_sched(omcts* m, int sims, int sims_pre, int pre_plies, double T, double e_greedy, uint64_t seed,
+                              uint64_t game_id, int max_moves, orc_episode_out* out) {
     const int n = m->n;
     ogame g; game_init(&g, n);
     memset(out, 0, sizeof *out);
@@ -540,7 +548,8 @@ ORC_API int orc_episode(omcts* m, int sims, double T, double e_greedy, uint64_t 
     while (!g.finished) {
         if (max_moves >= 0 && ply >= max_moves) break;
         uint64_t bl, wh; pack(&g.b, &bl, &wh);
-        for (int s = 0; s < sims; ++s) orc_mcts_simulate(m, bl, wh, g.player, NULL);
+        const int nsims = ply < pre_plies ? sims_pre : sims;
+        for (int s = 0; s < nsims; ++s) orc_mcts_simulate(m, bl, wh, g.player, NULL);
         uint64_t k0 = g.player == 1 ? bl : wh, k1 = g.player == 1 ? wh : bl;
         int counts[64]; uint64_t legal;
         int rc = orc_mcts_counts(m, k0, k1, counts, &legal);

@@ -3,8 +3,8 @@
 Same constructor arguments, `.network_type`, `.predict(board) -> (pi (n,n) float32, v float32)`,
 `.copy()`, `.save_checkpoint(path)`, `.load_checkpoint(path)`.  Added: `.predict_batch`,
 `.get_weights()/.set_weights()` (keras Model.get_weights() order), `StubNetWrapper`.
-Checkpoints are Keras HDF5 weight files (keras_h5.py).  Training (`.train`, Net/NNet.py:53-68) is out of this
-round's scope and raises NotImplementedError instead of silently doing something else.
+Checkpoints are Keras HDF5 weight files (keras_h5.py).  `.train` (Net/NNet.py:53-68) runs the optimiser steps on the GPU
+(oz_trainer_*, trainer.py).
 """
 import ctypes as C
 from enum import Enum, auto
@@ -180,7 +180,15 @@ class NNetWrapper(_NetHandle):
         return ms.value
 
     def profile(self, enable=True):
-        _lib.check(_lib.load().oz_net_profile(self._h, 1 if enable else 0))
+        """HIP-event timing on the launch stream: True / 1 = the dominant launch only, 2 = every kernel of the forward, False / 0 = off"""
+        _lib.check(_lib.load().oz_net_profile(self._h, int(enable)))
+
+    def profile_kernels(self, reset=False):
+        """{kernel: (ms_total, launches)} for _lib.NET_KERNELS (slots the profile mode did not time stay at their last value)"""
+        k = len(_lib.NET_KERNELS)
+        ms, cnt = np.zeros(k, np.float64), np.zeros(k, np.int64)
+        _lib.check(_lib.load().oz_net_profile_kernels(self._h, _lib.p_f64(ms), _lib.p_i64(cnt), 1 if reset else 0))
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.NET_KERNELS)}
 
     def profile_read(self):
         ms, cnt = C.c_double(), C.c_int64()

@@ -16,6 +16,8 @@ OZ_OK, OZ_ERR_HIP, OZ_ERR_ARG, OZ_ERR_CAPACITY, OZ_ERR_KEY, OZ_ERR_STATE = range
 QMODE_NEP50, QMODE_F64 = 0, 1
 LEAF_IDLE, LEAF_TERMINAL, LEAF_EVAL = 0, 1, 2
 VT_INT, VT_F32, VT_F64 = 0, 1, 2
+NET_KERNELS = ("input", "conv2", "conv3", "conv4", "fc1", "fc2", "heads")           # OZ_NET_KERNELS slots
+TREE_KERNELS = ("select", "compact", "network", "expand_backup", "roots_move")       # OZ_TREE_KERNELS slots
 
 
 class OzLibraryError(RuntimeError):
@@ -77,6 +79,7 @@ SIGNATURES = {
     "oz_net_time_forward": [_vp, C.c_int, C.c_int, _f32p],
     "oz_net_profile": [_vp, C.c_int], "oz_net_profile_read": [_vp, _f64p, _i64p],
     "oz_net_profiled_layer": [_vp, C.POINTER(C.c_int)], "oz_net_set_tables": [_vp, C.c_int],
+    "oz_net_profile_kernels": [_vp, _f64p, _i64p, C.c_int],
     "oz_mcts_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int],
     "oz_mcts_destroy": [_vp], "oz_mcts_reset": [_vp, C.c_int],
     "oz_mcts_set_roots": [_vp, _u64p, _u64p, _u8p],
@@ -90,6 +93,8 @@ SIGNATURES = {
     "oz_mcts_stats": [_vp, _i64p],
     "oz_selfplay_create": [C.POINTER(_vp), C.POINTER(SelfplayConfig), _vp],
     "oz_selfplay_destroy": [_vp], "oz_selfplay_run": [_vp, C.c_int], "oz_selfplay_run_steps": [_vp, C.c_int], "oz_selfplay_sync": [_vp],
+    "oz_selfplay_stagger": [_vp, C.c_int], "oz_selfplay_profile": [_vp, C.c_int],
+    "oz_selfplay_profile_read": [_vp, _f64p, _i64p, C.c_int],
     "oz_selfplay_get_stats": [_vp, C.POINTER(SelfplayStats)],
     "oz_selfplay_state": [_vp, _u64p, _u64p, _i8p, _u8p, _i32p, _u64p],
     "oz_selfplay_records": [_vp, _vp, C.c_int64, _i64p],

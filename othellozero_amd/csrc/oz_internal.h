@@ -10,6 +10,57 @@
 
 int oz_current_device();
 
+// HIP-event stopwatch with named slots, for timing launches on the stream they are launched on without a host sync:
+// begin / end record a pooled event pair around a launch sequence, collect() folds finished pairs into per-slot totals
+// and returns the events to the pool (no event is created or destroyed per launch once the pool is warm; a pair whose
+// end() never came -- an error return between the two -- is recycled by cancel()).
+struct OzTimer {
+    struct Pend { hipEvent_t a, b; int slot; bool ended; };
+    std::vector<hipEvent_t> pool;
+    std::vector<Pend> pending;
+    std::vector<double> ms;
+    std::vector<long long> count;
+    explicit OzTimer(int slots = 1) : ms(slots, 0.0), count(slots, 0) {}
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    // returns the index to hand to end() / cancel(), or -1 (events unavailable: the launch simply goes untimed)
+    int begin(int slot, hipStream_t s) {
+        hipEvent_t a = get(), b = get();
+        if (!a || !b) { if (a) pool.push_back(a); if (b) pool.push_back(b); return -1; }
+        if (hipEventRecord(a, s) != hipSuccess) { pool.push_back(a); pool.push_back(b); return -1; }
+        pending.push_back({a, b, slot, false});
+        return (int)pending.size() - 1;
+    }
+    void end(int idx, hipStream_t s) {
+        if (idx < 0) return;
+        pending[idx].ended = hipEventRecord(pending[idx].b, s) == hipSuccess;
+    }
+    void cancel(int idx) { if (idx >= 0) pending[idx].ended = false; }
+    size_t backlog() const { return pending.size(); }
+    int collect() {
+        int rc = OZ_OK;
+        for (auto& p : pending) {
+            float t = 0;
+            if (p.ended && hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
+                ms[p.slot] += t; count[p.slot] += 1;
+            } else if (p.ended) rc = OZ_ERR_HIP;
+            pool.push_back(p.a); pool.push_back(p.b);
+        }
+        pending.clear();
+        return rc;
+    }
+    void reset() { for (auto& x : ms) x = 0; for (auto& x : count) x = 0; }
+    void destroy() {
+        for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+        for (auto e : pool) hipEventDestroy(e);
+        pending.clear(); pool.clear();
+    }
+};
+
 // Leaf evaluator: NNetWrapper.predict (Net/NNet.py:70-87) over a device-resident batch.
 // d_count lives on the device (filled by the compaction kernel); kernels are launched for
 // max_count leaves and exit early beyond *d_count, so no host round trip per step.

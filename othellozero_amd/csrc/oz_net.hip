@@ -376,10 +376,10 @@ struct OnnNet : oz_net {
     bool t2_ok = false;
     bool h2_attr_set = false;
     std::vector<void*> allocs;
-    // profiling of the dominant launch (conv2)
-    bool profile = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    double conv2_ms = 0; long long conv2_launches = 0;
+    // HIP-event timing on the launch stream (oz_net_profile): mode 1 = the dominant launch only (bench.py's timed region),
+    // mode 2 = every kernel of the forward (slot order: OZ_NET_KERNELS in the header)
+    int profile = 0;
+    OzTimer timer{OZ_NET_KERNELS};
     int tables_mode = -1;            // oz_net_set_tables: -1 = environment default, 0 / 1 / 2 see forward_h2
     int profiled_layer = 2;          // 2 = conv2 GEMM, 3 = conv3 GEMM (when conv2 runs as the table gather-sum)
 
@@ -399,7 +399,7 @@ struct OnnNet : oz_net {
     }
     ~OnnNet() override {
         hipSetDevice(device);
-        for (auto& pr : pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+        timer.destroy();
         for (void* p : allocs) hipFree(p);
     }
 
@@ -562,6 +562,16 @@ struct OnnNet : oz_net {
         const bool want_t2 = tables_mode < 0 ? (lut_env && t2_env) : tables_mode >= 2;
         const bool use_t2 = want_t2 && t2_ok;
         const bool use_lut = !use_t2 && pp && want_lut && lut_ok && max_batch > 32;
+        // HIP events around the dominant launch (the conv2 GEMM, or conv3 when conv2 is the gather-sum), or around every kernel
+        profiled_layer = use_t2 ? 3 : 2;
+        if (profile && timer.backlog() > 8192) { if (int rc = collect_profile()) return rc; }
+        int tidx = -1;
+        auto mark = [&](int slot, bool begin) {
+            if (!(profile == 2 || (profile == 1 && slot == profiled_layer - 1))) return;
+            if (begin) tidx = timer.begin(slot, s);
+            else { timer.end(tidx, s); tidx = -1; }
+        };
+        mark(0, true);
         if (use_t2 || use_lut) {
             const long long threads = (long long)max_count * n * n;
             hipLaunchKernelGGL(k_lut_ids, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, d_lut_ids);
@@ -570,17 +580,7 @@ struct OnnNet : oz_net {
             hipLaunchKernelGGL(k_conv1_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, C,
                                d_w1, d_scale[0], d_shift[0], (uint4*)act1, d_flag);
         }
-        // HIP events around the dominant launch: the conv2 GEMM, or conv3 when conv2 is the gather-sum
-        profiled_layer = use_t2 ? 3 : 2;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (profile && pending.size() > 4096) { if (int rc = collect_profile()) return rc; }
-        if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); }
-        auto mark = [&](int layer, bool begin) -> int {
-            if (!profile || layer != profiled_layer) return OZ_OK;
-            OZ_HIP(hipEventRecord(begin ? e0 : e1, s));
-            if (!begin) pending.push_back({e0, e1});
-            return OZ_OK;
-        };
+        mark(0, false);
         const bool small = max_batch <= 32;
         // small networks (the drop-in OthelloMCTS / agents path, one position per call): latency, not throughput --
         // 128 x 128 tiles with the k loop split 16 ways over otherwise idle CUs, fixed-order reduce (keyed on max_batch,
@@ -588,7 +588,7 @@ struct OnnNet : oz_net {
         // medium networks (arenas, evaluation batches, the loop's 100 episodes): a convolution whose grid would leave most
         // CUs idle splits its k loop (conv_ksplit: from max_batch, a per-network constant; 1 at the bench's 4096 games)
         const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), 192), k4 = conv_ksplit((n - 4) * (n - 4), 256);
-        if (int rc = mark(2, true)) return rc;
+        mark(1, true);
         if (use_t2) {
             const long long threads = (long long)max_count * n * n * (C / 8);
             hipLaunchKernelGGL(k_conv2_lut, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_lut_ids, d_count, n, C, d_t2,
@@ -597,8 +597,8 @@ struct OnnNet : oz_net {
                             : use_lut ? launch_gemm_h2<H2BigPPLut>(d_lut, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2, d_lut_ids)
                             : pp      ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)
                                       : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)) return rc;
-        if (int rc = mark(2, false)) return rc;
-        if (int rc = mark(3, true)) return rc;
+        mark(1, false);
+        mark(2, true);
         // 3-phase loop on the 192-row tile (24-MFMA clusters): bit-identical, measured 0 .. +2 % on conv3 -- the layer is clock / power
         // bound, not load-section bound -- so the 4-phase loop stays the default; OZ_H2_PP3=1 selects it
         static const bool pp3 = getenv("OZ_H2_PP3") && atoi(getenv("OZ_H2_PP3")) != 0;
@@ -606,10 +606,13 @@ struct OnnNet : oz_net {
                      : pp && pp3 ? launch_gemm_h2<H2MidPP3>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                      : pp  ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                            : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
-        if (int rc = mark(3, false)) return rc;
+        mark(2, false);
+        mark(3, true);
         if (int rc = small ? launch_small<H2Small, H2Small2>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, 16)
                      : pp  ? launch_gemm_h2<H2BigPP>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
                            : launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)) return rc;
+        mark(3, false);
+        mark(4, true);
         // fc1: K = 8192 but only batch x 1024 outputs -> split-K (fixed-order reduce) to fill the chip
         // (large batches: on the 256 x 256 ping-pong tile, 16 x 4 tiles x 4 k-slices = one block per CU; bit-identical to
         //  the 128 x 128 tile because the k-slices and the order inside them are the same -- tools/pp_race_check.py)
@@ -617,9 +620,14 @@ struct OnnNet : oz_net {
         if (int rc = small ? launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)
                      : (fc1pp && pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
                                                           : launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
+        mark(4, false);
+        mark(5, true);
         // fc2: one position has 4 blocks of 32 k-tiles -> small networks split k 8 ways too, medium ones 4 ways (from max_batch)
         if (int rc = launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, small ? 8 : max_batch <= 512 ? 4 : 1)) return rc;
+        mark(5, false);
+        mark(6, true);
         hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        mark(6, false);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
     }
@@ -634,41 +642,52 @@ struct OnnNet : oz_net {
         static const bool t2f_env = !(getenv("OZ_H2_T2") && atoi(getenv("OZ_H2_T2")) == 0) && !(getenv("OZ_H2_LUT") && atoi(getenv("OZ_H2_LUT")) == 0);
         const bool use_t2f = (tables_mode < 0 ? t2f_env : tables_mode >= 2) && t2f_ok;
         profiled_layer = use_t2f ? 3 : 2;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (profile && pending.size() > 4096) { if (int rc = collect_profile()) return rc; }
-        if (profile) { OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1)); }
+        if (profile && timer.backlog() > 8192) { if (int rc = collect_profile()) return rc; }
+        int tidx = -1;
+        auto mark = [&](int slot, bool begin) {
+            if (!(profile == 2 || (profile == 1 && slot == profiled_layer - 1))) return;
+            if (begin) tidx = timer.begin(slot, s);
+            else { timer.end(tidx, s); tidx = -1; }
+        };
         if (use_t2f) {
             const long long pixels = (long long)max_count * P, threads = pixels * (C / 8);
+            mark(0, true);
             hipLaunchKernelGGL(k_lut_ids, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, d_lut_ids);
+            mark(0, false);
+            mark(1, true);
             hipLaunchKernelGGL(k_conv2_lut_f32, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_lut_ids, d_count, n, C, d_t2,
                                d_scale[1], d_shift[1], act2);
-            if (profile) OZ_HIP(hipEventRecord(e0, s));
+            mark(1, false);
         } else {
             const long long threads = (long long)max_count * P * (C / 4);
+            mark(0, true);
             hipLaunchKernelGGL(k_conv1, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, C,
                                d_w1, d_scale[0], d_shift[0], act1);
-            if (profile) OZ_HIP(hipEventRecord(e0, s));
+            mark(0, false);
+            mark(1, true);
             if (int rc = launch_gemm(act1, d_wt[0], 1, act2, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
-            if (profile) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
+            mark(1, false);
         }
+        mark(2, true);
         if (int rc = launch_gemm(act2, d_wt[1], 2, act3, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
-        if (profile && use_t2f) { OZ_HIP(hipEventRecord(e1, s)); pending.push_back({e0, e1}); }
+        mark(2, false);
+        mark(3, true);
         if (int rc = launch_gemm(act3, d_wt[2], 3, act4, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
+        mark(3, false);
+        mark(4, true);
         if (int rc = launch_gemm(act4, d_wt[3], 4, f1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
+        mark(4, false);
+        mark(5, true);
         if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
+        mark(5, false);
+        mark(6, true);
         hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        mark(6, false);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
     }
     int collect_profile() {
-        for (auto& pr : pending) {
-            float ms = 0;
-            OZ_HIP(hipEventSynchronize(pr.second));
-            OZ_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
-            conv2_ms += ms; conv2_launches += 1;
-            hipEventDestroy(pr.first); hipEventDestroy(pr.second);
-        }
-        pending.clear();
+        if (timer.collect() != OZ_OK) { oz_set_error("HIP event timing failed"); return OZ_ERR_HIP; }
         return OZ_OK;
     }
 };
@@ -975,8 +994,9 @@ OZ_API int oz_net_check(oz_net* net) {
 OZ_API int oz_net_profile(oz_net* net, int enable) {
     OnnNet* o = as_onn(net);
     OZ_REQUIRE(o, "not an OthelloNN network");
+    OZ_REQUIRE(enable >= 0 && enable <= 2, "profile mode must be 0 (off), 1 (dominant launch) or 2 (every kernel)");
     std::lock_guard<std::mutex> lk(o->mu);
-    o->profile = enable != 0;
+    o->profile = enable;
     return OZ_OK;
 }
 #ifdef H2PP_STAMPS
@@ -1011,7 +1031,22 @@ OZ_API int oz_net_profile_read(oz_net* net, double* conv2_ms_total, int64_t* con
     std::lock_guard<std::mutex> lk(o->mu);
     hipSetDevice(o->device);
     if (int rc = o->collect_profile()) return rc;
-    if (conv2_ms_total) *conv2_ms_total = o->conv2_ms;
-    if (conv2_launches) *conv2_launches = o->conv2_launches;
+    const int slot = o->profiled_layer - 1;
+    if (conv2_ms_total) *conv2_ms_total = o->timer.ms[slot];
+    if (conv2_launches) *conv2_launches = o->timer.count[slot];
+    return OZ_OK;
+}
+
+OZ_API int oz_net_profile_kernels(oz_net* net, double* ms_total, int64_t* launches, int reset) {
+    OnnNet* o = as_onn(net);
+    OZ_REQUIRE(o, "not an OthelloNN network");
+    std::lock_guard<std::mutex> lk(o->mu);
+    hipSetDevice(o->device);
+    if (int rc = o->collect_profile()) return rc;
+    for (int i = 0; i < OZ_NET_KERNELS; ++i) {
+        if (ms_total) ms_total[i] = o->timer.ms[i];
+        if (launches) launches[i] = o->timer.count[i];
+    }
+    if (reset) o->timer.reset();
     return OZ_OK;
 }

@@ -28,14 +28,14 @@ OZ_API int oz_set_device(int device) {
     g_device = device;
     return OZ_OK;
 }
+// The device a new object is created on / a batch call runs on: the one oz_set_device chose for this thread, else whatever
+// the HIP runtime's current device is RIGHT NOW (e.g. torch.cuda.set_device(local_rank) in a one-process-per-GPU job) --
+// never a value cached from an earlier call, and never overriding a device the caller selected.
 int oz_current_device() {
-    if (g_device < 0) {
-        int d = 0;
-        if (hipGetDevice(&d) != hipSuccess) d = 0;
-        g_device = d;
-    }
-    hipSetDevice(g_device);
-    return g_device;
+    if (g_device >= 0) { hipSetDevice(g_device); return g_device; }
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return d;
 }
 
 // small RAII device buffer for the batch entry points
@@ -44,6 +44,29 @@ template <typename T> struct DevBuf {
     hipError_t alloc(size_t count) { return hipMalloc((void**)&p, sizeof(T) * (count ? count : 1)); }
     ~DevBuf() { if (p) hipFree(p); }
 };
+
+// Persistent staging of the oz_rules_* entry points (one per device, process lifetime): the drop-in OthelloGame asks about
+// ONE position per call, so a call must not pay hipMalloc / hipFree (device-wide syncs) nor one blocking copy per array.
+// A call packs its inputs into the pinned host image, does ONE upload, the kernel, ONE download on a private stream.
+struct RulesStage {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    unsigned char *dev = nullptr, *host = nullptr;       // host = pinned (hipHostMalloc)
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (!stream) OZ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (bytes <= cap) return OZ_OK;
+        size_t want = cap ? cap : 4096;
+        while (want < bytes) want *= 2;
+        if (dev) { hipFree(dev); hipHostFree(host); dev = host = nullptr; cap = 0; }
+        OZ_HIP(hipMalloc((void**)&dev, want));
+        OZ_HIP(hipHostMalloc((void**)&host, want, hipHostMallocDefault));
+        cap = want;
+        return OZ_OK;
+    }
+};
+static RulesStage g_stage[16];
+static inline size_t pad8(size_t x) { return (x + 7) & ~(size_t)7; }
 
 // ---------------------------------------------------------------- rule kernels
 __global__ void k_legal(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp, int count, uint64_t valid,
@@ -87,18 +110,36 @@ static int check_n(int n) {
     return OZ_OK;
 }
 
+// run `launch(dev_in, dev_out, stream)` between one upload of in_bytes and one download of out_bytes
+template <typename Pack, typename Launch, typename Unpack>
+static int rules_call(size_t in_bytes, size_t out_bytes, Pack pack, Launch launch, Unpack unpack) {
+    const int dev = oz_current_device();
+    OZ_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+    RulesStage& st = g_stage[dev];
+    std::lock_guard<std::mutex> lk(st.mu);
+    const size_t in_p = pad8(in_bytes);
+    if (int rc = st.reserve(in_p + pad8(out_bytes))) return rc;
+    pack(st.host);
+    OZ_HIP(hipMemcpyAsync(st.dev, st.host, in_bytes, hipMemcpyHostToDevice, st.stream));
+    launch(st.dev, st.dev + in_p, st.stream);
+    OZ_HIP(hipGetLastError());
+    OZ_HIP(hipMemcpyAsync(st.host + in_p, st.dev + in_p, out_bytes, hipMemcpyDeviceToHost, st.stream));
+    OZ_HIP(hipStreamSynchronize(st.stream));
+    unpack(st.host + in_p);
+    return OZ_OK;
+}
+
 OZ_API int oz_rules_legal_moves(const uint64_t* own, const uint64_t* opp, int n, int count, uint64_t* legal) {
     if (int rc = check_n(n)) return rc;
     if (count <= 0) return OZ_OK;
-    oz_current_device();
-    DevBuf<uint64_t> a, b, l;
-    OZ_HIP(a.alloc(count)); OZ_HIP(b.alloc(count)); OZ_HIP(l.alloc(count));
-    OZ_HIP(hipMemcpy(a.p, own, 8ull * count, hipMemcpyHostToDevice));
-    OZ_HIP(hipMemcpy(b.p, opp, 8ull * count, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_legal, dim3(grid_for(count)), dim3(256), 0, 0, a.p, b.p, count, oz_valid_mask(n), l.p);
-    OZ_HIP(hipGetLastError());
-    OZ_HIP(hipMemcpy(legal, l.p, 8ull * count, hipMemcpyDeviceToHost));
-    return OZ_OK;
+    const size_t c8 = 8ull * count;
+    return rules_call(2 * c8, c8,
+        [&](unsigned char* h) { memcpy(h, own, c8); memcpy(h + c8, opp, c8); },
+        [&](unsigned char* di, unsigned char* dout, hipStream_t s) {
+            hipLaunchKernelGGL(k_legal, dim3(grid_for(count)), dim3(256), 0, s, (const uint64_t*)di, (const uint64_t*)(di + c8), count,
+                               oz_valid_mask(n), (uint64_t*)dout);
+        },
+        [&](const unsigned char* h) { memcpy(legal, h, c8); });
 }
 
 OZ_API int oz_rules_apply_moves(const uint64_t* own, const uint64_t* opp, const uint8_t* sq, int n, int count,
@@ -106,35 +147,33 @@ OZ_API int oz_rules_apply_moves(const uint64_t* own, const uint64_t* opp, const 
     if (int rc = check_n(n)) return rc;
     if (count <= 0) return OZ_OK;
     for (int i = 0; i < count; ++i) OZ_REQUIRE((sq[i] >> 3) < n && (sq[i] & 7) < n, "square %d outside the %dx%d board", sq[i], n, n);
-    oz_current_device();
-    DevBuf<uint64_t> a, b, ao, bo; DevBuf<uint8_t> s;
-    OZ_HIP(a.alloc(count)); OZ_HIP(b.alloc(count)); OZ_HIP(ao.alloc(count)); OZ_HIP(bo.alloc(count)); OZ_HIP(s.alloc(count));
-    OZ_HIP(hipMemcpy(a.p, own, 8ull * count, hipMemcpyHostToDevice));
-    OZ_HIP(hipMemcpy(b.p, opp, 8ull * count, hipMemcpyHostToDevice));
-    OZ_HIP(hipMemcpy(s.p, sq, count, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_apply, dim3(grid_for(count)), dim3(256), 0, 0, a.p, b.p, s.p, count, ao.p, bo.p);
-    OZ_HIP(hipGetLastError());
-    OZ_HIP(hipMemcpy(own_out, ao.p, 8ull * count, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(opp_out, bo.p, 8ull * count, hipMemcpyDeviceToHost));
-    return OZ_OK;
+    const size_t c8 = 8ull * count;
+    return rules_call(2 * c8 + count, 2 * c8,
+        [&](unsigned char* h) { memcpy(h, own, c8); memcpy(h + c8, opp, c8); memcpy(h + 2 * c8, sq, count); },
+        [&](unsigned char* di, unsigned char* dout, hipStream_t s) {
+            hipLaunchKernelGGL(k_apply, dim3(grid_for(count)), dim3(256), 0, s, (const uint64_t*)di, (const uint64_t*)(di + c8),
+                               (const uint8_t*)(di + 2 * c8), count, (uint64_t*)dout, (uint64_t*)(dout + c8));
+        },
+        [&](const unsigned char* h) { memcpy(own_out, h, c8); memcpy(opp_out, h + c8, c8); });
 }
 
 OZ_API int oz_rules_status(const uint64_t* ch0, const uint64_t* ch1, int n, int count, uint8_t* finished,
                            int32_t* pts0, int32_t* pts1, int8_t* winner) {
     if (int rc = check_n(n)) return rc;
     if (count <= 0) return OZ_OK;
-    oz_current_device();
-    DevBuf<uint64_t> a, b; DevBuf<uint8_t> f; DevBuf<int32_t> p0, p1; DevBuf<int8_t> w;
-    OZ_HIP(a.alloc(count)); OZ_HIP(b.alloc(count)); OZ_HIP(f.alloc(count)); OZ_HIP(p0.alloc(count)); OZ_HIP(p1.alloc(count)); OZ_HIP(w.alloc(count));
-    OZ_HIP(hipMemcpy(a.p, ch0, 8ull * count, hipMemcpyHostToDevice));
-    OZ_HIP(hipMemcpy(b.p, ch1, 8ull * count, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_status, dim3(grid_for(count)), dim3(256), 0, 0, a.p, b.p, count, oz_valid_mask(n), f.p, p0.p, p1.p, w.p);
-    OZ_HIP(hipGetLastError());
-    OZ_HIP(hipMemcpy(finished, f.p, count, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(pts0, p0.p, 4ull * count, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(pts1, p1.p, 4ull * count, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(winner, w.p, count, hipMemcpyDeviceToHost));
-    return OZ_OK;
+    const size_t c8 = 8ull * count, c4 = 4ull * count, c1 = pad8(count);
+    // output image: pts0 | pts1 | finished | winner (each 8-byte aligned)
+    return rules_call(2 * c8, 2 * pad8(c4) + 2 * c1,
+        [&](unsigned char* h) { memcpy(h, ch0, c8); memcpy(h + c8, ch1, c8); },
+        [&](unsigned char* di, unsigned char* dout, hipStream_t s) {
+            hipLaunchKernelGGL(k_status, dim3(grid_for(count)), dim3(256), 0, s, (const uint64_t*)di, (const uint64_t*)(di + c8), count,
+                               oz_valid_mask(n), (uint8_t*)(dout + 2 * pad8(c4)), (int32_t*)dout, (int32_t*)(dout + pad8(c4)),
+                               (int8_t*)(dout + 2 * pad8(c4) + c1));
+        },
+        [&](const unsigned char* h) {
+            memcpy(pts0, h, c4); memcpy(pts1, h + pad8(c4), c4);
+            memcpy(finished, h + 2 * pad8(c4), count); memcpy(winner, h + 2 * pad8(c4) + c1, count);
+        });
 }
 
 OZ_API int oz_rules_play(const uint64_t* black, const uint64_t* white, const int8_t* player, const uint8_t* sq, int n,
@@ -145,21 +184,17 @@ OZ_API int oz_rules_play(const uint64_t* black, const uint64_t* white, const int
         OZ_REQUIRE((sq[i] >> 3) < n && (sq[i] & 7) < n, "square %d outside the %dx%d board", sq[i], n, n);
         OZ_REQUIRE(player[i] == 1 || player[i] == -1, "player must be +1 or -1");
     }
-    oz_current_device();
-    DevBuf<uint64_t> b, w, bo, wo; DevBuf<int8_t> p, po; DevBuf<uint8_t> s, fo;
-    OZ_HIP(b.alloc(count)); OZ_HIP(w.alloc(count)); OZ_HIP(bo.alloc(count)); OZ_HIP(wo.alloc(count));
-    OZ_HIP(p.alloc(count)); OZ_HIP(po.alloc(count)); OZ_HIP(s.alloc(count)); OZ_HIP(fo.alloc(count));
-    OZ_HIP(hipMemcpy(b.p, black, 8ull * count, hipMemcpyHostToDevice));
-    OZ_HIP(hipMemcpy(w.p, white, 8ull * count, hipMemcpyHostToDevice));
-    OZ_HIP(hipMemcpy(p.p, player, count, hipMemcpyHostToDevice));
-    OZ_HIP(hipMemcpy(s.p, sq, count, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_play, dim3(grid_for(count)), dim3(256), 0, 0, b.p, w.p, p.p, s.p, count, oz_valid_mask(n), bo.p, wo.p, po.p, fo.p);
-    OZ_HIP(hipGetLastError());
-    OZ_HIP(hipMemcpy(black_out, bo.p, 8ull * count, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(white_out, wo.p, 8ull * count, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(player_out, po.p, count, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(finished_out, fo.p, count, hipMemcpyDeviceToHost));
-    return OZ_OK;
+    const size_t c8 = 8ull * count, c1 = pad8(count);
+    return rules_call(2 * c8 + 2 * c1, 2 * c8 + 2 * c1,
+        [&](unsigned char* h) { memcpy(h, black, c8); memcpy(h + c8, white, c8); memcpy(h + 2 * c8, player, count); memcpy(h + 2 * c8 + c1, sq, count); },
+        [&](unsigned char* di, unsigned char* dout, hipStream_t s) {
+            hipLaunchKernelGGL(k_play, dim3(grid_for(count)), dim3(256), 0, s, (const uint64_t*)di, (const uint64_t*)(di + c8),
+                               (const int8_t*)(di + 2 * c8), (const uint8_t*)(di + 2 * c8 + c1), count, oz_valid_mask(n), (uint64_t*)dout,
+                               (uint64_t*)(dout + c8), (int8_t*)(dout + 2 * c8), (uint8_t*)(dout + 2 * c8 + c1));
+        },
+        [&](const unsigned char* h) {
+            memcpy(black_out, h, c8); memcpy(white_out, h + c8, c8); memcpy(player_out, h + 2 * c8, count); memcpy(finished_out, h + 2 * c8 + c1, count);
+        });
 }
 
 // ---------------------------------------------------------------- symmetries (K8)

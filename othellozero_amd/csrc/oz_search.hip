@@ -353,9 +353,12 @@ struct oz_mcts {
     std::mutex mu;
     bool selected = false;
     std::vector<void*> allocs;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double eval_ms = 0; long long eval_launches = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    // HIP-event timing on the launch stream: slot TS_NN (the evaluator's launches) whenever a driver asks for it,
+    // the tree kernels too when `profile` is on (oz_selfplay_profile)
+    OzTimer timer{OZ_TREE_KERNELS};
+    bool profile = false;
+    // staging of oz_mcts_root_counts (called once per move by the drop-in agents): lives with the object
+    int32_t* rc_counts = nullptr; uint64_t* rc_legal = nullptr; int32_t* rc_rc = nullptr;
 
     template <typename T> int alloc(T** p, size_t count) {
         OZ_HIP(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
@@ -407,6 +410,9 @@ static int mcts_create(oz_mcts** out, int n, int G, int node_cap, int edge_cap, 
     A(last_value, G); A(last_vtype, G);
     A(stat, (size_t)G * OZ_NSTAT); A(error_flag, 1); A(eval_leaves, 1);
 #undef A
+    if (!rc) rc = m->alloc(&m->rc_counts, (size_t)G * 64);
+    if (!rc) rc = m->alloc(&m->rc_legal, (size_t)G);
+    if (!rc) rc = m->alloc(&m->rc_rc, (size_t)G);
     { const char* e = getenv("OZ_DEDUP"); d.dedup = !(e && atoi(e) == 0); }      // OZ_DEDUP=0: one evaluation per game and step (A/B runs, tests)
     if (!rc && hipStreamCreate(&m->stream) != hipSuccess) { oz_set_error("hipStreamCreate failed"); rc = OZ_ERR_HIP; }
     if (!rc) {
@@ -436,7 +442,7 @@ static void mcts_destroy(oz_mcts* m) {
     if (!m) return;
     hipSetDevice(m->device);
     hipStreamSynchronize(m->stream);
-    for (auto& pr : m->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    m->timer.destroy();
     for (void* p : m->allocs) hipFree(p);
     hipStreamDestroy(m->stream);
     delete m;
@@ -459,34 +465,29 @@ static int check_error_flag(oz_mcts* m) {
 }
 
 // one lock-step simulation for every active game, leaves evaluated by `net` (all on m->stream)
+enum { TS_SELECT = 0, TS_COMPACT = 1, TS_NN = 2, TS_BACKUP = 3, TS_MOVE = 4 };
 static int mcts_step_async(oz_mcts* m, oz_net* net, bool time_eval) {
     MctsDev& d = m->d;
-    hipLaunchKernelGGL(k_select, dim3(d.G), dim3(64), 0, m->stream, d);
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, m->stream, d);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (time_eval) {
-        OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1));
-        OZ_HIP(hipEventRecord(e0, m->stream));
-    }
-    if (int rc = oz_net_forward_device(net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, m->stream)) return rc;
-    if (time_eval) {
-        OZ_HIP(hipEventRecord(e1, m->stream));
-        m->pending.push_back({e0, e1});
-    }
-    hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, m->stream, d, 0);
+    hipStream_t s = m->stream;
+    const bool all = m->profile;
+    int i = all ? m->timer.begin(TS_SELECT, s) : -1;
+    hipLaunchKernelGGL(k_select, dim3(d.G), dim3(64), 0, s, d);
+    m->timer.end(i, s);
+    i = all ? m->timer.begin(TS_COMPACT, s) : -1;
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, d);
+    m->timer.end(i, s);
+    i = (time_eval || all) ? m->timer.begin(TS_NN, s) : -1;
+    if (int rc = oz_net_forward_device(net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, s)) { m->timer.cancel(i); return rc; }
+    m->timer.end(i, s);
+    i = all ? m->timer.begin(TS_BACKUP, s) : -1;
+    hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, s, d, 0);
+    m->timer.end(i, s);
     OZ_HIP(hipGetLastError());
     return OZ_OK;
 }
 
 static int mcts_collect_eval_time(oz_mcts* m) {
-    for (auto& pr : m->pending) {
-        float ms = 0;
-        OZ_HIP(hipEventSynchronize(pr.second));
-        OZ_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
-        m->eval_ms += ms; m->eval_launches += 1;
-        hipEventDestroy(pr.first); hipEventDestroy(pr.second);
-    }
-    m->pending.clear();
+    if (m->timer.collect() != OZ_OK) { oz_set_error("HIP event timing failed"); return OZ_ERR_HIP; }
     return OZ_OK;
 }
 
@@ -606,15 +607,12 @@ OZ_API int oz_mcts_root_counts(oz_mcts* m, int32_t* counts, uint64_t* legal, int
     std::lock_guard<std::mutex> lk(m->mu);
     hipSetDevice(m->device);
     const int G = m->d.G;
-    int32_t* dc; uint64_t* dl; int32_t* dr;
-    OZ_HIP(hipMalloc((void**)&dc, 4ull * G * 64)); OZ_HIP(hipMalloc((void**)&dl, 8ull * G)); OZ_HIP(hipMalloc((void**)&dr, 4ull * G));
+    int32_t* dc = m->rc_counts; uint64_t* dl = m->rc_legal; int32_t* dr = m->rc_rc;
     hipLaunchKernelGGL(k_root_counts, dim3(G), dim3(64), 0, m->stream, m->d, dc, dl, dr);
-    hipMemcpyAsync(counts, dc, 4ull * G * 64, hipMemcpyDeviceToHost, m->stream);
-    hipMemcpyAsync(legal, dl, 8ull * G, hipMemcpyDeviceToHost, m->stream);
-    hipMemcpyAsync(rc, dr, 4ull * G, hipMemcpyDeviceToHost, m->stream);
-    hipError_t e = hipStreamSynchronize(m->stream);
-    hipFree(dc); hipFree(dl); hipFree(dr);
-    OZ_HIP(e);
+    OZ_HIP(hipMemcpyAsync(counts, dc, 4ull * G * 64, hipMemcpyDeviceToHost, m->stream));
+    OZ_HIP(hipMemcpyAsync(legal, dl, 8ull * G, hipMemcpyDeviceToHost, m->stream));
+    OZ_HIP(hipMemcpyAsync(rc, dr, 4ull * G, hipMemcpyDeviceToHost, m->stream));
+    OZ_HIP(hipStreamSynchronize(m->stream));
     return OZ_OK;
 }
 
@@ -701,6 +699,20 @@ __global__ void k_sp_roots(GamesDev gm, MctsDev t, int mover_filter /* 0 all, +1
     if (g >= gm.G) return;
     const int p = gm.player[g];
     const bool act = !gm.finished[g] && (mover_filter == 0 || mover_filter == p);
+    t.active[g] = act ? 1 : 0;
+    if (act) {
+        t.root_own[g] = p == 1 ? gm.black[g] : gm.white[g];
+        t.root_opp[g] = p == 1 ? gm.white[g] : gm.black[g];
+    }
+}
+
+// oz_selfplay_stagger: in round r only the slots whose start offset is still ahead of r search and move
+__global__ void k_sp_roots_stagger(GamesDev gm, MctsDev t, int round, int period) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= gm.G) return;
+    const int offset = (int)(((long long)g * period) / gm.G);
+    const int p = gm.player[g];
+    const bool act = !gm.finished[g] && offset > round;
     t.active[g] = act ? 1 : 0;
     if (act) {
         t.root_own[g] = p == 1 ? gm.black[g] : gm.white[g];
@@ -882,6 +894,7 @@ struct oz_selfplay {
     GamesDev gm;
     int* d_sims_done = nullptr;      // free-running mode: simulations completed for the move in progress, per game
     int mode = 0;                    // 0 fresh, 1 driven by oz_selfplay_run (lock step), 2 by oz_selfplay_run_steps (free-running)
+    int stagger_period = 0;
     std::vector<void*> allocs;
     std::mutex mu;
     long long records_read = 0;
@@ -968,23 +981,76 @@ OZ_API int oz_selfplay_destroy(oz_selfplay* sp) {
     return OZ_OK;
 }
 
+// one move round on m->stream: roots, `sims` lock-step simulations, move.  stagger_round >= 0: only slots whose start
+// offset (oz_selfplay_stagger) is still ahead of that round take part
+static int selfplay_round_async(oz_selfplay* sp, int sims, int stagger_round) {
+    oz_mcts* m = sp->m;
+    const int G = sp->gm.G;
+    hipStream_t s = m->stream;
+    int ti = m->profile ? m->timer.begin(TS_MOVE, s) : -1;
+    if (stagger_round >= 0) hipLaunchKernelGGL(k_sp_roots_stagger, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, m->d, stagger_round, sp->stagger_period);
+    else hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, m->d, 0);
+    m->timer.end(ti, s);
+    for (int i = 0; i < sims; ++i)
+        if (int rc = mcts_step_async(m, sp->net, true)) return rc;
+    ti = m->profile ? m->timer.begin(TS_MOVE, s) : -1;
+    hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, m->d, 0);
+    m->timer.end(ti, s);
+    OZ_HIP(hipGetLastError());
+    if (m->timer.backlog() > 8192) { if (int rc = mcts_collect_eval_time(m)) return rc; }
+    return OZ_OK;
+}
+
 OZ_API int oz_selfplay_run(oz_selfplay* sp, int rounds) {
     OZ_REQUIRE(sp, "null selfplay");
     std::lock_guard<std::mutex> lk(sp->mu);
     std::lock_guard<std::mutex> lkn(sp->net->mu);
-    oz_mcts* m = sp->m;
-    hipSetDevice(m->device);
+    hipSetDevice(sp->m->device);
     OZ_REQUIRE(sp->mode != 2, "oz_selfplay_run after oz_selfplay_run_steps: moves are in progress (use one driver per engine)");
     sp->mode = 1;
-    const int G = sp->gm.G;
-    for (int r = 0; r < rounds; ++r) {
-        hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, m->stream, sp->gm, m->d, 0);
-        for (int s = 0; s < sp->cfg.sims; ++s)
-            if (int rc = mcts_step_async(m, sp->net, true)) return rc;
-        hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, m->stream, sp->gm, m->d, 0);
-        OZ_HIP(hipGetLastError());
-        if (m->pending.size() > 4096) { if (int rc = mcts_collect_eval_time(m)) return rc; }
+    for (int r = 0; r < rounds; ++r)
+        if (int rc = selfplay_round_async(sp, sp->cfg.sims, -1)) return rc;
+    return OZ_OK;
+}
+
+// Spread the slots of a continuous self-play engine over the plies of a game BEFORE measuring it: a service that has been
+// running for a while holds games at every stage, whereas a fresh engine holds num_games openings that would all finish in
+// the same move round.  Slot g gets the start offset (g * period) / num_games, period = the longest game (n*n - 4 plies):
+// in round r (r = 0 .. period-2) the slots whose offset is > r play one move with `sims_pre` simulations -- real searched
+// self-play moves by the same kernels and RNG streams, recorded like any other -- the others wait.  Afterwards slot g is
+// offset(g) plies into its first game, and the refills keep the spread.  Asynchronous, like oz_selfplay_run.
+OZ_API int oz_selfplay_stagger(oz_selfplay* sp, int sims_pre) {
+    OZ_REQUIRE(sp, "null selfplay");
+    OZ_REQUIRE(sims_pre >= 2, "sims_pre must be >= 2 (the reference raises KeyError with one simulation)");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    std::lock_guard<std::mutex> lkn(sp->net->mu);
+    hipSetDevice(sp->m->device);
+    OZ_REQUIRE(sp->mode == 0, "oz_selfplay_stagger must be the first driver call on an engine");
+    OZ_REQUIRE(sp->cfg.refill, "oz_selfplay_stagger is for continuous self-play (cfg.refill = 1)");
+    sp->mode = 1;
+    sp->stagger_period = sp->cfg.n * sp->cfg.n - 4;
+    for (int r = 0; r + 1 < sp->stagger_period; ++r)
+        if (int rc = selfplay_round_async(sp, sims_pre, r)) return rc;
+    return OZ_OK;
+}
+
+OZ_API int oz_selfplay_profile(oz_selfplay* sp, int enable) {
+    OZ_REQUIRE(sp, "null selfplay");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    sp->m->profile = enable != 0;
+    return OZ_OK;
+}
+
+OZ_API int oz_selfplay_profile_read(oz_selfplay* sp, double* ms_total, int64_t* launches, int reset) {
+    OZ_REQUIRE(sp, "null selfplay");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    hipSetDevice(sp->m->device);
+    if (int rc = mcts_collect_eval_time(sp->m)) return rc;
+    for (int i = 0; i < OZ_TREE_KERNELS; ++i) {
+        if (ms_total) ms_total[i] = sp->m->timer.ms[i];
+        if (launches) launches[i] = sp->m->timer.count[i];
     }
+    if (reset) sp->m->timer.reset();
     return OZ_OK;
 }
 
@@ -998,17 +1064,22 @@ OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
     if (sp->mode == 1) OZ_HIP(hipMemsetAsync(d.leaf_status, 0, sizeof(int) * d.G, m->stream));    // no simulation is pending after whole rounds
     sp->mode = 2;
     for (int i = 0; i < steps; ++i) {
-        hipLaunchKernelGGL(k_advance, dim3(d.G), dim3(64), 0, m->stream, sp->gm, d, sp->cfg.sims, sp->d_sims_done);
-        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, m->stream, d);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        OZ_HIP(hipEventCreate(&e0)); OZ_HIP(hipEventCreate(&e1));
-        OZ_HIP(hipEventRecord(e0, m->stream));
-        if (int rc = oz_net_forward_device(sp->net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, m->stream)) return rc;
-        OZ_HIP(hipEventRecord(e1, m->stream));
-        m->pending.push_back({e0, e1});
-        hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, m->stream, d, 0);
+        const bool all = m->profile;
+        hipStream_t s = m->stream;
+        int ti = all ? m->timer.begin(TS_SELECT, s) : -1;
+        hipLaunchKernelGGL(k_advance, dim3(d.G), dim3(64), 0, s, sp->gm, d, sp->cfg.sims, sp->d_sims_done);
+        m->timer.end(ti, s);
+        ti = all ? m->timer.begin(TS_COMPACT, s) : -1;
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, d);
+        m->timer.end(ti, s);
+        ti = m->timer.begin(TS_NN, s);
+        if (int rc = oz_net_forward_device(sp->net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, s)) { m->timer.cancel(ti); return rc; }
+        m->timer.end(ti, s);
+        ti = all ? m->timer.begin(TS_BACKUP, s) : -1;
+        hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, s, d, 0);
+        m->timer.end(ti, s);
         OZ_HIP(hipGetLastError());
-        if (m->pending.size() > 4096) { if (int rc = mcts_collect_eval_time(m)) return rc; }
+        if (m->timer.backlog() > 8192) { if (int rc = mcts_collect_eval_time(m)) return rc; }
     }
     return OZ_OK;
 }
@@ -1102,8 +1173,8 @@ OZ_API int oz_selfplay_eval_time(oz_selfplay* sp, double* ms_total, int64_t* lau
     std::lock_guard<std::mutex> lk(sp->mu);
     hipSetDevice(sp->m->device);
     if (int rc = mcts_collect_eval_time(sp->m)) return rc;
-    if (ms_total) *ms_total = sp->m->eval_ms;
-    if (launches) *launches = sp->m->eval_launches;
+    if (ms_total) *ms_total = sp->m->timer.ms[TS_NN];
+    if (launches) *launches = sp->m->timer.count[TS_NN];
     if (leaves) {
         int64_t s5[OZ_NSTAT];
         if (int rc = mcts_stats_locked(sp->m, s5)) return rc;

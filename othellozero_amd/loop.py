@@ -73,14 +73,25 @@ class CircularArray:
         return f'{type(self).__name__}({len(self._list)!r})'
 
 
-def examples_from_records(records, board_size, alias_final=True):
-    """move records of finished games -> the reference's example tuples [(board (n,n,2) bool, one-hot policy (n,n), z)],
-    8 per move in training.py:13-23's order.  alias_final=True shows every board as the game's FINAL position, which is
-    what execute_episode really returns; False stores the position at the move."""
-    boards, pol, z = expand_examples(records, board_size, alias_final=alias_final)
+def examples_from_records(records, board_size, alias_final=True, in_channels=2):
+    """move records of finished games -> the reference's example tuples [(board, one-hot policy (n,n), z)], 8 per move in
+    training.py:13-23's order.
+
+    in_channels=2 (OthelloNN): board (n,n,2) bool; alias_final=True shows every board as the game's FINAL position, which is
+    what execute_episode really returns (the examples are views of the live game array); False stores the
+    position at the move.
+    in_channels=1 (BaseNN): board (n,n) with +1 BLACK / -1 WHITE, the position AT THE MOVE whatever alias_final says -- the
+    reference builds a fresh one-channel array per round for BNN (training.py:34-37, Othello/__init__.py:79-84,266-270), so
+    those examples are never aliased."""
+    one_channel = in_channels == 1
+    boards, pol, z = expand_examples(records, board_size, alias_final=alias_final and not one_channel)
     n = board_size
+    if one_channel:
+        boards = boards[..., 0].astype(np.int64) - boards[..., 1].astype(np.int64)      # convert_to_one_channel_board
+    else:
+        boards = boards.astype(bool)
     out = []
-    for b, p, zz in zip(boards.astype(bool), pol, z):
+    for b, p, zz in zip(boards, pol, z):
         policy = np.zeros((n, n))
         policy[p // n, p % n] = 1
         out.append((b, policy, int(zz)))
@@ -176,6 +187,8 @@ def training(board_size, num_iterations, num_episodes, num_simulations, degree_e
         world, rank = dist.get_world_size(), dist.get_rank()
         assert num_episodes >= world, "fewer episodes than ranks"
         device = torch.device("cuda", torch.cuda.current_device())
+        # pin the library to the device torch selected for this rank (objects created on this thread from here on)
+        _lib.check(_lib.load().oz_set_device(torch.cuda.current_device()))
         allreduce = GradientAllReduce(board_size, neural_network.num_channels, neural_network.in_channels, device=device)
         random.seed(seed)
 
@@ -205,7 +218,8 @@ def training(board_size, num_iterations, num_episodes, num_simulations, degree_e
             records = selfplay_batch(neural_network, board_size, num_games=num_episodes, num_simulations=num_simulations,
                                      degree_exploration=degree_exploration, policy_temperature=temperature, e_greedy=e_greedy,
                                      seed=seed, first_game_id=total_episodes_done, q_mode=q_mode)
-        training_examples.extend(examples_from_records(records, board_size, alias_final=alias_final_boards))
+        training_examples.extend(examples_from_records(records, board_size, alias_final=alias_final_boards,
+                                                       in_channels=getattr(neural_network, "in_channels", 2)))
         total_episodes_done += num_episodes
         logging.info(f'Iteration {i}/{num_iterations}: All episodes finished')
 

@@ -113,6 +113,25 @@ class SelfPlayEngine:
         if sync:
             self.sync()
 
+    def stagger(self, sims_pre=None, sync=True):
+        """continuous self-play (refill=True), first call only: advance slot g (g * P) // num_games plies into its first game
+        (P = n*n - 4) by searched moves at `sims_pre` simulations each (default: num_simulations), so that the engine holds
+        games at every stage like a long-running service and every later move round completes about num_games / P games"""
+        _lib.check(_lib.load().oz_selfplay_stagger(self._h, int(sims_pre or self.cfg.sims)))
+        if sync:
+            self.sync()
+
+    def profile(self, enable=True):
+        """HIP-event timing of the tree kernels on the launch stream (the evaluator's launches are always timed)"""
+        _lib.check(_lib.load().oz_selfplay_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self, reset=False):
+        """{kernel: (ms_total, launches)} for _lib.TREE_KERNELS"""
+        k = len(_lib.TREE_KERNELS)
+        ms, cnt = np.zeros(k, np.float64), np.zeros(k, np.int64)
+        _lib.check(_lib.load().oz_selfplay_profile_read(self._h, _lib.p_f64(ms), _lib.p_i64(cnt), 1 if reset else 0))
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.TREE_KERNELS)}
+
     def sync(self):
         _lib.check(_lib.load().oz_selfplay_sync(self._h))
 

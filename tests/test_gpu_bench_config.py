@@ -1,0 +1,202 @@
+"""Parity at the configuration bench.py runs (BASELINE configs[1] / configs[3]): the 512-filter OthelloNN built with
+max_batch = 4096 -- every convolution on ONE k-slice with the fused BN + ReLU + h2 re-split epilogue, fc1 on the 256 x 256
+ping-pong tile with 4-way split-K, fc2 on the thin tile without split-K; precision f32 without split-K slabs -- against the
+float64 restatement of Net/OthelloNN.py:42-56 (oracle/nn_numpy.py), and the batched engine at 4096 games x 100 sims with
+that network against the oracle's search (MCTS/__init__.py:30-84, training.py:26-72) replaying sampled games.
+
+Tolerance (BASELINE.json north_star): |d pi|, |d v| <= 1e-5 absolute; moves, boards, z and visit counts bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import nn_numpy
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5            # north_star: "within 1e-5 on float policy/value"
+TWIN_TOL = 2e-6       # two builds of the same network with other tile shapes / k-splits: rounding only
+C = 512
+B = 4096
+
+
+@pytest.fixture(scope="module")
+def oz():
+    from othellozero_amd import _lib
+    _lib.require_gpu()
+    return _lib
+
+
+def _weights(n):
+    from othellozero_amd.weights import init_weights
+    w = init_weights(n, seed=40 + n, channels=C, randomize_all=True)     # kernels, biases, BN gamma / beta / mean / variance all random
+    for i in (36, 38):
+        w[i] = w[i] * 4.0                                                # logits away from uniform, |v| away from 0
+    return w
+
+
+def _positions(n, count):
+    """`count` canonical positions: the corner cases of the input planes, every position of 64 self-play games (what the
+    engine really feeds the network: openings, middle games, nearly full boards, both movers), random fillings for the rest"""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    valid = np.uint64(sum(1 << (r * 8 + c) for r in range(n) for c in range(n)))
+    bit = lambda r, c: np.uint64(1 << (r * 8 + c))
+    rs = np.random.RandomState(900 + n)
+    full = rs.randint(0, 2**63, size=1, dtype=np.uint64)[0] & valid
+    special = [(0, 0), (valid, 0), (0, valid), (full, valid & ~full), (bit(0, 0), bit(n - 1, n - 1)), (bit(0, n - 1), bit(n - 1, 0)),
+               (bit(n // 2, 0), bit(0, n // 2)), (bit(n - 1, n // 2) | bit(n // 2, n - 1), 0)]
+    G = 64
+    eng = SelfPlayEngine(StubNetWrapper((n, n), 17, 0, max_batch=G), n, G, 8, 1.0, 1.0, 0.7, seed=3)
+    rec = eng.play_to_end()
+    own = np.where(rec["player"] == 1, rec["black"], rec["white"])
+    opp = np.where(rec["player"] == 1, rec["white"], rec["black"])
+    # ... and the final boards of those games (full or nearly full)
+    own = np.concatenate([np.array([s[0] for s in special], np.uint64), own, rec["final_black"][::16]])
+    opp = np.concatenate([np.array([s[1] for s in special], np.uint64), opp, rec["final_white"][::16]])
+    rest = count - own.size
+    assert rest > count // 8
+    dens = rs.rand(rest)                                                 # sparse to dense fillings
+    a = np.zeros(rest, np.uint64); b = np.zeros(rest, np.uint64)
+    for r in range(n):
+        for c in range(n):
+            u = rs.rand(rest)
+            a |= np.where(u < dens * 0.5, bit(r, c), np.uint64(0))
+            b |= np.where((u >= dens * 0.5) & (u < dens), bit(r, c), np.uint64(0))
+    own, opp = np.concatenate([own, a]), np.concatenate([opp, b])
+    assert own.size == count and np.all((own & opp) == 0) and np.all(((own | opp) & ~valid) == 0)
+    return own, opp
+
+
+_CACHE = {}
+
+
+def _case(n):
+    """weights, 4096 positions and their float64 (pi, v) -- computed once per board size"""
+    if n not in _CACHE:
+        w = _weights(n)
+        own, opp = _positions(n, B)
+        pi64, v64 = nn_numpy.forward_chunked(w, own, opp, n, chunk=512)
+        assert pi64.std() > 2e-3 and np.abs(v64).max() > 0.05            # the comparison is not vacuous
+        _CACHE[n] = (w, own, opp, pi64, v64)
+    return _CACHE[n]
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+@pytest.mark.parametrize("n", [8, 6])
+def test_network_at_bench_batch_vs_float64_oracle(oz, n, precision):
+    """NNetWrapper(max_batch=4096), ONE call with 4096 positions == one forward of the kernels bench.py times"""
+    from othellozero_amd.NNet import NNetWrapper
+    w, own, opp, pi64, v64 = _case(n)
+    net = NNetWrapper((n, n), num_channels_1=C, max_batch=B, weights=w, precision=precision)
+    pi, v = net.predict_batch(own, opp)
+    pi = pi.reshape(B, -1)
+    err_pi, err_v = np.abs(pi - pi64).max(), np.abs(v - v64).max()
+    assert err_pi <= TOL and err_v <= TOL, (err_pi, err_v)
+    assert np.abs(pi.sum(axis=1) - 1).max() < 1e-5
+    # row mapping: the worst row is no worse than the tolerance, and no two distinct positions were swapped
+    # (a transposed / shifted epilogue row would put position i's outputs at position j != i)
+    rows = np.abs(pi - pi64).max(axis=1)
+    assert rows.max() <= TOL and int((rows > TOL / 10).sum()) <= B // 100
+    # the same positions in another order, and a shorter call: bit-identical per position
+    perm = np.random.RandomState(1).permutation(B)
+    p2, v2 = net.predict_batch(own[perm], opp[perm])
+    assert np.array_equal(p2.reshape(B, -1), pi[perm]) and np.array_equal(v2, v[perm])
+    p3, v3 = net.predict_batch(own[100:1337], opp[100:1337])
+    assert np.array_equal(p3.reshape(1237, -1), pi[100:1337]) and np.array_equal(v3, v[100:1337])
+    # a max_batch = 2048 build (the same one-k-slice kernels on half the grid) and a max_batch = 64 twin (split-K 2-8 with
+    # k_splitk_reduce_h2, 128 x 128 dense tiles): the same network to rounding
+    half = NNetWrapper((n, n), num_channels_1=C, max_batch=2048, weights=w, precision=precision)
+    ph, vh = half.predict_batch(own[:2048], opp[:2048])
+    assert np.abs(ph.reshape(2048, -1) - pi64[:2048]).max() <= TOL and np.abs(vh - v64[:2048]).max() <= TOL
+    assert np.abs(ph.reshape(2048, -1) - pi[:2048]).max() <= TWIN_TOL and np.abs(vh - v[:2048]).max() <= TWIN_TOL
+    del half
+    twin = NNetWrapper((n, n), num_channels_1=C, max_batch=64, weights=w, precision=precision)
+    sel = np.r_[0:64, 1000:1064, B - 64:B]
+    pt, vt = twin.predict_batch(own[sel], opp[sel])
+    assert np.abs(pt.reshape(sel.size, -1) - pi[sel]).max() <= TWIN_TOL and np.abs(vt - v[sel]).max() <= TWIN_TOL
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_network_at_bench_batch_gemm_form_vs_float64_oracle(oz, precision):
+    """the same 4096-position forward with conv1 as a kernel and conv2 as an MFMA implicit GEMM (oz_net_set_tables 0: the
+    `all_layers_as_gemm` leg of bench.py) -- the 256 x 256 ping-pong tile on conv2 at one k-slice"""
+    from othellozero_amd.NNet import NNetWrapper
+    n = 8
+    w, own, opp, pi64, v64 = _case(n)
+    net = NNetWrapper((n, n), num_channels_1=C, max_batch=B, weights=w, precision=precision)
+    net.set_tables(0)
+    pi, v = net.predict_batch(own, opp)
+    assert net.profiled_layer() == 2
+    assert np.abs(pi.reshape(B, -1) - pi64).max() <= TOL and np.abs(v - v64).max() <= TOL
+    if precision == "f16x2":
+        net.set_tables(1)                                                # conv1 from its table inside conv2's operand gather
+        p1, v1 = net.predict_batch(own, opp)
+        assert np.array_equal(p1, pi) and np.array_equal(v1, v)          # documented bit-identical to mode 0
+
+
+@pytest.mark.parametrize("precision,dedup", [("f16x2", False), ("f16x2", True), ("f32", False)])
+def test_config2_real_network_search_replay(oz, precision, dedup, monkeypatch):
+    """BASELINE configs[1] with the real network: 4096 concurrent 8x8 games x 100 sims/move x 2 move rounds on the
+    512-filter OthelloNN (max_batch 4096: the kernels bench.py times); 16 sampled games are replayed by the oracle's search
+    fed with the GPU network's own (pi, v) per position -- moves, boards and root visit counts must match bit for bit
+    (network rounding cannot excuse a divergent game), with the cross-game leaf de-duplication off (bench headline) and on"""
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    n, G, sims, rounds = 8, B, 100, 2
+    monkeypatch.setenv("OZ_DEDUP", "1" if dedup else "0")
+    net = NNetWrapper((n, n), num_channels_1=C, max_batch=G, seed=0, precision=precision)        # bench.py's network (seed 0)
+    eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=0, q_mode=1)
+    eng.run(1)
+    counts1 = eng.last_counts().copy()
+    eng.run(rounds - 1)
+    st, after, counts2 = eng.stats(), eng.state(), eng.last_counts()
+    assert st["simulations"] == G * sims * rounds and st["moves"] == G * rounds and st["overflow"] == 0
+    assert (st["leaves_evaluated"] < st["expansions"]) if dedup else (st["leaves_evaluated"] == st["expansions"])
+    cache = {}
+
+    def ev(own, opp, nn):
+        if (own, opp) not in cache:
+            p, v = net.predict_batch([own], [opp])                       # a position's (pi, v) does not depend on the batch
+            cache[(own, opp)] = (p[0].ravel(), float(v[0]))
+        return cache[(own, opp)]
+    for gi in list(range(0, G, G // 12)) + [1, 2, G - 1, G - 2][: 16 - len(range(0, G, G // 12))]:
+        ep = oracle.Mcts(n, 1.0, 1, evaluator=ev).episode(sims, 1.0, 0.9, 1234, gi, max_moves=rounds)
+        assert np.array_equal(counts1[gi], ep["counts"][0]), gi
+        assert np.array_equal(counts2[gi], ep["counts"][1]), gi
+        import ctypes as CT
+        b, w = CT.c_uint64(int(ep["black"][-1])), CT.c_uint64(int(ep["white"][-1]))
+        pl, fin = CT.c_int(int(ep["player"][-1])), CT.c_int(0)
+        oracle.lib().orc_game_play(CT.byref(b), CT.byref(w), n, CT.byref(pl), CT.byref(fin), int(ep["action"][-1]))
+        assert (b.value, w.value, pl.value) == (int(after["black"][gi]), int(after["white"][gi]), int(after["player"][gi])), gi
+
+
+def test_stagger_spreads_games_and_keeps_records_exact(oz):
+    """oz_selfplay_stagger: slot g ends (g * P) // G plies into its first game; the staggered moves are ordinary searched
+    moves -- a game's record list equals the oracle's episode with `sims_pre` simulations on its first offset(g) plies and
+    `sims` afterwards; afterwards every move round completes games"""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    n, G, sims, pre = 6, 64, 10, 4
+    P = n * n - 4
+    eng = SelfPlayEngine(StubNetWrapper((n, n), 9, 0, max_batch=G), n, G, sims, 1.0, 1.0, 0.9, seed=21, first_game_id=0,
+                         game_id_stride=G, refill=True, record_cap=G * 8 * n * n)
+    eng.stagger(pre)
+    st = eng.state()
+    offs = (np.arange(G) * P) // G
+    live = st["game_id"] < G                                              # (a game that ended during the stagger was refilled)
+    assert np.array_equal(st["ply"][live], offs[live]) and live.sum() >= G - 2
+    done0 = eng.stats()["games_completed"]
+    eng.run(P + 4)
+    s1 = eng.stats()
+    assert s1["games_completed"] - done0 >= G                              # every first-generation game finished ...
+    rec = eng.records()
+    per_round = np.bincount(rec["game_id"].astype(np.int64) % G, minlength=G)
+    assert per_round.min() > 0
+    with pytest.raises(oz.OzError):
+        eng.stagger(pre)                                                   # first driver call only
+    # exactness of a staggered game: the oracle plays game g with `pre` sims on plies < offset(g), `sims` afterwards
+    for g in (5, 33, 63):
+        r = rec[rec["game_id"] == g]
+        m = oracle.Mcts(n, 1.0, 1, salt=9)
+        ep = m.episode(sims, 1.0, 0.9, 21, g, sims_pre=pre, pre_plies=int(offs[g]))
+        assert np.array_equal(r["action"], ep["action"]) and np.array_equal(r["z"], ep["z"]), g

@@ -56,6 +56,65 @@ def test_examples_from_records_match_execute_episode_layout():
     assert ex2[7][0].sum() == 4 + 0                 # the real first position: 4 discs
 
 
+def test_pack_examples_accepts_one_channel_boards():
+    """trainer.pack_examples with in_channels=1 takes (n,n) +1 / -1 boards (what examples_from_records emits for BNN) --
+    two-channel boards handed to it by mistake fail loudly instead of being silently reshaped"""
+    from othellozero_amd.trainer import pack_examples
+    n = 6
+    rs = np.random.RandomState(2)
+    boards = rs.randint(-1, 2, size=(5, n, n)).astype(np.int64)
+    ex = [(b, np.eye(n * n)[i].reshape(n, n), 1 if i % 2 else -1) for i, b in enumerate(boards)]
+    own, opp, pi, z = pack_examples(ex, n, in_channels=1)
+    for i, b in enumerate(boards):
+        o = sum(1 << (r * 8 + c) for r in range(n) for c in range(n) if b[r, c] == 1)
+        p = sum(1 << (r * 8 + c) for r in range(n) for c in range(n) if b[r, c] == -1)
+        assert (int(own[i]), int(opp[i])) == (o, p)
+    assert pi.shape == (5, n * n) and np.array_equal(pi.argmax(axis=1), np.arange(5)) and list(z) == [-1, 1, -1, 1, -1]
+    two = [(np.stack([b == 1, b == -1], axis=2), e[1], e[2]) for b, e in zip(boards, ex)]
+    with pytest.raises(ValueError):
+        pack_examples(two, n, in_channels=1)
+
+
+@pytest.mark.gpu
+def test_examples_from_records_one_channel_for_basenn():
+    """BNN examples are (n,n) +1 BLACK / -1 WHITE boards of the position AT THE MOVE (training.py:34-37: a fresh one-channel
+    array per round, never aliased to the final board), in the same 8-symmetry order as the two-channel ones"""
+    from othellozero_amd.loop import examples_from_records
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.training import selfplay_batch
+    n = 6
+    rec = selfplay_batch(StubNetWrapper((n, n), salt=3, max_batch=4), n, num_games=4, num_simulations=6, seed=5)
+    ex1 = examples_from_records(rec, n, alias_final=True, in_channels=1)
+    ex2 = examples_from_records(rec, n, alias_final=False, in_channels=2)
+    assert len(ex1) == len(ex2) == 8 * len(rec)
+    for (b1, p1, z1), (b2, p2, z2) in zip(ex1, ex2):
+        assert b1.shape == (n, n) and np.array_equal(b1, b2[:, :, 0].astype(np.int64) - b2[:, :, 1].astype(np.int64))
+        assert np.array_equal(p1, p2) and z1 == z2
+    assert np.abs(ex1[7][0]).sum() == 4             # first position of game 0: four discs, not the final board
+
+
+@pytest.mark.gpu
+def test_training_loop_basenn_iteration(tmp_path, monkeypatch):
+    """one iteration of the loop with NNetWrapper(network=BNN): one-channel examples reach NNetWrapper.train (ADVICE r1:
+    this used to raise ValueError in pack_examples), the network changes and stays finite"""
+    from othellozero_amd.loop import training
+    from othellozero_amd.NNet import NNetWrapper, NeuralNets
+    monkeypatch.chdir(tmp_path)
+    random.seed(4)
+    np.random.seed(4)
+    n = 6
+    net = NNetWrapper((n, n), num_channels_1=128, batch_size=32, epochs=1, max_batch=8, network=NeuralNets.BNN)
+    w0 = net.get_weights()
+    historic = training(board_size=n, num_iterations=1, num_episodes=6, num_simulations=6, degree_exploration=1, temperature=1,
+                        neural_network=net, e_greedy=0.9, evaluation_interval=1, evaluation_iterations=2, temperature_threshold=0,
+                        self_play_training=False, self_play_interval=1, self_play_total_games=2, self_play_threshold=1,
+                        checkpoint_filepath=str(tmp_path / "bnn.h5"), training_buffer_size=8 * 40, seed=12, batched_evaluation=True)
+    assert len(historic) == 1
+    w1 = net.get_weights()                            # `net` is trained in place whatever the promotion rules then decide
+    assert w1[0].shape == (3, 3, 1, 128) and all(np.isfinite(a).all() for a in w1)
+    assert any(not np.array_equal(a, b) for a, b in zip(w0, w1))          # the optimiser steps happened
+
+
 @pytest.mark.gpu
 def test_training_loop_end_to_end(tmp_path, monkeypatch):
     """two iterations of main.training()'s structure on the GPU engines: episodes -> ring buffer -> shuffle -> fit ->
