@@ -174,12 +174,11 @@ def cpu_baseline(n, channels, sims, budget_s=12.0):
     }
 
 
-def cpu_baseline_config(n, channels, sims, budget_s):
+def cpu_baseline_config(n, channels, sims, budget_s, threads):
     """the same port on another config (configs 1, 2 and 4): whole sequential games within budget_s"""
     import oracle
     from othellozero_amd.weights import init_weights
     w = init_weights(n, seed=0, channels=channels)
-    threads = min(oracle.lib().orc_nn_max_threads(), 16)
     net = oracle.CNet(w, n, channels=channels, nthreads=threads)
     t, exp, plies, games = 0.0, 0, 0, 0
     while t < budget_s and games < 64:
@@ -600,7 +599,7 @@ def main():
             t_sec = time.perf_counter()
             out["cpu_baseline"] = cpu_baseline(n, args.channels, args.sims)
             if secondary and n == 8:
-                out["config4"]["cpu_baseline"] = cpu_baseline_config(6, args.channels, args.sims, 5.0)
+                out["config4"]["cpu_baseline"] = cpu_baseline_config(6, args.channels, args.sims, 5.0, out["cpu_baseline"]["cores"])
             wall["cpu_baseline_s"] = round(time.perf_counter() - t_sec, 2)
         print(json.dumps(out), flush=True)
     if world > 1:
