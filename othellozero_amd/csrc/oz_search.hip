@@ -27,24 +27,42 @@ enum { VT_INT = 0, VT_F32 = 1, VT_F64 = 2 };
 #define OZ_TAG_F32 0x80000000u
 #define OZ_NSTAT 5
 enum { ST_SIMS = 0, ST_VISITS = 1, ST_EXPAND = 2, ST_TERMINAL = 3, ST_FALLBACK = 4 };
-enum { EF_NODES = 1, EF_EDGES = 2, EF_DEPTH = 4, EF_NOMOVE = 8, EF_RECORDS = 16, EF_ROOT = 32 };
+enum { EF_NODES = 1, EF_EDGES = 2, EF_DEPTH = 4, EF_NOMOVE = 8, EF_RECORDS = 16, EF_ROOT = 32, EF_CORRUPT = 64 };
+
+// ---------------------------------------------------------------- tree storage (per game: one OthelloMCTS instance)
+// One fixed-stride RECORD per node, addressed by the node index alone:
+//     [ header 32 B: own u64 | opp u64 | Ns i32 | cnt i32 | pad ][ cnt edges x 24 B: N|tag u32, child i32, Q f64, P f64 ]
+// edges in ascending square order of the legal set (rank = popcount of the legal bits below the square).  rec_bytes is a
+// multiple of 64 and at most 1024, so ONE wave-wide 16-byte load (a lane per chunk) brings a whole node -- header and its
+// visit / Q / P table -- into LDS in a single memory round trip, from where every lane (= board square) picks its edge.
+// `child` caches the record index of the state the edge leads to (-1 = not expanded yet), so a descent follows indices and
+// probes the hash table only where it leaves the known tree (the leaf) -- not at every level.  The record stride trades HBM
+// capacity (22.6 GB of 288 for 4096 games x 6164 nodes; only the touched 64-byte sectors ever move) for one dependent
+// memory round trip per tree level instead of four (table window, key compare, node header, edge rows).
+// Hash table: 32-bit entries [tag 12 | index+1 20], 0 = empty; a 64-wide window is one 256-byte read and only tag matches
+// (1 in 4096 false positives) go on to compare the 128-bit key in the record header.
+struct OzEdge { uint32_t n_tag; int32_t child; double q; double p; };
+#define OZ_REC_HDR 32
+#define OZ_EDGE_BYTES 24
+#define OZ_HT_IDX_BITS 20
+#define OZ_HT_IDX_MASK ((1u << OZ_HT_IDX_BITS) - 1u)
+static_assert(sizeof(OzEdge) == OZ_EDGE_BYTES, "edge layout");
 
 struct MctsDev {
-    int G, n, n2, node_cap, edge_cap, ht_cap;
+    int G, n, n2, node_cap, row_cap, rec_bytes, ht_cap;
     uint64_t valid;
     double c;
     int qmode;
-    uint64_t *node_own, *node_opp, *node_legal;
-    int *node_Ns, *node_ebase, *node_count, *edge_count;
-    uint32_t* edge_N;          // visit count | OZ_TAG_F32 when Q is float32-typed
-    double *edge_Q, *edge_P;
-    int* ht;
+    unsigned char* recs;       // [G][node_cap][rec_bytes]
+    int* node_count;           // [G]
+    uint32_t* ht;              // [G][ht_cap]
+    int* root_node;            // [G] record index of the current root (-1: not looked up yet / not expanded)
     uint64_t *root_own, *root_opp;
     uint8_t* active;
     int* leaf_status;
     uint64_t *leaf_own, *leaf_opp, *leaf_legal;
-    int *depth, *term_value, *leaf_slot;
-    int2* path;                // [G][OZ_MAX_DEPTH] (node, edge)
+    int *depth, *term_value, *leaf_slot, *leaf_fs;
+    int2* path;                // [G][OZ_MAX_DEPTH] (node index, edge rank)
     uint64_t *batch_own, *batch_opp;
     int* batch_count;
     float *pi, *v;
@@ -54,6 +72,23 @@ struct MctsDev {
     int* error_flag;
     unsigned long long* eval_leaves;    // positions handed to the network so far (after cross-game de-duplication)
     int dedup;                 // k_compact: evaluate a board reached by several games in the same step once
+};
+
+__device__ __forceinline__ unsigned char* rec_ptr(const MctsDev& t, int g, int node) {
+    return t.recs + ((size_t)g * t.node_cap + (size_t)node) * (size_t)t.rec_bytes;
+}
+__device__ __forceinline__ OzEdge* rec_edge(const MctsDev& t, int g, int node, int rank) {
+    return reinterpret_cast<OzEdge*>(rec_ptr(t, g, node) + OZ_REC_HDR) + rank;
+}
+__device__ __forceinline__ int* rec_Ns(const MctsDev& t, int g, int node) {
+    return reinterpret_cast<int*>(rec_ptr(t, g, node) + 16);
+}
+
+// per-wavefront LDS working set of the tree kernels (one wave = one game = one block of 64)
+struct TreeLds {
+    uint4 rec[64];             // the staged node record: header + visit / Q / P rows (<= 1024 B)
+    int2 path[OZ_MAX_DEPTH];   // the frontier of this descent: (node, edge rank) per level
+    double arr[64];            // expand: masked policy row for the pairwise sum
 };
 
 // ---------------------------------------------------------------- wave helpers (wave = 64 lanes)
@@ -73,25 +108,51 @@ __device__ __forceinline__ int wave_max_i32(int x) {
     }
     return x;
 }
+// Wave-uniform values (the position a wave stands on, node indices, the chosen square) belong in SGPRs: the bitboard
+// arithmetic of the rules (legal set, flips: ~300 64-bit shift / and / or per tree level) then runs on the scalar unit --
+// one instruction per 64-bit op per WAVE instead of two vector instructions per op per 16 lanes.  Loads through a pointer
+// come back in vector registers, so the uniformity has to be stated.
+// (the builtin returns a signed int: every half is cast to uint32_t before it is widened)
+__device__ __forceinline__ uint32_t uni32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ int unii(int x) { return (int)__builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint64_t uni64(uint64_t x) {
+    const uint32_t lo = uni32((uint32_t)x), hi = uni32((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+__device__ __forceinline__ int lane_get(int x, int lane) { return (int)__builtin_amdgcn_readlane(x, lane); }   // lane must be uniform
 
-__device__ __forceinline__ uint32_t key_hash(uint64_t own, uint64_t opp) {
-    return (uint32_t)(oz_sm64(own * 0x2545F4914F6CDD1DULL ^ oz_sm64(opp)) >> 17);
+// one wave = one game: stores of one lane must have completed (and may not be reordered by the compiler) before the
+// other lanes load the same locations in the next phase
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint64_t key_hash64(uint64_t own, uint64_t opp) {
+    return oz_sm64(own * 0x2545F4914F6CDD1DULL ^ oz_sm64(opp));
 }
 
 // 64-wide linear probe.  Returns the node index or -1; *free_slot = first empty slot of the probe
 // sequence (where an insert must go).  All lanes get the same results.
-__device__ int ht_find(const int* __restrict__ ht, int cap, const uint64_t* __restrict__ nown,
-                       const uint64_t* __restrict__ nopp, uint64_t own, uint64_t opp, int lane, int* free_slot) {
-    const int mask = cap - 1;
-    int base = (int)(key_hash(own, opp) & (uint32_t)mask);
+__device__ int ht_find(const MctsDev& t, int g, uint64_t own, uint64_t opp, int lane, int* free_slot) {
+    const uint32_t* __restrict__ ht = t.ht + (size_t)g * t.ht_cap;
+    const int cap = t.ht_cap, mask = cap - 1;
+    const uint64_t hh = key_hash64(own, opp);
+    int base = (int)((uint32_t)(hh >> 17) & (uint32_t)mask);
+    const uint32_t tag = (uint32_t)(hh >> 52);
     for (int probed = 0; probed < cap; probed += 64, base = (base + 64) & mask) {
-        const int idx = ht[(base + lane) & mask];
-        const bool empty = idx < 0;
-        const bool match = !empty && nown[idx] == own && nopp[idx] == opp;
+        const uint32_t e = ht[(base + lane) & mask];
+        const bool empty = e == 0;
+        const int idx = (int)(e & OZ_HT_IDX_MASK) - 1;
+        bool match = false;
+        if (!empty && (e >> OZ_HT_IDX_BITS) == tag && idx < t.node_cap) {
+            const uint64_t* h = reinterpret_cast<const uint64_t*>(rec_ptr(t, g, idx));
+            match = h[0] == own && h[1] == opp;
+        }
         const uint64_t mb = __ballot(match), eb = __ballot(empty);
         if (mb) {
             const int ml = oz_ctz(mb);
-            if (!eb || ml < oz_ctz(eb)) return __shfl(idx, ml, 64);
+            if (!eb || ml < oz_ctz(eb)) return lane_get(idx, ml);
         }
         if (eb) {
             *free_slot = (base + oz_ctz(eb)) & mask;
@@ -100,6 +161,9 @@ __device__ int ht_find(const int* __restrict__ ht, int cap, const uint64_t* __re
     }
     *free_slot = -1;
     return -1;
+}
+__device__ __forceinline__ uint32_t ht_entry(uint64_t own, uint64_t opp, int node) {
+    return ((uint32_t)(key_hash64(own, opp) >> 52) << OZ_HT_IDX_BITS) | (uint32_t)(node + 1);
 }
 
 // NumPy pairwise sum of a contiguous float64 vector, 8 <= len <= 128 (np.sum at MCTS/__init__.py:49-51)
@@ -117,18 +181,17 @@ __device__ double pairwise_sum(const double* a, int len) {
 
 // ---------------------------------------------------------------- K4: select / descend
 // MCTS.simulate down to the first terminal or unexpanded state (MCTS/__init__.py:39-44,58-67),
-// get_next_state (othelo_mcts.py:43-49).  One wave per game.
+// get_next_state (othelo_mcts.py:43-49).  One wave per game; per level ONE wave-wide load stages the node's record in LDS.
 // (body shared by k_select and the free-running k_advance; returns the status it stored in leaf_status[g])
-__device__ __forceinline__ int select_body(const MctsDev& t, int g, int lane) {
+__device__ __forceinline__ int select_body(const MctsDev& t, TreeLds& L, int g, int lane) {
     if (!t.active[g]) {
         if (lane == 0) t.leaf_status[g] = OZ_LEAF_IDLE;
         return OZ_LEAF_IDLE;
     }
-    uint64_t own = t.root_own[g], opp = t.root_opp[g];
-    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
-    const int* ht = t.ht + (size_t)g * t.ht_cap;
-    int2* path = t.path + (size_t)g * OZ_MAX_DEPTH;
-    int depth = 0, status, tval = 0, err = 0;
+    uint64_t own = uni64(t.root_own[g]), opp = uni64(t.root_opp[g]);
+    int depth = 0, status, tval = 0, err = 0, fs = -1;
+    int node = unii(t.root_node[g]);                            // record index of the state we stand on, -1 = unknown
+    int pnode = -1, prank = 0;                                  // the edge we arrived through (to cache the child index)
     uint64_t legal;
     for (;;) {
         legal = oz_legal(own, opp, t.valid);
@@ -138,33 +201,52 @@ __device__ __forceinline__ int select_body(const MctsDev& t, int g, int lane) {
             status = OZ_LEAF_TERMINAL;
             break;
         }
-        int fs;
-        const int node = ht_find(ht, t.ht_cap, t.node_own + nb, t.node_opp + nb, own, opp, lane, &fs);
-        if (node < 0) { status = OZ_LEAF_EVAL; break; }
+        if (node < 0) {                                             // leaving the known tree: is the state in the table (transposition)?
+            node = ht_find(t, g, own, opp, lane, &fs);
+            if (node < 0) { status = OZ_LEAF_EVAL; break; }
+            if (lane == 0) {
+                if (pnode >= 0) rec_edge(t, g, pnode, prank)->child = node;
+                else t.root_node[g] = node;
+            }
+        }
         if (legal == 0) { err = EF_NOMOVE; status = OZ_LEAF_IDLE; break; }   // reference: max() of empty list
         if (depth >= OZ_MAX_DEPTH) { err = EF_DEPTH; status = OZ_LEAF_IDLE; break; }
-        const int Ns = t.node_Ns[nb + node], ebase = t.node_ebase[nb + node];
+        if (node >= t.node_cap) { err = EF_CORRUPT; status = OZ_LEAF_IDLE; break; }   // never dereference an index outside the pool
+        // stage the record: header + cnt edges, 16 bytes per lane
+        const int cnt = oz_popc(legal);
+        const int chunks = (OZ_REC_HDR + cnt * OZ_EDGE_BYTES + 15) >> 4;
+        __syncthreads();                                            // the previous level's LDS reads are done
+        if (lane < chunks) L.rec[lane] = reinterpret_cast<const uint4*>(rec_ptr(t, g, node))[lane];
+        __syncthreads();
+        const uint64_t* w = reinterpret_cast<const uint64_t*>(L.rec);
+        const int Ns = unii((int)(uint32_t)w[2]);
         const bool is_legal = (legal >> lane) & 1;
         const int rank = oz_popc(legal & ((1ULL << lane) - 1ULL));
         double U = -INFINITY;
+        int child = -1;
         if (is_legal) {
-            const size_t e = eb + ebase + rank;
-            const int N = (int)(t.edge_N[e] & ~OZ_TAG_F32);
-            const double Q = t.edge_Q[e], P = t.edge_P[e];
+            const uint64_t w0 = w[4 + 3 * rank];
+            const int N = (int)((uint32_t)w0 & ~OZ_TAG_F32);
+            child = (int)(w0 >> 32);
+            const double Q = __longlong_as_double((long long)w[5 + 3 * rank]), P = __longlong_as_double((long long)w[6 + 3 * rank]);
             const double bound = sqrt((double)Ns) / (double)(1 + N);       // MCTS/__init__.py:169
             U = Q + (t.c * P) * bound;                                     // :170, left to right
         }
         const double m = wave_max_f64(U);
         const int best = oz_ctz(__ballot(is_legal && U == m));             // first maximum
         const int brank = oz_popc(legal & ((1ULL << best) - 1ULL));
-        if (lane == 0) path[depth] = make_int2(node, ebase + brank);
+        if (lane == 0) L.path[depth] = make_int2(node, brank);
         ++depth;
+        pnode = node; prank = brank;
+        node = lane_get(child, best);
         oz_apply(own, opp, best);
         if (oz_legal(opp, own, t.valid) != 0) { uint64_t s = own; own = opp; opp = s; }   // swap only if the opponent can move
     }
+    __syncthreads();
+    if (lane < depth) t.path[(size_t)g * OZ_MAX_DEPTH + lane] = L.path[lane];            // the frontier, one coalesced store
     if (lane == 0) {
         t.leaf_status[g] = status;
-        t.leaf_own[g] = own; t.leaf_opp[g] = opp; t.leaf_legal[g] = legal;
+        t.leaf_own[g] = own; t.leaf_opp[g] = opp; t.leaf_legal[g] = legal; t.leaf_fs[g] = fs;
         t.depth[g] = depth; t.term_value[g] = tval;
         unsigned long long* st = t.stat + (size_t)g * OZ_NSTAT;
         st[ST_SIMS] += 1; st[ST_VISITS] += (unsigned long long)(depth + 1);
@@ -173,7 +255,10 @@ __device__ __forceinline__ int select_body(const MctsDev& t, int g, int lane) {
     }
     return status;
 }
-__global__ __launch_bounds__(64) void k_select(MctsDev t) { select_body(t, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void k_select(MctsDev t) {
+    __shared__ TreeLds L;
+    select_body(t, L, blockIdx.x, threadIdx.x);
+}
 
 // ---------------------------------------------------------------- K13: leaf compaction
 // ballot + prefix sum over the games; slot order = game order (deterministic).
@@ -256,11 +341,11 @@ __global__ __launch_bounds__(1024) void k_compact(MctsDev t) {
 }
 
 // ---------------------------------------------------------------- K5 + K6: expand and backup
-__device__ __forceinline__ void q_update(const MctsDev& t, size_t e, double val, int vt) {
-    const uint32_t nt = t.edge_N[e];
+__device__ __forceinline__ void q_update(const MctsDev& t, OzEdge* e, double val, int vt) {
+    const uint32_t nt = e->n_tag;
     const int N = (int)(nt & ~OZ_TAG_F32);
     const bool q32 = (nt & OZ_TAG_F32) != 0;
-    const double Q = t.edge_Q[e];
+    const double Q = e->q;
     uint32_t tag = 0;
     double q;
     if (t.qmode == OZ_QMODE_F64 || (!q32 && vt != VT_F32)) {
@@ -271,19 +356,21 @@ __device__ __forceinline__ void q_update(const MctsDev& t, size_t e, double val,
         q = (double)(s / (float)(N + 1));
         tag = OZ_TAG_F32;
     }
-    t.edge_Q[e] = q;
-    t.edge_N[e] = (uint32_t)(N + 1) | tag;
+    e->q = q;
+    e->n_tag = (uint32_t)(N + 1) | tag;
 }
 
-// backup (MCTS/__init__.py:68-71): the level-d caller sees the leaf value negated (depth-1-d) times
+// backup (MCTS/__init__.py:68-71): the level-d caller sees the leaf value negated (depth-1-d) times; all levels in
+// parallel, one lane per level (a path never visits a node twice: every move adds a disc)
 __device__ __forceinline__ void backup_body(const MctsDev& t, int g, int lane, double value, int vt) {
-    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
     const int depth = t.depth[g];
     if (lane < depth) {
         const int2 pe = t.path[(size_t)g * OZ_MAX_DEPTH + lane];
         const double val = ((depth - 1 - lane) & 1) ? -value : value;
-        q_update(t, eb + pe.y, val, vt);
-        t.node_Ns[nb + pe.x] += 1;
+        if ((unsigned)pe.x < (unsigned)t.node_cap && (unsigned)pe.y < (unsigned)t.row_cap) {
+            q_update(t, rec_edge(t, g, pe.x, pe.y), val, vt);
+            *rec_Ns(t, g, pe.x) += 1;
+        } else atomicOr(t.error_flag, EF_CORRUPT);
     }
     if (lane == 0) {
         t.last_value[g] = (depth & 1) ? -value : value;
@@ -292,49 +379,56 @@ __device__ __forceinline__ void backup_body(const MctsDev& t, int g, int lane, d
 }
 
 // slot_is_game != 0: pi / v are indexed by game (host evaluator path); else by compacted slot.
-__global__ __launch_bounds__(64) void k_expand_backup(MctsDev t, int slot_is_game) {
-    __shared__ double arr[64];
-    const int g = blockIdx.x, lane = threadIdx.x;
-    const int status = t.leaf_status[g];
+__device__ __forceinline__ void expand_backup_body(const MctsDev& t, TreeLds& L, int g, int lane, int slot_is_game) {
+    const int status = unii(t.leaf_status[g]);
     if (status == OZ_LEAF_IDLE) return;
-    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
     double value;
     int vt;
     if (status == OZ_LEAF_EVAL) {
         // first visit (MCTS/__init__.py:44-57): P = pi * mask, normalised; uniform over legal if the sum is 0
-        const uint64_t own = t.leaf_own[g], opp = t.leaf_opp[g], legal = t.leaf_legal[g];
-        const int slot = slot_is_game ? g : t.leaf_slot[g];
+        const uint64_t own = uni64(t.leaf_own[g]), opp = uni64(t.leaf_opp[g]), legal = uni64(t.leaf_legal[g]);
+        const int slot = slot_is_game ? g : unii(t.leaf_slot[g]);
         const int r = lane >> 3, c = lane & 7, n = t.n;
         const bool inb = r < n && c < n, is_legal = (legal >> lane) & 1;
         const int a = r * n + c;
         double p = is_legal ? (double)t.pi[(size_t)slot * t.n2 + a] : 0.0;     // float32 * float64 mask
-        if (inb) arr[a] = p;
+        if (inb) L.arr[a] = p;
         __syncthreads();
-        const double sum = pairwise_sum(arr, t.n2);
+        const double sum = pairwise_sum(L.arr, t.n2);
         const int cnt = oz_popc(legal);
         if (sum > 0) p = p / sum;
         else p = is_legal ? 1.0 / (double)cnt : 0.0;                           // mask / np.sum(mask)
-        const int node = t.node_count[g], ebase = t.edge_count[g];
-        const bool ok = node < t.node_cap && ebase + cnt <= t.edge_cap;
+        const int node = unii(t.node_count[g]), fs = unii(t.leaf_fs[g]), depth = unii(t.depth[g]);
+        const bool ok = node < t.node_cap && cnt <= t.row_cap && fs >= 0;
         if (ok) {
-            int fs;
-            ht_find(t.ht + (size_t)g * t.ht_cap, t.ht_cap, t.node_own + nb, t.node_opp + nb, own, opp, lane, &fs);
+            // build the record in LDS (header + one edge per legal square, N = 0, Q = 0, child unknown), store it with one
+            // wave-wide 16-byte store, link it into the table and into the edge we came through
+            uint64_t* w = reinterpret_cast<uint64_t*>(L.rec);
+            if (lane == 0) { w[0] = own; w[1] = opp; w[2] = (uint64_t)(uint32_t)cnt << 32; w[3] = 0; }
             if (is_legal) {
-                const size_t e = eb + ebase + oz_popc(legal & ((1ULL << lane) - 1ULL));
-                t.edge_N[e] = 0; t.edge_Q[e] = 0.0; t.edge_P[e] = p;
+                const int rank = oz_popc(legal & ((1ULL << lane) - 1ULL));
+                w[4 + 3 * rank] = 0xFFFFFFFF00000000ULL;                       // N|tag = 0, child = -1
+                w[5 + 3 * rank] = 0;                                           // Q = 0.0
+                w[6 + 3 * rank] = (uint64_t)__double_as_longlong(p);
             }
+            if (lane == 63 && (cnt * 3) % 2) w[4 + 3 * cnt] = 0;               // the last 16-byte chunk is half used: no stale bytes
+            __syncthreads();
+            const int chunks = (OZ_REC_HDR + cnt * OZ_EDGE_BYTES + 15) >> 4;
+            if (lane < chunks) reinterpret_cast<uint4*>(rec_ptr(t, g, node))[lane] = L.rec[lane];
             if (lane == 0) {
-                t.node_own[nb + node] = own; t.node_opp[nb + node] = opp; t.node_legal[nb + node] = legal;
-                t.node_Ns[nb + node] = 0; t.node_ebase[nb + node] = ebase;
-                t.node_count[g] = node + 1; t.edge_count[g] = ebase + cnt;
-                t.ht[(size_t)g * t.ht_cap + fs] = node;
+                t.node_count[g] = node + 1;
+                t.ht[(size_t)g * t.ht_cap + fs] = ht_entry(own, opp, node);
+                if (depth > 0) {
+                    const int2 pe = t.path[(size_t)g * OZ_MAX_DEPTH + depth - 1];
+                    rec_edge(t, g, pe.x, pe.y)->child = node;
+                } else t.root_node[g] = node;
             }
         }
         if (lane == 0) {
             unsigned long long* st = t.stat + (size_t)g * OZ_NSTAT;
             st[ST_EXPAND] += 1;
             if (!(sum > 0)) st[ST_FALLBACK] += 1;
-            if (!ok) atomicOr(t.error_flag, node >= t.node_cap ? EF_NODES : EF_EDGES);
+            if (!ok) atomicOr(t.error_flag, node >= t.node_cap || fs < 0 ? EF_NODES : EF_EDGES);
         }
         value = -(double)t.v[slot];                                            // return -v (:57)
         vt = t.qmode == OZ_QMODE_F64 ? VT_F64 : VT_F32;
@@ -343,6 +437,10 @@ __global__ __launch_bounds__(64) void k_expand_backup(MctsDev t, int slot_is_gam
         vt = VT_INT;
     }
     backup_body(t, g, lane, value, vt);
+}
+__global__ __launch_bounds__(64) void k_expand_backup(MctsDev t, int slot_is_game) {
+    __shared__ TreeLds L;
+    expand_backup_body(t, L, blockIdx.x, threadIdx.x, slot_is_game);
 }
 
 // ---------------------------------------------------------------- host object
@@ -373,38 +471,45 @@ static int mcts_reset_locked(oz_mcts* m, int game) {
     MctsDev& d = m->d;
     if (game < 0) {
         OZ_HIP(hipMemsetAsync(d.node_count, 0, sizeof(int) * d.G, m->stream));
-        OZ_HIP(hipMemsetAsync(d.edge_count, 0, sizeof(int) * d.G, m->stream));
-        OZ_HIP(hipMemsetAsync(d.ht, 0xFF, sizeof(int) * (size_t)d.G * d.ht_cap, m->stream));
+        OZ_HIP(hipMemsetAsync(d.root_node, 0xFF, sizeof(int) * d.G, m->stream));
+        OZ_HIP(hipMemsetAsync(d.ht, 0, sizeof(uint32_t) * (size_t)d.G * d.ht_cap, m->stream));
     } else {
         OZ_REQUIRE(game < d.G, "game index %d out of range", game);
         OZ_HIP(hipMemsetAsync(d.node_count + game, 0, sizeof(int), m->stream));
-        OZ_HIP(hipMemsetAsync(d.edge_count + game, 0, sizeof(int), m->stream));
-        OZ_HIP(hipMemsetAsync(d.ht + (size_t)game * d.ht_cap, 0xFF, sizeof(int) * (size_t)d.ht_cap, m->stream));
+        OZ_HIP(hipMemsetAsync(d.root_node + game, 0xFF, sizeof(int), m->stream));
+        OZ_HIP(hipMemsetAsync(d.ht + (size_t)game * d.ht_cap, 0, sizeof(uint32_t) * (size_t)d.ht_cap, m->stream));
     }
     return OZ_OK;
 }
 
+// row capacity of a node record: the largest legal-move count the board can show (n*n - 4 empty squares at most), capped
+// so that a record fits one wave-wide 16-byte load (1024 B = header + 41 edges; 33 is the known maximum mobility of 8x8
+// Othello positions).  A position with more legal moves raises OZ_ERR_CAPACITY, never a silent truncation.
+static int row_cap_for(int n) { const int e = n * n - 4; return e < 41 ? e : 41; }
+
 static int mcts_create(oz_mcts** out, int n, int G, int node_cap, int edge_cap, double c, int q_mode) {
     OZ_REQUIRE(n == 4 || n == 6 || n == 8, "board size must be 4, 6 or 8 (got %d)", n);
-    OZ_REQUIRE(G > 0 && node_cap > 0 && edge_cap > 0, "num_games, node_cap and edge_cap must be positive");
+    OZ_REQUIRE(G > 0 && node_cap > 0, "num_games and node_cap must be positive");
+    OZ_REQUIRE(node_cap < (int)OZ_HT_IDX_MASK, "node_cap %d too large (max %u)", node_cap, OZ_HT_IDX_MASK - 1);
     OZ_REQUIRE(q_mode == OZ_QMODE_NEP50 || q_mode == OZ_QMODE_F64, "unknown q_mode %d", q_mode);
+    (void)edge_cap;      // kept in the ABI: edges live inside the fixed-stride node records now, there is no separate edge pool
     oz_mcts* m = new oz_mcts();
     m->device = oz_current_device();
     MctsDev& d = m->d;
     memset(&d, 0, sizeof d);
-    d.G = G; d.n = n; d.n2 = n * n; d.node_cap = node_cap; d.edge_cap = edge_cap;
+    d.G = G; d.n = n; d.n2 = n * n; d.node_cap = node_cap;
+    d.row_cap = row_cap_for(n);
+    d.rec_bytes = (OZ_REC_HDR + d.row_cap * OZ_EDGE_BYTES + 63) & ~63;
     d.ht_cap = next_pow2(2 * node_cap);
     d.valid = oz_valid_mask(n); d.c = c; d.qmode = q_mode;
-    const size_t GN = (size_t)G * node_cap, GE = (size_t)G * edge_cap;
     int rc = OZ_OK;
 #define A(ptr, cnt) if (!rc) rc = m->alloc(&d.ptr, cnt)
-    A(node_own, GN); A(node_opp, GN); A(node_legal, GN); A(node_Ns, GN); A(node_ebase, GN);
-    A(node_count, G); A(edge_count, G);
-    A(edge_N, GE); A(edge_Q, GE); A(edge_P, GE);
+    A(recs, (size_t)G * node_cap * d.rec_bytes);
+    A(node_count, G); A(root_node, G);
     A(ht, (size_t)G * d.ht_cap);
     A(root_own, G); A(root_opp, G); A(active, G);
     A(leaf_status, G); A(leaf_own, G); A(leaf_opp, G); A(leaf_legal, G);
-    A(depth, G); A(term_value, G); A(leaf_slot, G); A(path, (size_t)G * OZ_MAX_DEPTH);
+    A(depth, G); A(term_value, G); A(leaf_slot, G); A(leaf_fs, G); A(path, (size_t)G * OZ_MAX_DEPTH);
     A(batch_own, G); A(batch_opp, G); A(batch_count, 1);
     A(pi, (size_t)G * d.n2); A(v, G);
     A(last_value, G); A(last_vtype, G);
@@ -453,14 +558,15 @@ static int check_error_flag(oz_mcts* m) {
     OZ_HIP(hipMemcpyAsync(&ef, m->d.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     OZ_HIP(hipStreamSynchronize(m->stream));
     if (ef & (EF_NODES | EF_EDGES)) {
-        oz_set_error("per-game %s table overflow (node_cap=%d edge_cap=%d): raise the capacity",
-                     (ef & EF_NODES) ? "node" : "edge", m->d.node_cap, m->d.edge_cap);
+        if (ef & EF_NODES) oz_set_error("per-game node table overflow (node_cap=%d): raise the capacity", m->d.node_cap);
+        else oz_set_error("a position has more than %d legal moves (the row capacity of a node record)", m->d.row_cap);
         return OZ_ERR_CAPACITY;
     }
     if (ef & EF_RECORDS) { oz_set_error("move-record buffer overflow: raise record_cap or drain records more often"); return OZ_ERR_CAPACITY; }
     if (ef & EF_DEPTH) { oz_set_error("search path deeper than %d", OZ_MAX_DEPTH); return OZ_ERR_CAPACITY; }
     if (ef & EF_NOMOVE) { oz_set_error("a revisited state has no legal action (the reference raises ValueError: max() arg is an empty sequence)"); return OZ_ERR_STATE; }
     if (ef & EF_ROOT) { oz_set_error("root state missing from the search table after the simulations"); return OZ_ERR_KEY; }
+    if (ef & EF_CORRUPT) { oz_set_error("search table corrupt: a node index outside the pool was met (internal error)"); return OZ_ERR_STATE; }
     return OZ_OK;
 }
 
@@ -518,6 +624,7 @@ OZ_API int oz_mcts_set_roots(oz_mcts* m, const uint64_t* own, const uint64_t* op
     OZ_HIP(hipMemcpyAsync(m->d.root_opp, opp, 8ull * G, hipMemcpyHostToDevice, m->stream));
     if (active) OZ_HIP(hipMemcpyAsync(m->d.active, active, G, hipMemcpyHostToDevice, m->stream));
     else OZ_HIP(hipMemsetAsync(m->d.active, 1, G, m->stream));
+    OZ_HIP(hipMemsetAsync(m->d.root_node, 0xFF, sizeof(int) * G, m->stream));       // new roots: look them up again
     OZ_HIP(hipStreamSynchronize(m->stream));
     m->selected = false;
     return OZ_OK;
@@ -586,18 +693,22 @@ OZ_API int oz_mcts_last_value(oz_mcts* m, double* value, int32_t* vtype, int32_t
 }
 
 // N(state, action) for the root of every slot (MCTS/__init__.py:73-84,172-175)
+// record index of the root of slot g (cached by the descent, else looked up); -1 = not in the table
+__device__ __forceinline__ int root_lookup(const MctsDev& t, int g, uint64_t own, uint64_t opp, int lane) {
+    int node = unii(t.root_node[g]);
+    if (node < 0) { int fs; node = ht_find(t, g, own, opp, lane, &fs); }
+    return node;
+}
 __global__ __launch_bounds__(64) void k_root_counts(MctsDev t, int32_t* counts, uint64_t* legal_out, int32_t* rc_out) {
     const int g = blockIdx.x, lane = threadIdx.x;
-    const uint64_t own = t.root_own[g], opp = t.root_opp[g];
-    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    const uint64_t own = uni64(t.root_own[g]), opp = uni64(t.root_opp[g]);
     const uint64_t legal = oz_legal(own, opp, t.valid);
-    int fs;
-    const int node = ht_find(t.ht + (size_t)g * t.ht_cap, t.ht_cap, t.node_own + nb, t.node_opp + nb, own, opp, lane, &fs);
+    const int node = root_lookup(t, g, own, opp, lane);
     int cnt = 0, rc = 0;
     if (node < 0) rc = 1;
-    else if (t.node_Ns[nb + node] == 0) rc = 2;          // _Nsa[hash] still empty -> KeyError in the reference
+    else if (*rec_Ns(t, g, node) == 0) rc = 2;          // _Nsa[hash] still empty -> KeyError in the reference
     else if ((legal >> lane) & 1)
-        cnt = (int)(t.edge_N[eb + t.node_ebase[nb + node] + oz_popc(legal & ((1ULL << lane) - 1ULL))] & ~OZ_TAG_F32);
+        cnt = (int)(rec_edge(t, g, node, oz_popc(legal & ((1ULL << lane) - 1ULL)))->n_tag & ~OZ_TAG_F32);
     counts[(size_t)g * 64 + lane] = cnt;
     if (lane == 0) { legal_out[g] = legal; rc_out[g] = rc; }
 }
@@ -636,23 +747,17 @@ OZ_API int oz_mcts_dump_node(oz_mcts* m, int game, int index, uint64_t* own, uin
     int nn = 0;
     OZ_HIP(hipMemcpy(&nn, d.node_count + game, 4, hipMemcpyDeviceToHost));
     OZ_REQUIRE(index >= 0 && index < nn, "node index %d out of range (%d nodes)", index, nn);
-    const size_t ni = (size_t)game * d.node_cap + index;
-    int ebase = 0;
-    OZ_HIP(hipMemcpy(own, d.node_own + ni, 8, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(opp, d.node_opp + ni, 8, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(legal, d.node_legal + ni, 8, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(Ns, d.node_Ns + ni, 4, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(&ebase, d.node_ebase + ni, 4, hipMemcpyDeviceToHost));
-    const int cnt = __builtin_popcountll(*legal);
-    uint32_t nt[64]; double q[64], p[64];
-    const size_t e0 = (size_t)game * d.edge_cap + ebase;
-    OZ_HIP(hipMemcpy(nt, d.edge_N + e0, 4ull * cnt, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(q, d.edge_Q + e0, 8ull * cnt, hipMemcpyDeviceToHost));
-    OZ_HIP(hipMemcpy(p, d.edge_P + e0, 8ull * cnt, hipMemcpyDeviceToHost));
+    std::vector<unsigned char> rec((size_t)d.rec_bytes);
+    OZ_HIP(hipMemcpy(rec.data(), d.recs + ((size_t)game * d.node_cap + index) * (size_t)d.rec_bytes, rec.size(), hipMemcpyDeviceToHost));
+    const uint64_t* h = reinterpret_cast<const uint64_t*>(rec.data());
+    *own = h[0]; *opp = h[1];
+    *Ns = (int32_t)(uint32_t)h[2];
+    *legal = oz_legal(h[0], h[1], d.valid);                 // the legal set is a function of the key (recomputed, not stored)
+    const OzEdge* e = reinterpret_cast<const OzEdge*>(rec.data() + OZ_REC_HDR);
     for (int s = 0; s < 64; ++s) { N[s] = 0; Q[s] = 0; qtag[s] = 0; P[s] = 0; }
     int k = 0;
     for (int s = 0; s < 64; ++s)
-        if ((*legal >> s) & 1) { N[s] = (int)(nt[k] & ~OZ_TAG_F32); qtag[s] = (nt[k] & OZ_TAG_F32) ? 1 : 0; Q[s] = q[k]; P[s] = p[k]; ++k; }
+        if ((*legal >> s) & 1) { N[s] = (int)(e[k].n_tag & ~OZ_TAG_F32); qtag[s] = (e[k].n_tag & OZ_TAG_F32) ? 1 : 0; Q[s] = e[k].q; P[s] = e[k].p; ++k; }
     return OZ_OK;
 }
 
@@ -701,6 +806,7 @@ __global__ void k_sp_roots(GamesDev gm, MctsDev t, int mover_filter /* 0 all, +1
     const bool act = !gm.finished[g] && (mover_filter == 0 || mover_filter == p);
     t.active[g] = act ? 1 : 0;
     if (act) {
+        t.root_node[g] = -1;
         t.root_own[g] = p == 1 ? gm.black[g] : gm.white[g];
         t.root_opp[g] = p == 1 ? gm.white[g] : gm.black[g];
     }
@@ -715,6 +821,7 @@ __global__ void k_sp_roots_stagger(GamesDev gm, MctsDev t, int round, int period
     const bool act = !gm.finished[g] && offset > round;
     t.active[g] = act ? 1 : 0;
     if (act) {
+        t.root_node[g] = -1;
         t.root_own[g] = p == 1 ? gm.black[g] : gm.white[g];
         t.root_opp[g] = p == 1 ? gm.white[g] : gm.black[g];
     }
@@ -725,22 +832,20 @@ __global__ void k_sp_roots_stagger(GamesDev gm, MctsDev t, int round, int period
 //   arena != 0: agents.py semantics (temperature 0, argmax over valid actions of the one-hot).
 __device__ __forceinline__ void sp_move_body(const GamesDev& gm, const MctsDev& t, int g, int lane, int arena) {
     if (!t.active[g]) return;
-    const uint64_t own = t.root_own[g], opp = t.root_opp[g];
-    const size_t nb = (size_t)g * t.node_cap, eb = (size_t)g * t.edge_cap;
+    const uint64_t own = uni64(t.root_own[g]), opp = uni64(t.root_opp[g]);
     const uint64_t legal = oz_legal(own, opp, t.valid);
-    int fs;
-    const int node = ht_find(t.ht + (size_t)g * t.ht_cap, t.ht_cap, t.node_own + nb, t.node_opp + nb, own, opp, lane, &fs);
-    if (node < 0 || t.node_Ns[nb + node] == 0) {          // KeyError path of the reference (sims < 2)
+    const int node = root_lookup(t, g, own, opp, lane);
+    if (node < 0 || *rec_Ns(t, g, node) == 0) {           // KeyError path of the reference (sims < 2)
         if (lane == 0) atomicOr(t.error_flag, EF_ROOT);
         return;
     }
     const bool is_legal = (legal >> lane) & 1;
     int cnt = 0;
-    if (is_legal) cnt = (int)(t.edge_N[eb + t.node_ebase[nb + node] + oz_popc(legal & ((1ULL << lane) - 1ULL))] & ~OZ_TAG_F32);
+    if (is_legal) cnt = (int)(rec_edge(t, g, node, oz_popc(legal & ((1ULL << lane) - 1ULL)))->n_tag & ~OZ_TAG_F32);
     gm.last_counts[(size_t)g * 64 + lane] = cnt;
-    const int ply = gm.ply[g];
-    const uint64_t gid = gm.game_id[g];
-    const int mx = wave_max_i32(cnt);                      // >= 1 once the root has been selected from
+    const int ply = unii(gm.ply[g]);
+    const uint64_t gid = uni64(gm.game_id[g]);
+    const int mx = unii(wave_max_i32(cnt));                      // >= 1 once the root has been selected from
     int action, greedy = 1;
     if (arena || gm.temperature == 0.0) {
         // bests = argwhere(p == p.max()) over the whole board; random.choice(bests) -> RNG_TIE stream
@@ -758,8 +863,8 @@ __device__ __forceinline__ void sp_move_body(const GamesDev& gm, const MctsDev& 
             action = oz_kth_bit(legal, (int)(oz_rng(gm.seed, gid, (uint64_t)ply, OZ_RNG_EXPLORE) % (uint64_t)oz_popc(legal)));
         }
     }
-    uint64_t black = gm.black[g], white = gm.white[g];
-    int player = gm.player[g], fin = 0;
+    uint64_t black = uni64(gm.black[g]), white = uni64(gm.white[g]);
+    int player = unii(gm.player[g]), fin = 0;
     const size_t lb = (size_t)g * 64;
     if (lane == 0 && ply < 64) {
         gm.log_black[lb + ply] = black; gm.log_white[lb + ply] = white;
@@ -796,15 +901,16 @@ __device__ __forceinline__ void sp_move_body(const GamesDev& gm, const MctsDev& 
     if (lane == 0) atomicAdd(&gm.counters[2], 1ULL);
     if (fin && gm.refill) {
         // a fresh OthelloGame + a fresh OthelloMCTS in the same slot (training.py:30-32)
-        for (int i = lane; i < t.ht_cap; i += 64) t.ht[(size_t)g * t.ht_cap + i] = -1;
+        for (int i = lane; i < t.ht_cap; i += 64) t.ht[(size_t)g * t.ht_cap + i] = 0;
         if (lane == 0) {
-            t.node_count[g] = 0; t.edge_count[g] = 0;
+            t.node_count[g] = 0; t.root_node[g] = -1;
             gm.black[g] = gm.init_black; gm.white[g] = gm.init_white; gm.player[g] = 1;
             gm.finished[g] = 0; gm.ply[g] = 0; gm.game_id[g] = gid + gm.id_stride;
         }
     } else if (lane == 0) {
         gm.black[g] = black; gm.white[g] = white; gm.player[g] = (int8_t)player;
         gm.finished[g] = (uint8_t)fin; gm.ply[g] = nply;
+        t.root_node[g] = -1;                               // the position changed: the next descent looks its root up again
     }
 }
 __global__ __launch_bounds__(64) void k_sp_move(GamesDev gm, MctsDev t, int arena) { sp_move_body(gm, t, blockIdx.x, threadIdx.x, arena); }
@@ -821,13 +927,8 @@ __global__ __launch_bounds__(64) void k_sp_move(GamesDev gm, MctsDev t, int aren
 // games changes.  OZ_ADVANCE_CAP bounds the work of one call (late-game positions whose whole remaining tree is known
 // can run many network-free simulations); a game that hits the cap simply contributes no leaf to this batch.
 #define OZ_ADVANCE_CAP 24
-// one wave = one game: stores of one lane must have completed (and may not be reordered by the compiler) before the
-// other lanes load the same locations in the next phase of the loop
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
 __global__ __launch_bounds__(64) void k_advance(GamesDev gm, MctsDev t, int sims, int* __restrict__ sims_done) {
+    __shared__ TreeLds L;
     const int g = blockIdx.x, lane = threadIdx.x;
     int done = sims_done[g];
     if (t.leaf_status[g] == OZ_LEAF_EVAL) ++done;          // the simulation whose leaf the previous step evaluated and backed up
@@ -848,7 +949,7 @@ __global__ __launch_bounds__(64) void k_advance(GamesDev gm, MctsDev t, int sims
             wave_sync();
             continue;                                      // (a finished game is refilled by the move, or goes idle above)
         }
-        status = select_body(t, g, lane);
+        status = select_body(t, L, g, lane);
         if (status != OZ_LEAF_TERMINAL) break;             // EVAL: wait for the network; IDLE: error path
         wave_sync();
         backup_body(t, g, lane, (double)t.term_value[g], VT_INT);

@@ -1,20 +1,28 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun): the rocprofv3 passes behind profiles/ -- kernel trace + stats, then the PMC passes
-# one counter group at a time (never combined with other trace domains).  Usage: tools/profile_round.sh <precision> <tag>
+# Run ON THE GPU BOX (through gpurun): the rocprofv3 passes behind profiles/ -- kernel trace + stats of the default bench
+# command (secondary legs off), then the PMC passes, one counter group at a time (never combined with other trace domains).
+# Usage: tools/profile_round.sh <precision> <tag> [extra bench args]
 set -e
-PREC=${1:-f16x2}; TAG=${2:-r1}
+PREC=${1:-f16x2}; TAG=${2:-r2}; shift 2 || true
+EXTRA="$@"
 OUT=gpurun_out/prof_${TAG}_${PREC}
 mkdir -p $OUT
 export TMPDIR=/tmp
 run() { # name, rocprof args..., then bench args
   local name=$1; shift
-  timeout -k 10 400 rocprofv3 "$@" --output-format csv -d $OUT/$name -o run -- python3 bench.py --precision $PREC --no-cpu-baseline --no-dedup-compare $BENCH_ARGS > $OUT/$name.log 2>&1
+  timeout -k 10 500 rocprofv3 "$@" --output-format csv -d $OUT/$name -o run -- python3 bench.py --precision $PREC --no-cpu-baseline --no-compare $EXTRA $BENCH_ARGS > $OUT/$name.log 2>&1
   echo "$name done"
 }
-BENCH_ARGS="" run trace --kernel-trace --stats          # the default command: 64 move rounds = whole games
-BENCH_ARGS="--steps 1 --warmup 0" run fetch --kernel-trace --pmc FETCH_SIZE
-BENCH_ARGS="--steps 1 --warmup 0" run write --kernel-trace --pmc WRITE_SIZE
-BENCH_ARGS="--steps 1 --warmup 0" run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY
-# keep only the CSVs (the merge back is capped at 64 MiB)
+BENCH_ARGS="" run trace --kernel-trace --stats          # the default command: staggered slots, 2 warm-up + 20 timed move rounds
+# counter passes: one timed move round after a cheap stagger (every launch is serialised under --pmc)
+BENCH_ARGS="--steps 1 --warmup 0 --stagger-sims 8" run fetch --kernel-trace --pmc FETCH_SIZE
+BENCH_ARGS="--steps 1 --warmup 0 --stagger-sims 8" run write --kernel-trace --pmc WRITE_SIZE
+BENCH_ARGS="--steps 1 --warmup 0 --stagger-sims 8" run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY
+# keep only the CSVs (the merge back is capped at 64 MiB); the kernel trace of the long run is summarised on the box
+LEAVES=$(python3 -c "import json,sys; d=json.loads([l for l in open('$OUT/trace.log') if l.startswith('{')][0]); print(d['leaves_evaluated_rank0']/d['roofline']['launches'])")
+python3 tools/summarize_prof.py trace $OUT/trace $OUT/kernel_trace_by_shape.csv "round ${TAG}, precision ${PREC}: rocprofv3 --kernel-trace --stats -- python3 bench.py --precision ${PREC} --no-cpu-baseline --no-compare ${EXTRA}" $LEAVES
+python3 tools/summarize_prof.py pmc $OUT/pmc_by_shape.csv "round ${TAG}, precision ${PREC}: rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group), bench.py --steps 1 --warmup 0 --stagger-sims 8" $OUT/fetch $OUT/write $OUT/sq
+cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
+find $OUT -type f -name '*kernel_trace.csv' -size +20M -delete
 find $OUT -type f ! -name '*.csv' ! -name '*.log' -delete
-ls -la $OUT/*
+ls -la $OUT

@@ -1,11 +1,13 @@
 """Turn rocprofv3 output directories into the summaries kept under profiles/.
 
-  python tools/summarize_prof.py trace  <rocprof_dir> <out_csv>  "<header comment>"
+  python tools/summarize_prof.py trace  <rocprof_dir> <out_csv>  "<header comment>" [leaves_per_launch]
   python tools/summarize_prof.py pmc    <out_csv> "<header comment>" <rocprof_dir> [<rocprof_dir> ...]
   python tools/summarize_prof.py traffic <pmc_by_shape_csv> <out_json> <precision> <kernel substring> <grid_threads> [layer=conv2]
 
 `trace`   : per (kernel, grid) averages from *_kernel_trace.csv; the OthelloNN layers are recognised by grid size
-            (4096 leaves per launch) and get their algorithmic fp32 TFLOP/s.
+            (launched for 4096 slots) and get their algorithmic fp32 TFLOP/s for `leaves_per_launch` positions actually
+            evaluated per launch -- take it from the bench line of the same run (leaves_evaluated_rank0 / roofline.launches;
+            ~3760 in whole-game self-play, because ~8 % of the simulations end on finished boards); default 4096 = full batches.
 `pmc`     : per (kernel, grid, counter) per-launch averages from one or more *_counter_collection.csv (separate passes).
 `traffic` : conv2's HBM bytes per launch -> the json bench.py reads for roofline.traffic
             (gfx950: FETCH_SIZE is in KB and counts half of wide coalesced reads -> x2; WRITE_SIZE in KB).
@@ -36,7 +38,7 @@ def find(d, suffix):
     return hits[-1]
 
 
-def trace(d, out, header):
+def trace(d, out, header, leaves=LEAVES):
     rows = defaultdict(list)
     with open(find(d, "_kernel_trace.csv")) as f:
         for r in csv.DictReader(f):
@@ -65,14 +67,14 @@ def trace(d, out, header):
             names[k] = lay
     with open(out, "w") as f:
         f.write(f"# {header}\n")
-        f.write("# per (kernel, grid) averages from the kernel trace; 4096 leaves per launch; TFLOP_per_s = ALGORITHMIC fp32 FLOP "
+        f.write(f"# per (kernel, grid) averages from the kernel trace; {leaves:g} leaves evaluated per launch; TFLOP_per_s = ALGORITHMIC fp32 FLOP "
                 "(precision f16x2 executes 3x that on the matrix pipe)\n")
         f.write("kernel,grid_threads,wg,lds_bytes,vgpr,agpr,scratch,calls,avg_us,min_us,max_us,total_ms,layer,algorithmic_TFLOP_per_s\n")
         for k in sorted(rows, key=lambda k: -sum(rows[k])):
             t = rows[k]
             avg = sum(t) / len(t)
             lay = names.get(k, "")
-            tf = f"{FLOP[lay] * LEAVES / (avg * 1e-9) / 1e12:.1f}" if lay else ""
+            tf = f"{FLOP[lay] * leaves / (avg * 1e-9) / 1e12:.1f}" if lay else ""
             f.write(f"\"{k[0]}\",{k[1]},{k[2]},{k[3]},{k[4]},{k[5]},{k[6]},{len(t)},{avg / 1e3:.1f},{min(t) / 1e3:.1f},"
                     f"{max(t) / 1e3:.1f},{sum(t) / 1e6:.1f},{lay},{tf}\n")
 
@@ -128,7 +130,7 @@ def traffic(src, out, precision, kernel_sub, grid, layer="conv2"):
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "trace":
-        trace(sys.argv[2], sys.argv[3], sys.argv[4])
+        trace(sys.argv[2], sys.argv[3], sys.argv[4], float(sys.argv[5]) if len(sys.argv) > 5 else LEAVES)
     elif mode == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4:])
     elif mode == "traffic":
