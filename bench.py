@@ -374,6 +374,7 @@ def main():
     stagger_sims = args.sims if args.stagger_sims < 0 else args.stagger_sims
     period = n * n - 4
     net = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0, precision=args.precision)   # same weights on every rank
+    net.profile(1)          # HIP events around the dominant launch from the first launch on; the timed region is the difference of two readings
 
     def make_engine(dedup, the_net=net, board=n, games=G, steps=args.steps):
         os.environ["OZ_DEDUP"] = "1" if dedup else "0"          # read when the engine's search object is created
@@ -425,7 +426,7 @@ def main():
     eng.sync()
     if world > 1:           # warm-up of the exchange step too (communicator channels for both collectives), like the W untimed steps
         gather_records(torch.zeros((8, 48), dtype=torch.uint8, device=dev))
-    net.profile(1)
+    dom0_ms, dom0_launches = net.profile_read()
     s0 = eng.stats()
     ev0 = eng.eval_time()
     barrier()
@@ -438,7 +439,8 @@ def main():
     dt = time.perf_counter() - t0
     s1 = eng.stats()
     ev1 = eng.eval_time()
-    dom_ms, dom_launches = net.profile_read()                   # the dominant launch: conv3 (conv2 is a gather-sum), or conv2
+    dom_all_ms, dom_all_launches = net.profile_read()           # the dominant launch: conv3 (conv2 is a gather-sum), or conv2
+    dom_ms, dom_launches = dom_all_ms - dom0_ms, dom_all_launches - dom0_launches
     layer = net.profiled_layer()
     net.profile(0)
 
@@ -493,7 +495,12 @@ def main():
             "whole_net_tflops_rank0": d["leaves_evaluated"] * flop_exec / max(nn_ms * 1e-3, 1e-9) / 1e12,
             "flop_per_expansion": {"reference_network": flop_ref, "executed": flop_exec,
                                    "note": "executed < reference when conv1 + conv2 are evaluated as pattern-table lookups (exact refactoring, no GEMM)"},
-            "roofline": roofline(args.precision, layer, achieved, dom_ms, dom_launches, d["leaves_evaluated"], n, args.channels),
+            "roofline": dict(roofline(args.precision, layer, achieved, dom_ms, dom_launches, d["leaves_evaluated"], n, args.channels),
+                             all_launches={"launches": int(dom_all_launches), "avg_launch_ms": dom_all_ms / max(dom_all_launches, 1),
+                                           "leaves_per_launch": s1["leaves_evaluated"] / max(dom_all_launches, 1),
+                                           "note": "every launch of this kernel since process start, incl. the untimed stagger and warm-up rounds "
+                                                   "(partly filled batches): the population `rocprofv3 --stats` of the same command averages over; "
+                                                   "avg_launch_ms above is the timed region only"}),
             # the tree / rules side is latency-bound integer work, ~1.3 KB of algorithmic HBM bytes per simulation
             "tree_side_hbm": {"bytes_per_sim": TREE_BYTES_PER_SIM, "bytes_per_sim_source": "SURVEY.md 8(d) algorithmic estimate (not measured in this run)",
                               "achieved_GBps": sims_all / dt * TREE_BYTES_PER_SIM / 1e9, "peak_GBps": PEAK_HBM_GBPS,

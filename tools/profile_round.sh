@@ -20,9 +20,11 @@ BENCH_ARGS="--steps 1 --warmup 0 --stagger-sims 8" run write --kernel-trace --pm
 BENCH_ARGS="--steps 1 --warmup 0 --stagger-sims 8" run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY
 # keep only the CSVs (the merge back is capped at 64 MiB); the kernel trace of the long run is summarised on the box
 LEAVES=$(python3 -c "import json,sys; d=json.loads([l for l in open('$OUT/trace.log') if l.startswith('{')][0]); print(d['leaves_evaluated_rank0']/d['roofline']['launches'])")
-python3 tools/summarize_prof.py trace $OUT/trace $OUT/kernel_trace_by_shape.csv "round ${TAG}, precision ${PREC}: rocprofv3 --kernel-trace --stats -- python3 bench.py --precision ${PREC} --no-cpu-baseline --no-compare ${EXTRA}" $LEAVES
-python3 tools/summarize_prof.py pmc $OUT/pmc_by_shape.csv "round ${TAG}, precision ${PREC}: rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group), bench.py --steps 1 --warmup 0 --stagger-sims 8" $OUT/fetch $OUT/write $OUT/sq
+TIMED=$(python3 -c "import json,sys; d=json.loads([l for l in open('$OUT/trace.log') if l.startswith('{')][0]); print(d['roofline']['launches'])")
+python3 tools/summarize_prof.py trace $OUT/trace $OUT/kernel_trace_by_shape.csv "round ${TAG}, precision ${PREC}: rocprofv3 --kernel-trace --stats -- python3 bench.py --precision ${PREC} --no-cpu-baseline --no-compare ${EXTRA}" $LEAVES $TIMED
+grep -h '^{' $OUT/trace.log > $OUT/bench_line_of_the_traced_run.json
+python3 tools/summarize_prof.py pmc $OUT/pmc_by_shape.csv "round ${TAG}, precision ${PREC}: rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group), bench.py --steps 1 --warmup 0 --stagger-sims 8; per-launch averages over the 100 launches of the ONE timed move round (4096 games, full batches)" last=100 $OUT/fetch $OUT/write $OUT/sq
 cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 find $OUT -type f -name '*kernel_trace.csv' -size +20M -delete
-find $OUT -type f ! -name '*.csv' ! -name '*.log' -delete
+find $OUT -type f ! -name '*.csv' ! -name '*.log' ! -name '*.json' -delete
 ls -la $OUT

@@ -1,14 +1,20 @@
 """Turn rocprofv3 output directories into the summaries kept under profiles/.
 
-  python tools/summarize_prof.py trace  <rocprof_dir> <out_csv>  "<header comment>" [leaves_per_launch]
-  python tools/summarize_prof.py pmc    <out_csv> "<header comment>" <rocprof_dir> [<rocprof_dir> ...]
-  python tools/summarize_prof.py traffic <pmc_by_shape_csv> <out_json> <precision> <kernel substring> <grid_threads> [layer=conv2]
+  python tools/summarize_prof.py trace  <rocprof_dir> <out_csv>  "<header comment>" [leaves_per_launch] [last_n]
+  python tools/summarize_prof.py pmc    <out_csv> "<header comment>" [last=N] <rocprof_dir> [<rocprof_dir> ...]
+
+last_n / last=N: the window of the run that is bench.py's TIMED region -- the last N launches of every (kernel, grid) in
+dispatch order (N = steps x sims; run bench.py with --no-compare so that nothing is launched after the timed region).
+The untimed stagger / warm-up launches before it run on partly filled batches; the `trace` summary lists both windows.
+  python tools/summarize_prof.py traffic <pmc_by_shape_csv> <out_json> <precision> <kernel substring> <grid_threads> [layer=conv2] [leaves_per_launch]
 
 `trace`   : per (kernel, grid) averages from *_kernel_trace.csv; the OthelloNN layers are recognised by grid size
             (launched for 4096 slots) and get their algorithmic fp32 TFLOP/s for `leaves_per_launch` positions actually
             evaluated per launch -- take it from the bench line of the same run (leaves_evaluated_rank0 / roofline.launches;
             ~3760 in whole-game self-play, because ~8 % of the simulations end on finished boards); default 4096 = full batches.
 `pmc`     : per (kernel, grid, counter) per-launch averages from one or more *_counter_collection.csv (separate passes).
+  python tools/summarize_prof.py tree   <pmc_by_shape_csv> <out_json> <simulations_per_launch>
+`tree`    : FETCH_SIZE / WRITE_SIZE of k_select / k_expand_backup / k_compact per simulation -> profiles/tree_traffic.json
 `traffic` : conv2's HBM bytes per launch -> the json bench.py reads for roofline.traffic
             (gfx950: FETCH_SIZE is in KB and counts half of wide coalesced reads -> x2; WRITE_SIZE in KB).
 """
@@ -38,10 +44,10 @@ def find(d, suffix):
     return hits[-1]
 
 
-def trace(d, out, header, leaves=LEAVES):
+def trace(d, out, header, leaves=LEAVES, last_n=0):
     rows = defaultdict(list)
     with open(find(d, "_kernel_trace.csv")) as f:
-        for r in csv.DictReader(f):
+        for r in sorted(csv.DictReader(f), key=lambda r: int(r["Dispatch_Id"])):
             k = short(r["Kernel_Name"])
             if k.startswith("__amd") or "at::" in k or "elementwise" in k:
                 continue
@@ -69,27 +75,37 @@ def trace(d, out, header, leaves=LEAVES):
         f.write(f"# {header}\n")
         f.write(f"# per (kernel, grid) averages from the kernel trace; {leaves:g} leaves evaluated per launch; TFLOP_per_s = ALGORITHMIC fp32 FLOP "
                 "(precision f16x2 executes 3x that on the matrix pipe)\n")
-        f.write("kernel,grid_threads,wg,lds_bytes,vgpr,agpr,scratch,calls,avg_us,min_us,max_us,total_ms,layer,algorithmic_TFLOP_per_s\n")
+        if last_n:
+            f.write(f"# timed_* columns: the last {last_n} launches of the kernel in dispatch order = bench.py's timed region (full batches); "
+                    "calls / avg_us / total_ms: every launch of the run incl. the untimed stagger and warm-up rounds (partly filled batches) -- "
+                    "the population rocprofv3's own --stats file averages over\n")
+        f.write("kernel,grid_threads,wg,lds_bytes,vgpr,agpr,scratch,calls,avg_us,min_us,max_us,total_ms,timed_calls,timed_avg_us,layer,algorithmic_TFLOP_per_s\n")
         for k in sorted(rows, key=lambda k: -sum(rows[k])):
             t = rows[k]
             avg = sum(t) / len(t)
             lay = names.get(k, "")
-            tf = f"{FLOP[lay] * leaves / (avg * 1e-9) / 1e12:.1f}" if lay else ""
+            tw = t[-last_n:] if last_n and len(t) >= last_n else []
+            tavg = sum(tw) / len(tw) if tw else avg
+            tf = f"{FLOP[lay] * leaves / (tavg * 1e-9) / 1e12:.1f}" if lay else ""
             f.write(f"\"{k[0]}\",{k[1]},{k[2]},{k[3]},{k[4]},{k[5]},{k[6]},{len(t)},{avg / 1e3:.1f},{min(t) / 1e3:.1f},"
-                    f"{max(t) / 1e3:.1f},{sum(t) / 1e6:.1f},{lay},{tf}\n")
+                    f"{max(t) / 1e3:.1f},{sum(t) / 1e6:.1f},{len(tw) if tw else ''},{tavg / 1e3 if tw else 0:.1f},{lay},{tf}\n")
 
 
-def pmc(out, header, dirs):
+def pmc(out, header, dirs, last_n=0):
     acc = defaultdict(lambda: [0.0, 0])
     for d in dirs:
+        per = defaultdict(list)
         with open(find(d, "_counter_collection.csv")) as f:
-            for r in csv.DictReader(f):
+            for r in sorted(csv.DictReader(f), key=lambda r: int(r["Dispatch_Id"])):
                 k = short(r["Kernel_Name"])
                 if k.startswith("__amd") or "at::" in k or "elementwise" in k:
                     continue
-                a = acc[(k, int(r["Grid_Size"]), r["Counter_Name"])]
-                a[0] += float(r["Counter_Value"])
-                a[1] += 1
+                per[(k, int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for key, vals in per.items():
+            if last_n and len(vals) >= last_n:
+                vals = vals[-last_n:]                       # the timed region's launches only
+            acc[key][0] += sum(vals)
+            acc[key][1] += len(vals)
     with open(out, "w") as f:
         f.write(f"# {header}\n")
         f.write("# per-launch averages; FETCH_SIZE/WRITE_SIZE in KB as reported (gfx950: FETCH_SIZE counts 1/2 of wide coalesced "
@@ -99,7 +115,31 @@ def pmc(out, header, dirs):
             f.write(f"\"{k}\",{g},{c},{s / n:.6g},{n}\n")
 
 
-def traffic(src, out, precision, kernel_sub, grid, layer="conv2"):
+def tree(src, out, games):
+    """HBM-side bytes per simulation of the tree kernels from the pmc-by-shape summary of ONE timed move round
+    (`games` simulations per launch).  FETCH_SIZE is reported raw and x2 (the gfx950 correction the guide prescribes for wide
+    16-byte-per-lane reads -- the node records are read that way; the 4-byte table window and the scattered 8/16-byte reads
+    are uncalibrated, so x2 is an upper bound)."""
+    vals = defaultdict(dict)
+    with open(src) as f:
+        for r in csv.DictReader(l for l in f if not l.startswith("#")):
+            vals[r["kernel"]][r["counter"]] = float(r["avg_per_launch"])
+    j = {"round": 2, "simulations_per_launch": int(games), "algorithmic_bytes_per_sim": 1300, "source": src, "kernels": {}}
+    tot_raw = tot_w = 0.0
+    for k in ("k_select", "k_expand_backup", "k_compact"):
+        if k not in vals:
+            continue
+        fr, wr = vals[k]["FETCH_SIZE"] * 1024 / int(games), vals[k]["WRITE_SIZE"] * 1024 / int(games)
+        j["kernels"][k] = {"fetch_bytes_per_sim_raw": fr, "fetch_bytes_per_sim_x2": 2 * fr, "write_bytes_per_sim": wr}
+        tot_raw += fr; tot_w += wr
+    j["tree_side_bytes_per_sim"] = {"fetch_raw": tot_raw, "fetch_x2": 2 * tot_raw, "write": tot_w, "total_with_x2_fetch": 2 * tot_raw + tot_w}
+    with open(out, "w") as f:
+        json.dump(j, f, indent=1)
+    print(json.dumps(j))
+
+
+def traffic(src, out, precision, kernel_sub, grid, layer="conv2", leaves=LEAVES):
+    leaves = float(leaves)
     vals = {}
     with open(src) as f:
         for r in csv.DictReader(l for l in f if not l.startswith("#")):
@@ -108,12 +148,12 @@ def traffic(src, out, precision, kernel_sub, grid, layer="conv2"):
     fetch = vals["FETCH_SIZE"] * 1024 * 2
     write = vals["WRITE_SIZE"] * 1024
     # algorithmic bytes per leaf (h2 activations are 4 B per value, like fp32): input pixels + output pixels + the layer's weights once per launch
-    alg = {"conv2": 64 * 2048 + 64 * 2048 + 9 * 512 * 512 * 4 / LEAVES, "conv3": 64 * 2048 + 36 * 2048 + 9 * 512 * 512 * 4 / LEAVES}[layer]
+    alg = {"conv2": 64 * 2048 + 64 * 2048 + 9 * 512 * 512 * 4 / leaves, "conv3": 64 * 2048 + 36 * 2048 + 9 * 512 * 512 * 4 / leaves}[layer]
     if precision == "f32" and layer == "conv2":
         alg = 262144.0 + 18 * 512 * 512 * 4 / LEAVES           # as first committed: the transposed copy of the kernel counted too
-    j = {"round": 1, "precision": precision, "kernel": f"{kernel_sub} {layer}", "leaves_per_launch": LEAVES,
+    j = {"round": 2, "precision": precision, "kernel": f"{kernel_sub} {layer}", "leaves_per_launch": leaves,
          "fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-         "hbm_bytes_per_leaf": (fetch + write) / LEAVES,
+         "hbm_bytes_per_leaf": (fetch + write) / leaves,
          "algorithmic_bytes_per_leaf": alg,
          "source": src}
     if "GRBM_GUI_ACTIVE" in vals:                  # summed over the 8 XCDs
@@ -130,10 +170,15 @@ def traffic(src, out, precision, kernel_sub, grid, layer="conv2"):
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "trace":
-        trace(sys.argv[2], sys.argv[3], sys.argv[4], float(sys.argv[5]) if len(sys.argv) > 5 else LEAVES)
+        trace(sys.argv[2], sys.argv[3], sys.argv[4], float(sys.argv[5]) if len(sys.argv) > 5 else LEAVES,
+              int(sys.argv[6]) if len(sys.argv) > 6 else 0)
     elif mode == "pmc":
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4:])
+        rest = sys.argv[4:]
+        last = int(rest.pop(0).split("=")[1]) if rest and rest[0].startswith("last=") else 0
+        pmc(sys.argv[2], sys.argv[3], rest, last)
     elif mode == "traffic":
-        traffic(*sys.argv[2:8])
+        traffic(*sys.argv[2:9])
+    elif mode == "tree":
+        tree(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         raise SystemExit(__doc__)
