@@ -95,7 +95,12 @@ struct GemmGeom {
     int relu;
     int ksplit;                      // > 1: k loop split over blockIdx.y, raw sums to partial[split] (slab floats apart)
     long long slab;
+    // pixel-major row tiles (large batches): a 128-row tile = ONE output pixel of 128 consecutive boards, so which of the
+    // nine taps fall outside the image -- or outside [core_lo, core_hi)^2, the non-zero core of a zero-bordered gradient
+    // buffer -- is the same for every row of the tile and those k-tiles are skipped instead of multiplied by zeros
+    // (adding exact zeros changes no bit of the result).  ksplit must be 1.
+    int pixmajor, core_lo, core_hi;
 };
 int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
                        const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
-                       hipStream_t s, float* partial, long long partial_floats, int sizing_count = 0);
+                       hipStream_t s, float* partial, long long partial_floats, int sizing_count = 0, int core_lo = 0, int core_hi = -1);

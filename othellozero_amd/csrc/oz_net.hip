@@ -82,8 +82,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
     const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
     const int mt = (j / nnt) * 8 + xcd, nt = j % nnt;
     const int P = g.Hout * g.Hout;
-    const long long M = (long long)(*d_count) * P;
-    if (mt >= num_mt || (long long)mt * GM_BM >= M) return;
+    const int count = *d_count;
+    const long long M = (long long)count * P;
+    // row r of tile mt -> (board, output pixel): board-major (b, oy, ox) rows, or one pixel of 128 consecutive boards
+    int tile_pix = 0, tile_b0 = 0;
+    if (g.pixmajor) {
+        // tile mt = (pixel, board group) with the GROUP minor: workgroup ids go round-robin over the 8 XCDs, so an XCD sees every
+        // pixel of its board groups -- border pixels (few taps) and interior pixels (all nine) in the same mix on every XCD
+        // (pixel-minor order put one board COLUMN on each XCD: the two border columns idled while six XCDs did the work)
+        const int ngrp = (count + GM_BM - 1) / GM_BM;
+        if (mt >= ngrp * P) return;
+        tile_pix = mt / ngrp; tile_b0 = (mt % ngrp) * GM_BM;
+    } else if (mt >= num_mt || (long long)mt * GM_BM >= M) return;
+    auto row_bp = [&](int r, int& b, int& pix) -> bool {
+        if (g.pixmajor) { b = tile_b0 + r; pix = tile_pix; return b < count; }
+        const long long m = (long long)mt * GM_BM + r;
+        b = (int)(m / P); pix = (int)(m % P);
+        return m < M;
+    };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -92,12 +108,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
     // per staged A row: base offset of input pixel (oy-pad, ox-pad) and the 9-bit tap validity mask
     long long abase[4];
     unsigned amask[4];
+    const int chi = g.core_hi < 0 ? g.Hin : g.core_hi;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const long long m = (long long)mt * GM_BM + srow + 32 * i;
+        int b, pix;
         abase[i] = 0; amask[i] = 0;
-        if (m < M) {
-            const int b = (int)(m / P), pix = (int)(m % P), oy = pix / g.Hout, ox = pix % g.Hout;
+        if (row_bp(srow + 32 * i, b, pix)) {
+            const int oy = pix / g.Hout, ox = pix % g.Hout;
             abase[i] = (((long long)b * g.Hin + (oy - g.pad)) * g.Hin + (ox - g.pad)) * g.Cin;
             unsigned mk = 0;
             for (int t = 0; t < g.taps; ++t) {
@@ -107,13 +124,30 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
             amask[i] = mk;
         }
     }
+    // taps this tile has to visit: all of them, or (pixel-major) those that read inside the image / the non-zero core
+    unsigned tmask = (1u << g.taps) - 1u;
+    if (g.pixmajor) {
+        const int oy = tile_pix / g.Hout, ox = tile_pix % g.Hout;
+        tmask = 0;
+        for (int t = 0; t < g.taps; ++t) {
+            const int iy = oy - g.pad + t / 3, ix = ox - g.pad + t % 3;
+            if (iy >= g.core_lo && iy < chi && ix >= g.core_lo && ix < chi) tmask |= 1u << t;
+        }
+    }
+    const int kpt = g.Cin / GM_BK;                       // k-tiles per tap
+    auto tap_of = [&](int kt) -> int {                   // the (kt / kpt)-th visited tap
+        if (!g.pixmajor) return kt / kpt;
+        unsigned m = tmask;
+        for (int q = kt / kpt; q > 0; --q) m &= m - 1;
+        return __builtin_ctz(m);
+    };
     const float* brow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) brow[i] = Wt + (size_t)(nt * GM_BN + srow + 32 * i) * g.K + chunk * 4;
 
     f32x4 ra[4], rb[4];
     auto gload = [&](int kt) {
-        const int k0 = kt * GM_BK, tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin;
+        const int tap = tap_of(kt), ci0 = (kt % kpt) * GM_BK, k0 = tap * g.Cin + ci0;
         const long long toff = ((long long)(tap / 3) * g.Hin + (tap % 3)) * g.Cin + ci0 + chunk * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -139,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
     // split-K (training step, few row tiles): blockIdx.y owns k-tiles [kt0, nk); raw partial sums go to partial[split]
-    const int nk_all = g.K / GM_BK, nk_s = (nk_all + g.ksplit - 1) / g.ksplit;
+    const int nk_all = g.pixmajor ? __builtin_popcount(tmask) * kpt : g.K / GM_BK, nk_s = (nk_all + g.ksplit - 1) / g.ksplit;
     const int kt0 = blockIdx.y * nk_s, nk = min(nk_all, kt0 + nk_s);
     const int r32 = lane & 31, half = lane >> 5;
     if (kt0 < nk) { gload(kt0); lstore(kt0 & 1); }
@@ -177,8 +211,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long m = (long long)mt * GM_BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < M) {
+                int b, pix;
+                if (row_bp(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, b, pix)) {
+                    const long long m = (long long)b * P + pix;
                     if (g.ksplit > 1) { partial[(size_t)blockIdx.y * g.slab + (size_t)m * g.N + col] = acc[i][jj][r]; continue; }
                     float v = fmaf(acc[i][jj][r], sc, sh);
                     if (g.relu) v = v > 0.f ? v : 0.f;
@@ -215,16 +250,22 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_f32(const float* __restri
 // in a fixed order by k_splitk_reduce_f32 -- same result for every batch position, different rounding than ksplit = 1.
 int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
                        const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
-                       hipStream_t s, float* partial, long long partial_floats, int sizing_count) {
+                       hipStream_t s, float* partial, long long partial_floats, int sizing_count, int core_lo, int core_hi) {
     OZ_REQUIRE(N % GM_BN == 0 && Cin % GM_BK == 0, "gemm_f32: N %% 128 and Cin %% 32 must be 0 (N=%d Cin=%d)", N, Cin);
     GemmGeom g;
     g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.relu = relu;
+    g.core_lo = core_lo; g.core_hi = core_hi;
     const long long Mmax = (long long)max_count * Hout * Hout;
-    const int num_mt = (int)((Mmax + GM_BM - 1) / GM_BM);
+    // pixel-major tiles skip the k-tiles of taps that only read zeros; they pay when the boards fill the 128-row tiles
+    // (keyed on the call's capacity `max_count` / `sizing_count`, like the split-K choice: per-network constants)
+    static const bool pm_env = !(getenv("OZ_GEMM_PIXMAJOR") && atoi(getenv("OZ_GEMM_PIXMAJOR")) == 0);
+    const int cap = sizing_count > 0 ? sizing_count : max_count;
+    g.pixmajor = pm_env && taps == 9 && cap >= 2 * GM_BM && ((cap + GM_BM - 1) / GM_BM) * GM_BM <= cap + cap / 8;
+    const int num_mt = g.pixmajor ? ((max_count + GM_BM - 1) / GM_BM) * Hout * Hout : (int)((Mmax + GM_BM - 1) / GM_BM);
     const int grid = ((num_mt + 7) / 8) * 8 * (N / GM_BN);
     int ksplit = 1;
     const int nk = g.K / GM_BK;
-    if (partial) {
+    if (partial && !g.pixmajor) {
         // the split is chosen from `sizing_count` when given (a per-network constant: results then do not depend on the
         // size of an individual call), else from this launch's own grid
         const long long Ms = (long long)(sizing_count > 0 ? sizing_count : max_count) * Hout * Hout;

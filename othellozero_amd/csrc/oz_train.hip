@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BN_EPS 1e-3f
-#define RED_S 32          // row splits of the column reductions
+#define RED_S 256         // row splits of the column reductions (2048 waves of 1 KB loads at 512 channels: the passes are HBM streams)
 
 // ---------------------------------------------------------------- dropout hash (same formula in oracle/train_ref.py)
 OZ_HD bool oz_dropout_keep(uint64_t seed, uint64_t step, uint64_t layer, uint64_t idx, float rate) {
@@ -46,43 +46,60 @@ __device__ __forceinline__ float t_plane(uint64_t o, uint64_t p, int sq, int ch,
     return cin == 2 ? (ch == 0 ? a : b) : a - b;
 }
 
+// one thread = one pixel row m x 4 consecutive output channels (16-byte weight loads and stores)
 __global__ __launch_bounds__(256) void k_t_conv1_fwd(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
                                                      const int* __restrict__ d_count, int n, int C, int cin,
                                                      const float* __restrict__ W /*[9][cin][C]*/, const float* __restrict__ bias,
                                                      float* __restrict__ z /*[B][n*n][C]*/) {
-    const int P = n * n;
+    const int P = n * n, Q = C / 4;
     const long long M = (long long)(*d_count) * P;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long m = idx / C;
+    const long long m = idx / Q;
     if (m >= M) return;
-    const int co = (int)(idx % C);
+    const int co = (int)(idx % Q) * 4;
     const int b = (int)(m / P), pix = (int)(m % P), y = pix / n, x = pix % n;
     const uint64_t o = own[b], p = opp[b];
-    float acc = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < 9; ++t) {
         const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
         if (iy < 0 || iy >= n || ix < 0 || ix >= n) continue;
-        for (int ch = 0; ch < cin; ++ch) acc = fmaf(t_plane(o, p, iy * 8 + ix, ch, cin), W[(size_t)(t * cin + ch) * C + co], acc);
+        for (int ch = 0; ch < cin; ++ch) {
+            const float xv = t_plane(o, p, iy * 8 + ix, ch, cin);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)(t * cin + ch) * C + co);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(xv, w[k], acc[k]);
+        }
     }
-    z[(size_t)m * C + co] = acc + bias[co];
+    *reinterpret_cast<f32x4*>(z + (size_t)m * C + co) = acc + *reinterpret_cast<const f32x4*>(bias + co);
 }
 
-// dW1[t][ch][co] = sum_m x[m shifted by t][ch] * dz[m][co]; block = (t*cin + ch, 256 output channels), rows split in RED_S
+// dW1[t][ch][co] = sum_m x[m shifted by t][ch] * dz[m][co]: ONE pass over dz -- a thread owns an output channel and keeps the
+// 9 * cin sums of its row split in registers (the input planes are bits of the two bitboards, wave-uniform per row)
 __global__ __launch_bounds__(256) void k_t_conv1_wgrad(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
                                                        const int* __restrict__ d_count, int n, int C, int cin,
-                                                       const float* __restrict__ dz, float* __restrict__ partial /*[RED_S][9*cin][C]*/) {
-    const int P = n * n, tc = blockIdx.x, t = tc / cin, ch = tc % cin;
-    const int co = blockIdx.y * 256 + threadIdx.x, sp = blockIdx.z;
+                                                       const float* __restrict__ dz, float* __restrict__ partial /*[S][9*cin][C]*/, int S) {
+    const int P = n * n;
+    const int co = blockIdx.x * 256 + threadIdx.x, sp = blockIdx.y;
     if (co >= C) return;
     const long long M = (long long)(*d_count) * P;
-    float acc = 0.f;
-    for (long long m = sp; m < M; m += RED_S) {
-        const int b = (int)(m / P), pix = (int)(m % P), y = pix / n + t / 3 - 1, x = pix % n + t % 3 - 1;
-        if (y < 0 || y >= n || x < 0 || x >= n) continue;
-        const float xv = t_plane(own[b], opp[b], y * 8 + x, ch, cin);
-        if (xv != 0.f) acc = fmaf(xv, dz[(size_t)m * C + co], acc);
+    float acc[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) acc[i] = 0.f;
+    for (long long m = sp; m < M; m += S) {
+        const int b = (int)(m / P), pix = (int)(m % P), y0 = pix / n, x0 = pix % n;
+        const uint64_t o = own[b], p = opp[b];
+        const float d = dz[(size_t)m * C + co];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int y = y0 + t / 3 - 1, x = x0 + t % 3 - 1;
+            if (y < 0 || y >= n || x < 0 || x >= n) continue;
+            const int sq = y * 8 + x;
+            const float a = (float)((o >> sq) & 1), bb = (float)((p >> sq) & 1);
+            if (cin == 2) { acc[2 * t] = fmaf(a, d, acc[2 * t]); acc[2 * t + 1] = fmaf(bb, d, acc[2 * t + 1]); }
+            else acc[t] = fmaf(a - bb, d, acc[t]);
+        }
     }
-    partial[((size_t)sp * 9 * cin + tc) * C + co] = acc;
+    for (int tc = 0; tc < 9 * cin; ++tc) partial[((size_t)sp * 9 * cin + tc) * C + co] = acc[tc];
 }
 
 // out[i] = sum_s partial[s][i] in fixed order
@@ -103,37 +120,55 @@ struct RedArgs {
     float post_scale;
     int P, C, Hout, Hz, zoff;
 };
+// Streaming form: a thread owns 4 consecutive channels (16-byte loads), the lanes of a row cover up to 256 channels
+// (1 KB per wave instruction), the 256 threads of a block cover 4 rows (8 at 128 channels) per pass, rows strided RED_S
+// passes apart; the row groups of a block are combined through LDS in fixed order.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_t_colreduce(RedArgs r, const int* __restrict__ d_count, float* __restrict__ partial /*[RED_S][2][C]*/) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane4 = threadIdx.x >> 6, sp = blockIdx.y;
-    const long long M = (long long)(*d_count) * r.P;
-    float s0 = 0.f, s1 = 0.f;
-    const float mu = (MODE == 1 || MODE == 2) ? r.mean[c] : 0.f, rs = MODE == 2 ? r.rstd[c] : 0.f;
-    for (long long m = sp * 4 + lane4; m < M; m += RED_S * 4) {
-        if (MODE == 0) s0 += r.x[(size_t)m * r.C + c];
-        if (MODE == 1) { const float d = r.x[(size_t)m * r.C + c] - mu; s0 = fmaf(d, d, s0); }
+    const int Q = r.C / 4;                                   // float4 columns
+    const int lpr = Q < 64 ? Q : 64, rpp = 256 / lpr;        // lanes per row, rows per pass
+    const int q = blockIdx.x * 64 + (int)(threadIdx.x % lpr), rsub = threadIdx.x / lpr, sp = blockIdx.y;
+    const bool valid = q < Q;                                // (channel counts that are not a multiple of 256: the last block is partly idle)
+    const int c = valid ? q * 4 : 0;
+    const long long M = valid ? (long long)(*d_count) * r.P : 0;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    f32x4 mu = s0, rs = s0;
+    if (MODE == 1 || MODE == 2) mu = *reinterpret_cast<const f32x4*>(r.mean + c);
+    if (MODE == 2) rs = *reinterpret_cast<const f32x4*>(r.rstd + c);
+    for (long long m = (long long)sp * rpp + rsub; m < M; m += (long long)RED_S * rpp) {
+        const size_t o = (size_t)m * r.C + c;
+        if (MODE == 0) s0 += *reinterpret_cast<const f32x4*>(r.x + o);
+        if (MODE == 1) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(r.x + o) - mu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s0[k] = fmaf(d[k], d[k], s0[k]);
+        }
         if (MODE == 2) {
-            const size_t o = (size_t)m * r.C + c;
-            const float dy = r.a[o] > 0.f ? r.x[o] * r.post_scale : 0.f;
-            s0 += dy;
-            s1 = fmaf(dy, (r.z[o] - mu) * rs, s1);
+            const f32x4 av = *reinterpret_cast<const f32x4*>(r.a + o), xv = *reinterpret_cast<const f32x4*>(r.x + o),
+                        zv = *reinterpret_cast<const f32x4*>(r.z + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dy = av[k] > 0.f ? xv[k] * r.post_scale : 0.f;
+                s0[k] += dy;
+                s1[k] = fmaf(dy, (zv[k] - mu[k]) * rs[k], s1[k]);
+            }
         }
         if (MODE == 3) {
             const int HH = r.Hout * r.Hout, b = (int)(m / HH), pix = (int)(m % HH);
-            s0 += r.x[(((size_t)b * r.Hz + pix / r.Hout + r.zoff) * r.Hz + pix % r.Hout + r.zoff) * r.C + c];
+            s0 += *reinterpret_cast<const f32x4*>(r.x + (((size_t)b * r.Hz + pix / r.Hout + r.zoff) * r.Hz + pix % r.Hout + r.zoff) * r.C + c);
         }
     }
-    __shared__ float sh[2][4][64];
-    sh[0][lane4][threadIdx.x & 63] = s0;
-    sh[1][lane4][threadIdx.x & 63] = s1;
+    __shared__ f32x4 sh[2][256];
+    sh[0][threadIdx.x] = s0;
+    sh[1][threadIdx.x] = s1;
     __syncthreads();
-    if (lane4 == 0) {
-        const int l = threadIdx.x;
-        partial[((size_t)sp * 2 + 0) * r.C + c] = (sh[0][0][l] + sh[0][1][l]) + (sh[0][2][l] + sh[0][3][l]);
-        partial[((size_t)sp * 2 + 1) * r.C + c] = (sh[1][0][l] + sh[1][1][l]) + (sh[1][2][l] + sh[1][3][l]);
+    if (rsub == 0 && valid) {
+        f32x4 a0 = sh[0][threadIdx.x], a1 = sh[1][threadIdx.x];
+        for (int k = 1; k < rpp; ++k) { a0 += sh[0][threadIdx.x + k * lpr]; a1 += sh[1][threadIdx.x + k * lpr]; }
+        *reinterpret_cast<f32x4*>(partial + ((size_t)sp * 2 + 0) * r.C + c) = a0;
+        *reinterpret_cast<f32x4*>(partial + ((size_t)sp * 2 + 1) * r.C + c) = a1;
     }
 }
-
 __device__ __forceinline__ float t_sum_s(const float* partial, int which, int C, int c) {
     float a = 0.f;
     for (int s = 0; s < RED_S; ++s) a += partial[((size_t)s * 2 + which) * C + c];
@@ -162,18 +197,26 @@ __global__ void k_t_fin_colsum(const float* __restrict__ partial, int C, float* 
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) out[c] = t_sum_s(partial, 0, C, c);
 }
-// a = relu((z - mean) * rstd * gamma + beta) [* keep / (1 - rate)]
+// a = relu((z - mean) * rstd * gamma + beta) [* keep / (1 - rate)]; 4 consecutive channels per thread
 __global__ __launch_bounds__(256) void k_t_bn_fwd(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ a,
                                                   const int* __restrict__ d_count, int P, int C, float rate, uint64_t seed, uint64_t step, int dlayer) {
     const long long total = (long long)(*d_count) * P * C;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= total) return;
     const int c = (int)(i % C);
-    float y = (z[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
-    y = y > 0.f ? y : 0.f;
-    if (rate > 0.f) y = oz_dropout_keep(seed, step, (uint64_t)dlayer, (uint64_t)i, rate) ? y / (1.0f - rate) : 0.f;
-    a[i] = y;
+    const f32x4 zv = *reinterpret_cast<const f32x4*>(z + i), mu = *reinterpret_cast<const f32x4*>(mean + c),
+                rs = *reinterpret_cast<const f32x4*>(rstd + c), ga = *reinterpret_cast<const f32x4*>(gamma + c),
+                be = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 out;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float y = (zv[k] - mu[k]) * rs[k] * ga[k] + be[k];
+        y = y > 0.f ? y : 0.f;
+        if (rate > 0.f) y = oz_dropout_keep(seed, step, (uint64_t)dlayer, (uint64_t)(i + k), rate) ? y / (1.0f - rate) : 0.f;
+        out[k] = y;
+    }
+    *reinterpret_cast<f32x4*>(a + i) = out;
 }
 // dgamma = s1, dbeta = s0
 __global__ void k_t_fin_bnbwd(const float* __restrict__ partial, int C, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ sums /*[2][C]*/) {
@@ -182,23 +225,31 @@ __global__ void k_t_fin_bnbwd(const float* __restrict__ partial, int C, float* _
     const float s0 = t_sum_s(partial, 0, C, c), s1 = t_sum_s(partial, 1, C, c);
     dbeta[c] = s0; dgamma[c] = s1; sums[c] = s0; sums[C + c] = s1;
 }
-// dz = gamma * rstd * (dy - s0/M - xhat * s1/M), written at (b, oy+zoff, ox+zoff) of an Hz x Hz buffer
+// dz = gamma * rstd * (dy - s0/M - xhat * s1/M), written at (b, oy+zoff, ox+zoff) of an Hz x Hz buffer; 4 channels per thread
 __global__ __launch_bounds__(256) void k_t_bn_bwd(const float* __restrict__ dA, const float* __restrict__ a, const float* __restrict__ z,
                                                   const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                   const float* __restrict__ sums, float post_scale, const int* __restrict__ d_count,
                                                   int Hout, int C, int Hz, int zoff, float* __restrict__ dz) {
     const int P = Hout * Hout;
     const long long M = (long long)(*d_count) * P, total = M * C;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= total) return;
     const int c = (int)(i % C);
     const long long m = i / C;
-    const float dy = a[i] > 0.f ? dA[i] * post_scale : 0.f;
-    const float xh = (z[i] - mean[c]) * rstd[c];
+    const f32x4 av = *reinterpret_cast<const f32x4*>(a + i), dv = *reinterpret_cast<const f32x4*>(dA + i), zv = *reinterpret_cast<const f32x4*>(z + i),
+                mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c),
+                ga = *reinterpret_cast<const f32x4*>(gamma + c), s0 = *reinterpret_cast<const f32x4*>(sums + c),
+                s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
     const float inv = 1.0f / (float)M;
-    const float g = gamma[c] * rstd[c] * (dy - sums[c] * inv - xh * sums[C + c] * inv);
+    f32x4 g;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float dy = av[k] > 0.f ? dv[k] * post_scale : 0.f;
+        const float xh = (zv[k] - mu[k]) * rs[k];
+        g[k] = ga[k] * rs[k] * (dy - s0[k] * inv - xh * s1[k] * inv);
+    }
     const int b = (int)(m / P), pix = (int)(m % P);
-    dz[(((size_t)b * Hz + pix / Hout + zoff) * Hz + pix % Hout + zoff) * C + c] = g;
+    *reinterpret_cast<f32x4*>(dz + (((size_t)b * Hz + pix / Hout + zoff) * Hz + pix % Hout + zoff) * C + c) = g;
 }
 
 // ---------------------------------------------------------------- heads: forward, losses, gradient wrt f2
@@ -381,6 +432,97 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(const float* __restrict__ X, 
             }
 }
 
+// ---------------------------------------------------------------- weight gradient of a 3x3 convolution, board-resident
+// dW[tap][ci][co] = sum over boards b and output pixels p of X[b][p + tap][ci] * dZ[b][p][co].
+// k_wgrad_f32 above (kept for the dense layers) gives every (tap, 128 ci, 128 co) tile its own block, so the two operand
+// matrices stream through 9 x 4 x 4 blocks: 32 FLOP per byte staged, the launch is bound by the memory system (measured
+// 30-49 TFLOP/s at batch 1024).  Here a block owns a 64 (ci) x 128 (co) tile for ALL NINE taps: one board's X tile (with its
+// zero border for 'same' layers) and dZ tile are staged in LDS once and every tap reads the SAME staged pixels at a shifted
+// address -- 9 accumulators per wave (one 32 x 32 MFMA tile per tap = 144 registers), 190 FLOP per byte staged, one barrier
+// per board, next board prefetched into registers during the 288 MFMAs of the current one.  The k index of
+// v_mfma_f32_32x32x2_f32 is the output pixel: k-steps of two pixels (Hout^2 is even for every layer of either board size).
+#define WC_CI 64
+#define WC_CO 128
+struct WconvGeom { int Hin, Hout, pad, Cin, Cout, Hz, zoff; };
+__global__ __launch_bounds__(512) void k_wgrad_conv(const float* __restrict__ X, const float* __restrict__ dZ, const int* __restrict__ d_count,
+                                                    WconvGeom g, float* __restrict__ dW, int msplit, float* __restrict__ partial, long long slab) {
+    extern __shared__ __attribute__((aligned(16))) float wc_lds[];
+    const int XW = g.Hin + 2 * g.pad, XP = XW * XW, P = g.Hout * g.Hout;
+    const int stage_floats = XP * WC_CI + P * WC_CO;
+    const int nco = g.Cout / WC_CO;
+    const int ci0 = (blockIdx.x / nco) * WC_CI, co0 = (blockIdx.x % nco) * WC_CO;
+    const int B = *d_count;
+    const int per = (B + msplit - 1) / msplit, b0 = blockIdx.y * per, b1 = b0 + per < B ? b0 + per : B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3, r32 = lane & 31, kk = lane >> 5;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // staging: float4 units; X tile = XP pixels x 16 units (border pixels are zeros), dZ tile = P pixels x 32 units
+    const int xu = XP * (WC_CI / 4), zu = P * (WC_CO / 4);
+    f32x4 rx[4], rz[4];
+    auto gload = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = tid + 512 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (u < xu) {
+                const int px = u >> 4, c4 = (u & 15) * 4, iy = px / XW - g.pad, ix = px % XW - g.pad;
+                if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Hin)
+                    v = *reinterpret_cast<const f32x4*>(X + (((size_t)b * g.Hin + iy) * g.Hin + ix) * g.Cin + ci0 + c4);
+            }
+            rx[i] = v;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (u < zu) {
+                const int px = u >> 5, c4 = (u & 31) * 4, oy = px / g.Hout, ox = px % g.Hout;
+                z = *reinterpret_cast<const f32x4*>(dZ + (((size_t)b * g.Hz + oy + g.zoff) * g.Hz + ox + g.zoff) * g.Cout + co0 + c4);
+            }
+            rz[i] = z;
+        }
+    };
+    auto lstore = [&](int st) {
+        float* Xs = wc_lds + st * stage_floats;
+        float* Zs = Xs + XP * WC_CI;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = tid + 512 * i;
+            if (u < xu) *reinterpret_cast<f32x4*>(Xs + u * 4) = rx[i];
+            if (u < zu) *reinterpret_cast<f32x4*>(Zs + u * 4) = rz[i];
+        }
+    };
+    if (b0 < b1) { gload(b0); lstore(0); }
+    __syncthreads();
+    for (int b = b0; b < b1; ++b) {
+        const int st = (b - b0) & 1;
+        if (b + 1 < b1) gload(b + 1);
+        const float* Xs = wc_lds + st * stage_floats + wm * 32 + r32;
+        const float* Zs = wc_lds + st * stage_floats + XP * WC_CI + wn * 32 + r32;
+        for (int s2 = 0; s2 < P / 2; ++s2) {
+            const int p = 2 * s2 + kk, oy = p / g.Hout, ox = p - oy * g.Hout;
+            const float zb = Zs[p * WC_CO];
+            const float* xa = Xs + (oy * XW + ox) * WC_CI;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[((t / 3) * XW + (t % 3)) * WC_CI], zb, acc[t], 0, 0, 0);
+        }
+        if (b + 1 < b1) lstore(st ^ 1);             // the other stage was last read before the previous barrier
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31 (co), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (ci)
+    float* __restrict__ outp = msplit > 1 ? partial + (size_t)blockIdx.y * slab : dW;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int co = co0 + wn * 32 + r32;
+            outp[((size_t)t * g.Cin + ci) * g.Cout + co] = acc[t][r];
+        }
+}
+
 // ---------------------------------------------------------------- operand layouts derived from the Keras-layout masters
 // out[c][r] = in[r][c]   (forward operand Wt[N][K] of k_gemm_f32 from the Keras kernel [K][N])
 __global__ __launch_bounds__(256) void k_t_transpose(const float* __restrict__ in, int R, int Cc, float* __restrict__ out) {
@@ -435,7 +577,8 @@ struct oz_trainer {
     hipStream_t s2 = nullptr;
     hipEvent_t ev_dz[6] = {}, ev_w = nullptr;
     bool overlap = true;                 // env OZ_TRAIN_OVERLAP=0: weight gradients on the main stream
-    long long gpartial_floats = 16LL << 20;
+    long long gpartial_floats = 40LL << 20;      // 160 MB each: 16 row-split slabs of a 3x3 x 512 x 512 weight gradient
+    bool wconv_attr = false;
     int split_mask = 7;                  // diagnostic (env OZ_TRAIN_SPLIT_MASK): 1 forward, 2 dense dgrad, 4 conv dgrad GEMMs may split K
     int P_[6], Co[6], Hout[6], Hz[6], zoff[6];
     std::vector<void*> allocs;
@@ -617,7 +760,7 @@ static int t_refresh(oz_trainer* t) {
 
 template <int MODE>
 static int t_reduce(oz_trainer* t, RedArgs r) {
-    hipLaunchKernelGGL(k_t_colreduce<MODE>, dim3(r.C / 64, RED_S), dim3(256), 0, t->s, r, t->d_count, t->partial);
+    hipLaunchKernelGGL(k_t_colreduce<MODE>, dim3((r.C / 4 + 63) / 64, RED_S), dim3(256), 0, t->s, r, t->d_count, t->partial);
     OZ_HIP(hipGetLastError());
     return OZ_OK;
 }
@@ -640,7 +783,7 @@ static int t_bn_forward(oz_trainer* t, int l, int B) {
     hipLaunchKernelGGL(k_t_fin_var, dim3((Cc + 255) / 256), dim3(256), 0, t->s, t->partial, t->d_count, P, Cc, t->mean[l], t->rstd[l],
                        t->stats[6 * l + 4], t->stats[6 * l + 5], t->stats_new[6 * l + 4], t->stats_new[6 * l + 5], t->mom, l < 4 ? 1 : 0);
     const long long total = (long long)B * P * Cc;
-    hipLaunchKernelGGL(k_t_bn_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, t->s, t->z[l], t->mean[l], t->rstd[l], t->param(6 * l + 2),
+    hipLaunchKernelGGL(k_t_bn_fwd, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, t->s, t->z[l], t->mean[l], t->rstd[l], t->param(6 * l + 2),
                        t->param(6 * l + 3), t->a[l], t->d_count, P, Cc, l >= 4 ? t->rate : 0.f, t->seed, (uint64_t)t->step, l - 4);
     OZ_HIP(hipGetLastError());
     return OZ_OK;
@@ -662,7 +805,7 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
     if (t->dirty) if (int rc = t_refresh(t)) return rc;
 
     // ---- forward
-    { const long long tot = (long long)B * A * C;
+    { const long long tot = (long long)B * A * (C / 4);
       hipLaunchKernelGGL(k_t_conv1_fwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, t->d_own, t->d_opp, t->d_count, n, C, t->cin,
                          t->param(0), t->param(1), t->z[0]);
       OZ_HIP(hipGetLastError()); }
@@ -697,7 +840,7 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
         if (int rc = t_reduce<2>(t, r)) return rc;
         hipLaunchKernelGGL(k_t_fin_bnbwd, dim3((Cc + 255) / 256), dim3(256), 0, s, t->partial, Cc, t->grad(6 * l + 2), t->grad(6 * l + 3), t->sums);
         const long long total = (long long)B * P * Cc;
-        hipLaunchKernelGGL(k_t_bn_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t->dA[cur], t->a[l], t->z[l], t->mean[l], t->rstd[l],
+        hipLaunchKernelGGL(k_t_bn_bwd, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, t->dA[cur], t->a[l], t->z[l], t->mean[l], t->rstd[l],
                            t->param(6 * l + 2), t->sums, post, t->d_count, t->Hout[l], Cc, t->Hz[l], t->zoff[l], t->dz[l]);
         OZ_HIP(hipGetLastError());
         // bias gradient = column sums of dz (mathematically 0 behind a training-mode BN; computed like autograd would)
@@ -708,10 +851,12 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
         }
         // weight gradient
         if (l == 0) {
-            hipLaunchKernelGGL(k_t_conv1_wgrad, dim3(9 * t->cin, (C + 255) / 256, RED_S), dim3(256), 0, s, t->d_own, t->d_opp, t->d_count, n, C, t->cin,
-                               t->dz[0], t->partial);
+            int S1 = 8;                                    // row splits: ~64 rows per thread, at most RED_S (the partial buffer's capacity)
+            while (S1 < RED_S && (long long)B * A > 64LL * S1) S1 *= 2;
+            hipLaunchKernelGGL(k_t_conv1_wgrad, dim3((C + 255) / 256, S1), dim3(256), 0, s, t->d_own, t->d_opp, t->d_count, n, C, t->cin,
+                               t->dz[0], t->partial, S1);
             const long long cnt = 9LL * t->cin * C;
-            hipLaunchKernelGGL(k_t_sum_partials, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, t->partial, RED_S, cnt, t->grad(0));
+            hipLaunchKernelGGL(k_t_sum_partials, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, t->partial, S1, cnt, t->grad(0));
             OZ_HIP(hipGetLastError());
         } else {
             WgradGeom g; g.Hin = Hin[l]; g.Hout = t->Hout[l]; g.pad = pad[l]; g.Cin = Cin[l]; g.Cout = Cc; g.taps = taps[l]; g.Hz = t->Hz[l]; g.zoff = t->zoff[l];
@@ -728,8 +873,25 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
                 OZ_HIP(hipStreamWaitEvent(t->s2, t->ev_dz[l], 0));
                 sw = t->s2; wp = t->wpartial;
             }
-            hipLaunchKernelGGL(k_wgrad_f32, dim3(wblocks, msplit), dim3(256), 0, sw, t->a[l - 1], t->dz[l], t->d_count, g, t->grad(6 * l), msplit,
-                               wp, wcount);
+            static const bool conv_kernel = !(getenv("OZ_WGRAD_CONV") && atoi(getenv("OZ_WGRAD_CONV")) == 0);   // OZ_WGRAD_CONV=0: the tap-per-block kernel (A/B runs)
+            if (taps[l] == 9 && conv_kernel && Cin[l] % WC_CI == 0 && Cc % WC_CO == 0) {
+                // board-resident kernel: (Cin / 64) x (Cout / 128) tiles, boards split over blockIdx.y until every CU has a block
+                WconvGeom cg; cg.Hin = Hin[l]; cg.Hout = t->Hout[l]; cg.pad = pad[l]; cg.Cin = Cin[l]; cg.Cout = Cc; cg.Hz = t->Hz[l]; cg.zoff = t->zoff[l];
+                const int tiles = (Cin[l] / WC_CI) * (Cc / WC_CO);
+                msplit = 1;
+                while (msplit < 16 && tiles * msplit < 256 && msplit * 2 <= B && wcount * msplit * 2 <= t->gpartial_floats) msplit *= 2;
+                const int XW = cg.Hin + 2 * cg.pad;
+                const size_t lds_bytes = 2 * sizeof(float) * ((size_t)XW * XW * WC_CI + (size_t)P * WC_CO);
+                if (!t->wconv_attr) {
+                    OZ_HIP(hipFuncSetAttribute((const void*)k_wgrad_conv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                    t->wconv_attr = true;
+                }
+                hipLaunchKernelGGL(k_wgrad_conv, dim3(tiles, msplit), dim3(512), lds_bytes, sw, t->a[l - 1], t->dz[l], t->d_count, cg, t->grad(6 * l), msplit,
+                                   wp, wcount);
+            } else {
+                hipLaunchKernelGGL(k_wgrad_f32, dim3(wblocks, msplit), dim3(256), 0, sw, t->a[l - 1], t->dz[l], t->d_count, g, t->grad(6 * l), msplit,
+                                   wp, wcount);
+            }
             if (msplit > 1)
                 hipLaunchKernelGGL(k_t_sum_partials, dim3((unsigned)((wcount + 255) / 256)), dim3(256), 0, sw, wp, msplit, wcount, t->grad(6 * l));
             OZ_HIP(hipGetLastError());
@@ -738,8 +900,10 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
                 if (int rc = oz_gemm_f32_launch(t->dz[l], t->param(6 * l), t->ones, t->zeros, t->dA[cur ^ 1], t->d_count, B, 1, 1, 0, Cc, 1, Cin[l], 0, s, t->gpartial, (t->split_mask & 2) ? t->gpartial_floats : 0)) return rc;
             } else {               // 3x3 conv: conv of dz (zero-bordered for 'valid' layers) with the reversed, channel-swapped taps
                 const int same = pad[l];
+                // (the non-zero core of the zero-bordered dz buffer: taps that only read the border are skipped at large batch)
                 if (int rc = oz_gemm_f32_launch(t->dz[l], t->Wd[l], t->ones, t->zeros, t->dA[cur ^ 1], t->d_count, B, t->Hz[l], Hin[l], same ? 1 : 0, Cc, 9,
-                                                Cin[l], 0, s, t->gpartial, (t->split_mask & 4) ? t->gpartial_floats : 0)) return rc;
+                                                Cin[l], 0, s, t->gpartial, (t->split_mask & 4) ? t->gpartial_floats : 0, 0, t->zoff[l],
+                                                t->zoff[l] + t->Hout[l])) return rc;
             }
             cur ^= 1;
         }

@@ -8,7 +8,7 @@
 // Used when rows <= OZ_BN_FUSED_MAX_ROWS; larger batches keep the multi-block reductions (bandwidth-bound there).
 #pragma once
 
-#define OZ_BN_FUSED_MAX_ROWS 16384
+#define OZ_BN_FUSED_MAX_ROWS 4096        // (64 boards of 8x8; above that the streaming multi-block reductions win: 32 blocks cannot feed HBM)
 
 #define OZ_BN_RL 64                        // row lanes per block
 #define OZ_BN_COLS 16                      // channels per block

@@ -65,7 +65,11 @@ def _check_grads(ref, gpu, scale=3e-4):
     return worst
 
 
-@pytest.mark.parametrize("n,C,cin,B", [(6, 128, 2, 8), (8, 128, 2, 5), (6, 128, 1, 7), (8, 256, 2, 32), (8, 512, 2, 6)])
+@pytest.mark.parametrize("n,C,cin,B", [(6, 128, 2, 8), (8, 128, 2, 5), (6, 128, 1, 7), (8, 256, 2, 32), (8, 512, 2, 6),
+                                       # large batches: pixel-major GEMM tiles that skip the taps reading only zeros (forward 'same'
+                                       # borders, the zero-bordered data-gradient buffers), streaming BN reductions, the board-resident
+                                       # weight-gradient kernel with its row splits
+                                       (8, 128, 2, 256), (6, 128, 1, 384)])
 def test_forward_backward_matches_autograd(n, C, cin, B):
     ref, gpu = _pair(n, C, cin, B, seed=3)
     lg, lr_ = _both(ref, gpu, _batch(n, B, 11, cin))
