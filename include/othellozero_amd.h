@@ -252,6 +252,14 @@ int oz_trainer_grad_arena(oz_trainer* t, void** device_ptr, int64_t* nelem);
 int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const uint64_t* opp, const float* pi_target,
                                 const float* z_target, int B, float* losses3);
 int oz_trainer_apply(oz_trainer* t);                         /* Adam step + BN moving-statistics commit (stream-ordered) */
+/* keras Model.fit as the reference drives it (Net/NNet.py:67) with the examples RESIDENT on the device: one upload per fit
+ * (set_dataset: own / opp / pi_target [N][n*n] / z_target [N]), then per epoch ONE call that runs the optimiser steps of the
+ * shuffled order (`order`: `count` example indices, batches of `batch`, the last one may be short) back to back on the
+ * stream -- per-step batch gather on the device, no host copy or synchronisation per step -- and returns the
+ * sample-weighted mean losses of the epoch {total, policy, value}.  Single-process training; a data-parallel job keeps
+ * the step-wise calls (its all-reduce sits between backward and apply). */
+int oz_trainer_set_dataset(oz_trainer* t, const uint64_t* own, const uint64_t* opp, const float* pi_target, const float* z_target, int64_t N);
+int oz_trainer_fit_epoch(oz_trainer* t, const int32_t* order, int64_t count, int batch, float* losses3);
 int oz_trainer_outputs(oz_trainer* t, int B, float* p /* [B][n*n] */, float* v /* [B] */);   /* of the last forward pass */
 /* post-activation output of block `layer` (0-3 conv, 4-5 dense; [B][pixels][channels]) of the last forward pass -- inspection */
 int oz_trainer_get_activation(oz_trainer* t, int layer, int B, float* data, int64_t nelem);

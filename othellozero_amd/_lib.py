@@ -117,6 +117,8 @@ SIGNATURES = {
     "oz_trainer_grad_arena": [_vp, C.POINTER(_vp), C.POINTER(C.c_int64)],
     "oz_trainer_forward_backward": [_vp, _u64p, _u64p, _f32p, _f32p, C.c_int, _f32p],
     "oz_trainer_apply": [_vp],
+    "oz_trainer_set_dataset": [_vp, _u64p, _u64p, _f32p, _f32p, C.c_int64],
+    "oz_trainer_fit_epoch": [_vp, _i32p, C.c_int64, C.c_int, _f32p],
     "oz_trainer_outputs": [_vp, C.c_int, _f32p, _f32p],
     "oz_trainer_get_activation": [_vp, C.c_int, C.c_int, _f32p, C.c_int64],
     "oz_trainer_sync": [_vp],

@@ -90,6 +90,21 @@ class Trainer:
                                                            _lib.p_f32(zt), B, _lib.p_f32(losses)))
         return float(losses[0]), float(losses[1]), float(losses[2])
 
+    def set_dataset(self, own, opp, pi, z):
+        """upload the examples of a fit once; they stay in HBM until the next set_dataset"""
+        own = np.ascontiguousarray(own, dtype=np.uint64); opp = np.ascontiguousarray(opp, dtype=np.uint64)
+        pi = np.ascontiguousarray(pi, dtype=np.float32).reshape(own.size, self.n * self.n)
+        z = np.ascontiguousarray(z, dtype=np.float32)
+        _lib.check(_lib.load().oz_trainer_set_dataset(self._h, _lib.p_u64(own), _lib.p_u64(opp), _lib.p_f32(pi), _lib.p_f32(z), own.size))
+
+    def fit_epoch(self, order, batch_size):
+        """the optimiser steps of one epoch over the resident examples in `order` (batches of batch_size, last one short);
+        -> sample-weighted mean (loss, policy loss, value loss)"""
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        out = np.zeros(3, np.float32)
+        _lib.check(_lib.load().oz_trainer_fit_epoch(self._h, _lib.p_i32(order), order.size, int(batch_size), _lib.p_f32(out)))
+        return out
+
     def apply(self):
         _lib.check(_lib.load().oz_trainer_apply(self._h))
 
@@ -132,23 +147,38 @@ def pack_examples(examples, board_size, in_channels=2):
     return own, opp, pi, z
 
 
-def fit(trainer, own, opp, pi, z, batch_size=32, epochs=10, shuffle_seed=0, allreduce=None, verbose=None):
+def fit(trainer, own, opp, pi, z, batch_size=32, epochs=10, shuffle_seed=0, allreduce=None, verbose=None, resident=None):
     """keras Model.fit(x, y, batch_size, epochs) with shuffle=True (the default the reference relies on).
-    `allreduce(trainer)` -- if given -- averages the gradient arena across ranks between backward and apply."""
+    `allreduce(trainer)` -- if given -- averages the gradient arena across ranks between backward and apply.
+
+    resident (default: True without an all-reduce): the examples are uploaded ONCE (oz_trainer_set_dataset) and every
+    epoch is one library call that runs its optimiser steps back to back on the device (oz_trainer_fit_epoch) -- the
+    same shuffled order, batches, steps and weights as the step-wise loop, without a host copy or a synchronisation
+    per step.  With an all-reduce (data-parallel training) the loop stays step-wise: the collective sits between
+    backward and apply."""
     N = len(z)
     hist = History()
+    if resident is None:
+        resident = allreduce is None
+    assert not (resident and allreduce is not None), "the resident path has no room for a per-step all-reduce"
+    if resident:
+        trainer.set_dataset(own, opp, pi, z)
     for ep in range(epochs):
         order = np.random.RandomState(shuffle_seed + ep).permutation(N)
-        tot, seen = np.zeros(3), 0
-        for s in range(0, N, batch_size):
-            idx = order[s:s + batch_size]
-            losses = trainer.forward_backward(own[idx], opp[idx], pi[idx], z[idx])
-            if allreduce is not None:
-                allreduce(trainer)
-            trainer.apply()
-            tot += np.asarray(losses) * len(idx)            # keras reports the sample-weighted running mean
-            seen += len(idx)
-        for k, val in zip(("loss", "pi-reshaped_loss", "v_loss"), tot / max(seen, 1)):
+        if resident:
+            means = np.asarray(trainer.fit_epoch(order, batch_size), dtype=np.float64)
+        else:
+            tot, seen = np.zeros(3), 0
+            for s in range(0, N, batch_size):
+                idx = order[s:s + batch_size]
+                losses = trainer.forward_backward(own[idx], opp[idx], pi[idx], z[idx])
+                if allreduce is not None:
+                    allreduce(trainer)
+                trainer.apply()
+                tot += np.asarray(losses) * len(idx)            # keras reports the sample-weighted running mean
+                seen += len(idx)
+            means = tot / max(seen, 1)
+        for k, val in zip(("loss", "pi-reshaped_loss", "v_loss"), means):
             hist.history[k].append(float(val))
         hist.epoch.append(ep)
         if verbose:
