@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--fit-examples", type=int, default=0,
+                    help="also time trainer.fit over this many examples (2 epochs) both ways: step-wise host loop vs HBM-resident data set")
     args = ap.parse_args()
     from othellozero_amd.trainer import Trainer
     from othellozero_amd.weights import init_weights
@@ -51,9 +53,30 @@ def main():
     fwd = 2 * (n * n * 18 * C + n * n * 9 * C * C + (n - 2) ** 2 * 9 * C * C + (n - 4) ** 2 * 9 * C * C + F * 1024 + 1024 * 512 + 512 * (n * n + 1))
     flop = (3 * fwd - 2 * n * n * 18 * C) * B
     params = 18 * C + 3 * 9 * C * C + F * 1024 + 1024 * 512
-    print(json.dumps({"metric": "training_steps_per_sec", "value": args.steps / dt, "examples_per_s": args.steps * B / dt,
+    fit_cmp = None
+    if args.fit_examples:
+        from othellozero_amd.trainer import fit
+        N = args.fit_examples
+        o2 = rs.randint(0, 2**63, size=N, dtype=np.uint64) & valid
+        p2 = rs.randint(0, 2**63, size=N, dtype=np.uint64) & valid & ~o2
+        pi2 = np.zeros((N, n * n), np.float32)
+        pi2[np.arange(N), rs.randint(0, n * n, N)] = 1
+        z2 = rs.choice([-1.0, 1.0], N).astype(np.float32)
+        fit_cmp = {}
+        for name, resident in (("stepwise_host_loop", False), ("resident_dataset", True)):
+            fit(tr, o2[:B * 4], p2[:B * 4], pi2[:B * 4], z2[:B * 4], batch_size=B, epochs=1, resident=resident)      # warm-up
+            t1 = time.perf_counter()
+            fit(tr, o2, p2, pi2, z2, batch_size=B, epochs=2, shuffle_seed=3, resident=resident)
+            d = time.perf_counter() - t1
+            steps = 2 * ((N + B - 1) // B)
+            fit_cmp[name] = {"seconds": d, "steps": steps, "ms_per_step": 1e3 * d / steps}
+    print(json.dumps({"metric": "training_steps_per_sec", "value": args.steps / dt, "examples_per_s": args.steps * B / dt, "fit": fit_cmp,
                       "ms_per_step": 1e3 * dt / args.steps, "batch": B, "board": n, "channels": C,
                       "tflops_fp32": flop * args.steps / dt / 1e12, "flop_per_step": flop,
+                      # the step as a whole against the fp32 matrix-core roof (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md): algorithmic
+                      # contraction FLOP of forward + data gradient + weight gradient / wall time of the whole step (BN, losses, Adam included)
+                      "roofline": {"bound": "mfma", "achieved": flop * args.steps / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                   "frac": flop * args.steps / dt / 1e12 / 157.3, "traffic": None},
                       "adam_bytes_per_step": params * 4 * 7, "last_loss": loss[0], "dtype": "f32", "data": "synthetic"}))
 
 
