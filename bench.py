@@ -133,6 +133,25 @@ def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tabl
     return out
 
 
+def tree_side(sims_per_s):
+    """the tree / rules side is latency-bound integer work; ~1.3 KB of algorithmic HBM bytes per simulation.
+    The measured bytes (PMC FETCH_SIZE / WRITE_SIZE of k_select / k_expand_backup / k_compact over one timed move round) come
+    from the committed profile, labelled as such."""
+    r = {"bytes_per_sim": TREE_BYTES_PER_SIM, "bytes_per_sim_source": "SURVEY.md 8(d) algorithmic estimate",
+         "achieved_GBps": sims_per_s * TREE_BYTES_PER_SIM / 1e9, "peak_GBps": PEAK_HBM_GBPS,
+         "frac": sims_per_s * TREE_BYTES_PER_SIM / (PEAK_HBM_GBPS * 1e9), "note": "not the binding roof; reported per SURVEY 8(d)"}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "tree_traffic.json")))
+        t = tj["tree_side_bytes_per_sim"]
+        r["measured"] = {"fetch_bytes_per_sim_raw": t["fetch_raw"], "fetch_bytes_per_sim_x2": t["fetch_x2"], "write_bytes_per_sim": t["write"],
+                         "k_select_fetch_bytes_per_sim_x2": tj["kernels"]["k_select"]["fetch_bytes_per_sim_x2"],
+                         "source": "profiles/tree_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, the 100 launches of one timed move round; "
+                                   "x2 = the gfx950 rule for 16-byte-per-lane reads, an upper bound for this access mix); not re-measured in this run"}
+    except Exception:
+        pass
+    return r
+
+
 def cpu_baseline(n, channels, sims, budget_s=12.0):
     """The oracle port of the reference path (sequential simulations, one game, batch-1 leaf evaluation by the
     float32 C restatement of OthelloNN on all host cores), timed on a bounded sample of about budget_s seconds."""
@@ -502,9 +521,7 @@ def main():
                                                    "(partly filled batches): the population `rocprofv3 --stats` of the same command averages over; "
                                                    "avg_launch_ms above is the timed region only"}),
             # the tree / rules side is latency-bound integer work, ~1.3 KB of algorithmic HBM bytes per simulation
-            "tree_side_hbm": {"bytes_per_sim": TREE_BYTES_PER_SIM, "bytes_per_sim_source": "SURVEY.md 8(d) algorithmic estimate (not measured in this run)",
-                              "achieved_GBps": sims_all / dt * TREE_BYTES_PER_SIM / 1e9, "peak_GBps": PEAK_HBM_GBPS,
-                              "frac": sims_all / dt * TREE_BYTES_PER_SIM / (PEAK_HBM_GBPS * 1e9), "note": "not the binding roof; reported per SURVEY 8(d)"},
+            "tree_side_hbm": tree_side(sims_all / dt),
         }
         out["dtype"] = "f32" if args.precision == "f32" else "f32 (2xf16 split)"
         out["dtype_detail"] = ("fp32 operands and accumulators on v_mfma_f32_32x32x2_f32" if args.precision == "f32" else
