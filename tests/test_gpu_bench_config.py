@@ -200,3 +200,26 @@ def test_stagger_spreads_games_and_keeps_records_exact(oz):
         m = oracle.Mcts(n, 1.0, 1, salt=9)
         ep = m.episode(sims, 1.0, 0.9, 21, g, sims_pre=pre, pre_plies=int(offs[g]))
         assert np.array_equal(r["action"], ep["action"]) and np.array_equal(r["z"], ep["z"]), g
+
+
+def test_config3_last_rank_shard_at_full_size(oz):
+    """BASELINE configs[2] (32768 games over 8 GPUs) as ONE rank sees it: the engine of rank 7 of 8 -- 4096 slots holding
+    global game ids [28672, 32768), refills stepping by the job-wide 32768 -- at 100 sims/move: per-game RNG streams are keyed
+    by the GLOBAL id, so sampled games (first and second generation) equal the oracle's episodes of those ids move for move.
+    (The all-gather of the eight ranks' records is covered by the world_size-2 tests; RCCL itself needs the 8-GPU node.)"""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    n, G, world, rank, sims = 6, 4096, 8, 7, 100
+    eng = SelfPlayEngine(StubNetWrapper((n, n), 23, 0, max_batch=G), n, G, sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * G,
+                         game_id_stride=world * G, q_mode=1, refill=True, record_cap=G * 3 * n * n)
+    eng.run(2 * (n * n - 4) + 2)                                           # two generations of 6x6 games
+    st = eng.stats()
+    assert st["overflow"] == 0 and st["games_completed"] >= 2 * G - 8
+    rec = eng.records()
+    ids = np.unique(rec["game_id"])
+    assert ids.min() == rank * G and np.all((ids % (world * G)) >= rank * G)   # only this rank's residue classes
+    for gid in (rank * G, rank * G + 1234, (rank + 1) * G - 1, rank * G + world * G, (rank + 1) * G - 1 + world * G):
+        r = rec[rec["game_id"] == gid]
+        ep = oracle.Mcts(n, 1.0, 1, salt=23).episode(sims, 1.0, 0.9, 1234, gid)
+        assert np.array_equal(r["action"], ep["action"]) and np.array_equal(r["z"], ep["z"]), gid
+        assert np.array_equal(r["black"], ep["black"]) and np.array_equal(r["white"], ep["white"]), gid
