@@ -223,6 +223,64 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
     }
 }
 
+// ---------------------------------------------------------------- dense layers on few rows (M <= 64): a weight STREAM, not a GEMM
+// out[m][n] = sum_k A[m][k] Wt[n][k] with M = the batch (<= 64 boards): 2 M FLOP per weight, so the layer is bound by reading
+// Wt once (33.5 MB for fc1) and the 128-row tiles of k_gemm_f32 waste 3/4 of their MFMAs on padding rows while only
+// 64-128 blocks pull on HBM.  Here a block owns 128 output columns x `kb` reduction indices: every lane fetches ITS column's
+// weights straight into registers (kb / 8 16-byte loads per lane, all in flight at once; a row's consecutive 32-byte pieces
+// meet in the L2 line they share), the few A rows come through LDS, one 32 x 32 MFMA tile per wave and row tile, raw partial
+// sums per k-slice; k_splitk_reduce_f32 adds the slices in fixed order and applies scale / shift.  The split depends on
+// (N, K) only, so a row's result does not depend on the size of the call.
+#define SK_COLS 128
+#define SK_KB_MAX 256
+__global__ __launch_bounds__(256) void k_gemm_f32_skinny(const float* __restrict__ A, const float* __restrict__ Wt, const int* __restrict__ d_count,
+                                                         int K, int N, int kb, float* __restrict__ partial, long long slab) {
+    __shared__ __attribute__((aligned(16))) float As[64 * (SK_KB_MAX + 4)];
+    const int M = *d_count;                                  // rows (boards) of this call, <= 64
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.x * SK_COLS + wave * 32, k0 = blockIdx.y * kb, stride = kb + 4;
+    // this lane's column: kb / 8 float4 of weights, k = k0 + 8 q + 4 half + {0..3}
+    const float* wrow = Wt + (size_t)(n0 + r32) * K + k0 + 4 * half;
+    f32x4 b[SK_KB_MAX / 8];
+#pragma unroll
+    for (int q = 0; q < SK_KB_MAX / 8; ++q)
+        if (q * 8 < kb) b[q] = *reinterpret_cast<const f32x4*>(wrow + 8 * q);
+    // A rows [0, 32 * tiles) x kb -> LDS (zero rows beyond M)
+    const int tiles = M > 32 ? 2 : 1, q4 = kb / 4;
+    for (int u = tid; u < tiles * 32 * q4; u += 256) {
+        const int m = u / q4, c = (u % q4) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < M) v = *reinterpret_cast<const f32x4*>(A + (size_t)m * K + k0 + c);
+        *reinterpret_cast<f32x4*>(&As[m * stride + c]) = v;
+    }
+    __syncthreads();
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const float* a0p = &As[r32 * stride + 4 * half];
+    const float* a1p = a0p + 32 * stride;
+#pragma unroll
+    for (int q = 0; q < SK_KB_MAX / 8; ++q) {
+        if (q * 8 < kb) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[q][j], acc0, 0, 0, 0);
+            if (tiles == 2) {
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + 8 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[q][j], acc1, 0, 0, 0);
+            }
+        }
+    }
+    float* outp = partial + (size_t)blockIdx.y * slab;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < M) outp[(size_t)m * N + n0 + r32] = acc0[r];
+        if (tiles == 2 && m + 32 < M) outp[(size_t)(m + 32) * N + n0 + r32] = acc1[r];
+    }
+}
+
 // out = act(sum over splits (fixed order) * scale + shift)
 __global__ __launch_bounds__(256) void k_splitk_reduce_f32(const float* __restrict__ partial, long long slab, int ksplit, int N, int P,
                                                            const int* __restrict__ d_count, const float* __restrict__ scale,
@@ -263,6 +321,22 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
     g.pixmajor = pm_env && taps == 9 && cap >= 2 * GM_BM && ((cap + GM_BM - 1) / GM_BM) * GM_BM <= cap + cap / 8;
     const int num_mt = g.pixmajor ? ((max_count + GM_BM - 1) / GM_BM) * Hout * Hout : (int)((Mmax + GM_BM - 1) / GM_BM);
     const int grid = ((num_mt + 7) / 8) * 8 * (N / GM_BN);
+    // dense layers on at most 64 rows: the weight-stream kernel (the capacity decides, a per-network constant)
+    static const bool skinny_env = !(getenv("OZ_GEMM_SKINNY") && atoi(getenv("OZ_GEMM_SKINNY")) == 0);
+    if (skinny_env && taps == 1 && partial && cap <= 64 && max_count <= 64 && Hout == 1 && g.K % 64 == 0 && N % SK_COLS == 0) {
+        int kb = SK_KB_MAX;
+        while (kb > 64 && (g.K % kb != 0 || (long long)(N / SK_COLS) * (g.K / kb) < 192)) kb /= 2;
+        const int ks = g.K / kb;
+        if ((long long)ks * max_count * N <= partial_floats) {
+            const long long slab = (long long)max_count * N;
+            hipLaunchKernelGGL(k_gemm_f32_skinny, dim3(N / SK_COLS, ks), dim3(256), 0, s, in, Wt, d_count, g.K, N, kb, partial, slab);
+            const long long quads = (slab + 3) / 4;
+            hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, partial, slab, ks, N, 1, d_count, scale,
+                               shift, relu, out);
+            OZ_HIP(hipGetLastError());
+            return OZ_OK;
+        }
+    }
     int ksplit = 1;
     const int nk = g.K / GM_BK;
     if (partial && !g.pixmajor) {
