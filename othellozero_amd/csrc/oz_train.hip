@@ -851,8 +851,8 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
         }
         // weight gradient
         if (l == 0) {
-            int S1 = 8;                                    // row splits: ~64 rows per thread, at most RED_S (the partial buffer's capacity)
-            while (S1 < RED_S && (long long)B * A > 64LL * S1) S1 *= 2;
+            int S1 = 8;                                    // row splits: ~16 rows per thread (each a dependent ~1 us load at small batch), at most RED_S (the partial buffer's capacity)
+            while (S1 < RED_S && (long long)B * A > 16LL * S1) S1 *= 2;
             hipLaunchKernelGGL(k_t_conv1_wgrad, dim3((C + 255) / 256, S1), dim3(256), 0, s, t->d_own, t->d_opp, t->d_count, n, C, t->cin,
                                t->dz[0], t->partial, S1);
             const long long cnt = 9LL * t->cin * C;
