@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 run() { # name, rocprof args..., then bench args
   local name=$1; shift
-  timeout -k 10 500 rocprofv3 "$@" --output-format csv -d $OUT/$name -o run -- python3 bench.py --precision $PREC --no-cpu-baseline --no-compare $EXTRA $BENCH_ARGS > $OUT/$name.log 2>&1
+  timeout -k 10 300 rocprofv3 "$@" --output-format csv -d $OUT/$name -o run -- python3 bench.py --precision $PREC --no-cpu-baseline --no-compare $EXTRA $BENCH_ARGS > $OUT/$name.log 2>&1
   echo "$name done"
 }
 BENCH_ARGS="" run trace --kernel-trace --stats          # the default command: staggered slots, 2 warm-up + 20 timed move rounds
