@@ -192,9 +192,9 @@ __device__ __forceinline__ int select_body(const MctsDev& t, TreeLds& L, int g, 
     int depth = 0, status, tval = 0, err = 0, fs = -1;
     int node = unii(t.root_node[g]);                            // record index of the state we stand on, -1 = unknown
     int pnode = -1, prank = 0;                                  // the edge we arrived through (to cache the child index)
-    uint64_t legal;
+    uint64_t legal = oz_legal(own, opp, t.valid);
     for (;;) {
-        legal = oz_legal(own, opp, t.valid);
+        // `legal` = the mover's legal set of the state we stand on (of the root above; below, the move that led here computed it)
         if (legal == 0 && oz_legal(opp, own, t.valid) == 0) {       // is_terminal_state, othelo_mcts.py:28-29
             // get_state_reward: winner of the ch0 view, draw -> ch0; simulate returns -reward
             tval = oz_popc(own) >= oz_popc(opp) ? -1 : 1;
@@ -240,7 +240,10 @@ __device__ __forceinline__ int select_body(const MctsDev& t, TreeLds& L, int g, 
         pnode = node; prank = brank;
         node = lane_get(child, best);
         oz_apply(own, opp, best);
-        if (oz_legal(opp, own, t.valid) != 0) { uint64_t s = own; own = opp; opp = s; }   // swap only if the opponent can move
+        // swap only if the opponent can move (othelo_mcts.py:43-49); its legal set IS the next state's -- one flood per level, not two
+        const uint64_t theirs = oz_legal(opp, own, t.valid);
+        if (theirs != 0) { uint64_t s = own; own = opp; opp = s; legal = theirs; }
+        else legal = oz_legal(own, opp, t.valid);                   // pass (or the game is over): the same side is to move again
     }
     __syncthreads();
     if (lane < depth) t.path[(size_t)g * OZ_MAX_DEPTH + lane] = L.path[lane];            // the frontier, one coalesced store
