@@ -27,7 +27,7 @@ extern "C" {
 #define OZ_OK 0
 #define OZ_ERR_HIP 1       /* a HIP runtime call failed                         */
 #define OZ_ERR_ARG 2       /* bad argument                                      */
-#define OZ_ERR_CAPACITY 3  /* a per-game node/edge table overflowed             */
+#define OZ_ERR_CAPACITY 3  /* a per-game node table / record buffer overflowed      */
 #define OZ_ERR_KEY 4       /* the reference would raise KeyError here           */
 #define OZ_ERR_STATE 5     /* call sequence error                               */
 
@@ -107,6 +107,8 @@ int oz_net_set_tables(oz_net* net, int mode);
  * OthelloMCTS / MCTS (othelo_mcts.py:9-88, MCTS/__init__.py:19-187): num_games independent
  * instances, one wavefront per instance, tables resident in HBM. */
 typedef struct oz_mcts oz_mcts;
+/* node_cap: states per instance (each a fixed-stride record: header + one 24-byte edge per legal move, 1024 B on 8x8);
+ * edge_cap: kept for ABI stability, unused since the edges live inside the node records (round 2) */
 int oz_mcts_create(oz_mcts** out, int n, int num_games, int node_cap, int edge_cap, double c, int q_mode);
 int oz_mcts_destroy(oz_mcts* m);
 int oz_mcts_reset(oz_mcts* m, int game /* -1 = all */);                 /* fresh OthelloMCTS() */
@@ -147,7 +149,7 @@ typedef struct {
     uint64_t game_id_stride;/* id step when a slot is refilled (world_size*num_games) */
     int32_t refill;         /* 1: a finished slot immediately starts a new game */
     int32_t node_cap;       /* per-game node table capacity (0 = sims*61+64) */
-    int32_t edge_cap;       /* per-game edge pool capacity (0 = node_cap*14) */
+    int32_t edge_cap;       /* unused (edges live inside the node records); kept for ABI stability */
     int32_t record_cap;     /* move records kept for export (0 = num_games*64*4) */
 } oz_selfplay_config;
 
