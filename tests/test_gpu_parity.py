@@ -935,3 +935,28 @@ def test_bench_launches_its_own_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 0 and out["config"]["backend"] == "gloo"
     assert out["games_completed"] > 0 and out["pooled_records"] >= 28 * out["games_completed"] and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_worker_side_driver_functions_behave_like_the_reference(oz):
+    """training.duel_between_neural_networks / evaluate_neural_network (training.py:75-118; workers.py:14-15 imports them next
+    to execute_episode): the reference hands the (agent, points) tuple of duel_between_agents on as if it were the agent --
+    the first raises KeyError, the second never counts a win (tests/golden/drivers_misc.json, written by running the
+    reference).  The mirror does the same by default; fixed=True gives the evident intent."""
+    import json
+    import os
+    from othellozero_amd import training
+    from othellozero_amd.agents import RandomOthelloAgent
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "drivers_misc.json")))
+    n, sims = 4, 6
+    a, b = PyStubNet(n, 5, 0, True), PyStubNet(n, 6, 0, True)
+    assert want["duel_between_neural_networks"] == {"raises": "KeyError"}
+    with pytest.raises(KeyError):
+        training.duel_between_neural_networks(n, a, b, 1, sims)
+    assert training.duel_between_neural_networks(n, a, b, 1, sims, fixed=True) in (0, 1)
+    random.seed(2); np.random.seed(2)
+    assert training.evaluate_neural_network(n, want["evaluate_neural_network"]["iterations"], a, sims, 1, RandomOthelloAgent, ()) \
+        == want["evaluate_neural_network"]["returns"] == 0
+    random.seed(2); np.random.seed(2)
+    wins = training.evaluate_neural_network(n, 5, a, sims, 1, RandomOthelloAgent, (), fixed=True)
+    assert 0 <= wins <= 5
