@@ -106,6 +106,11 @@ class OthelloGame:
             self._flat_view = (self._round, OthelloGame.convert_to_one_channel_board(self._board))
         return self._flat_view[1]
 
+    def is_square_free(self, x, y):
+        """Othello/__init__.py:88-98.  (The reference's body reads the undefined names `row` / `col` and raises NameError;
+        the mirror answers the question its docstring asks.)"""
+        return OthelloGame.is_board_square_free(self._board, x, y)
+
     def is_valid_action(self, row, col):
         return OthelloGame.is_valid_player_action(self._board, self.current_player, row, col)
 
@@ -144,6 +149,24 @@ class OthelloGame:
         b[lo, hi, 0] = b[hi, lo, 0] = True          # BLACK on the anti-diagonal of the centre (Othello:177-184)
         b[lo, lo, 1] = b[hi, hi, 1] = True          # WHITE on the diagonal
         return b
+
+    ALL_DIRECTIONS = np.array([(1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1)])    # Othello/__init__.py:27 (same order)
+
+    @staticmethod
+    def get_all_directions_squares(board_size, row, col):
+        """Othello/__init__.py:186-189: one generator of squares per direction (host-side geometry; the kernels walk rays as bit shifts)"""
+        for direction in OthelloGame.ALL_DIRECTIONS:
+            yield OthelloGame.get_direction_squares(board_size, direction, row, col)
+
+    @staticmethod
+    def get_direction_squares(board_size, direction, row, col):
+        """Othello/__init__.py:191-198"""
+        row_offset, col_offset = direction
+        row, col = row + row_offset, col + col_offset
+        while 0 <= row < board_size and 0 <= col < board_size:
+            yield row, col
+            row += row_offset
+            col += col_offset
 
     @staticmethod
     def get_board_free_squares(board):

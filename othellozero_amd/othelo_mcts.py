@@ -137,6 +137,45 @@ class OthelloMCTS:
             probabilities[row, col] = int(cnt[row * 8 + col]) ** (1 / temperature)
         return probabilities / (np.sum(probabilities) or 1)
 
+    # ---- the MCTS template hooks of the reference (othelo_mcts.py:28-49,69-88).  The search itself runs in the library
+    # (k_select / k_expand_backup restate these per wavefront); the methods are kept for callers that use them directly.
+    def is_terminal_state(self, state):
+        return OthelloGame.has_board_finished(state)
+
+    def get_state_reward(self, state):
+        return OthelloGame.get_board_winning_player(state)[0].value
+
+    def get_next_state(self, state, action):
+        board = np.copy(state)
+        OthelloGame.flip_board_squares(board, OthelloPlayer.BLACK, *action)
+        if OthelloGame.has_player_actions_on_board(board, OthelloPlayer.WHITE):
+            board = OthelloGame.invert_board(board)            # keep the mover in channel 0
+        return board
+
+    def _neural_network_predict(self, state):
+        key = _lib.pack_board(state)                           # exact board equality, what hash(sha1(bytes)) stands for
+        cache = self.__dict__.setdefault("_predict_cache", {})
+        if key not in cache:
+            if self._one_channel:
+                state = OthelloGame.convert_to_one_channel_board(state)
+            cache[key] = self._neural_network.predict(state)
+        return cache[key]
+
+    def get_state_value(self, state):
+        return self._neural_network_predict(state)[1]
+
+    def get_state_actions_propabilities(self, state):
+        return self._neural_network_predict(state)[0]
+
+    def _mask_valid_moves(self, state):
+        board_mask = np.zeros((self._board_size, self._board_size))
+        for row, col in self.get_state_actions(state):
+            board_mask[row, col] = 1
+        return board_mask
+
+    def moves_scaled_by_valid_moves(self, state):
+        return self.get_state_actions_propabilities(state) * self._mask_valid_moves(state)
+
     # ---- inspection (parity tests)
     def dump(self):
         lib = _lib.load()

@@ -960,3 +960,34 @@ def test_worker_side_driver_functions_behave_like_the_reference(oz):
     random.seed(2); np.random.seed(2)
     wins = training.evaluate_neural_network(n, 5, a, sims, 1, RandomOthelloAgent, (), fixed=True)
     assert 0 <= wins <= 5
+
+
+@pytest.mark.gpu
+def test_mcts_template_hooks_and_geometry_helpers(oz, golden_rules):
+    """the MCTS template hooks OthelloMCTS overrides in the reference (othelo_mcts.py:28-49,69-88) and OthelloGame's ray
+    helpers (Othello/__init__.py:186-198) answer like the search kernels do: next state / terminal / reward against the
+    golden transitions, the masked policy against the expanded node's P row"""
+    from othellozero_amd.Othello import BoardView, OthelloGame, OthelloPlayer
+    from othellozero_amd.othelo_mcts import OthelloMCTS
+    n = 6
+    net = PyStubNet(n, 3, 0, True)
+    m = OthelloMCTS(n, net, 1.0, q_mode=1)
+    g = OthelloGame(n)
+    state = g.board(BoardView.TWO_CHANNELS)
+    acts = m.get_state_actions(state)
+    assert acts == [tuple(int(x) for x in a) for a in OthelloGame.get_player_valid_actions(state, OthelloPlayer.BLACK)]
+    assert not m.is_terminal_state(state) and m.get_state_reward(state) in (1, -1)
+    nxt = m.get_next_state(state, acts[0])
+    assert nxt.shape == state.shape and nxt.sum() == state.sum() + 1 and not np.shares_memory(nxt, state)
+    # the opponent can move after the first ply: channels swapped, so the mover's discs (channel 0) are the 1 disc WHITE kept
+    assert nxt[:, :, 0].sum() == 1 and nxt[:, :, 1].sum() == 4
+    p = m.moves_scaled_by_valid_moves(state)
+    mask = m._mask_valid_moves(state)
+    assert p.shape == (n, n) and np.all((p > 0) <= (mask > 0)) and mask.sum() == len(acts)
+    assert net.calls == 1 and m.get_state_value(state) == net.predict(state)[1] and net.calls == 2     # the second came from this line, not the cache miss
+    m.simulate(state, OthelloPlayer.BLACK)
+    root = m.dump()[0]
+    assert np.allclose(root["P"].reshape(8, 8)[:n, :n], p / p.sum(), rtol=0, atol=0)                   # the expanded node's P row = normalised masked policy
+    rays = [list(r) for r in OthelloGame.get_all_directions_squares(n, 2, 3)]
+    assert len(rays) == 8 and rays[0] == [(3, 4), (4, 5)] and rays[5] == [(1, 3), (0, 3)]
+    assert g.is_square_free(0, 0) and not g.is_square_free(n // 2, n // 2)
