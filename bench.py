@@ -221,7 +221,10 @@ def dropin_config0(channels, precision):
     from othellozero_amd.NNet import NNetWrapper
     from othellozero_amd.weights import init_weights
     n, sims = 8, 25
-    net = NNetWrapper((n, n), num_channels_1=channels, max_batch=1, seed=0, precision=precision)
+    # the network a drop-in caller gets: NNetWrapper's defaults (max_batch 1 = the library's latency path; exact fp32 arithmetic,
+    # which is also the faster one for a single position: its layers of <= 64 rows run as weight streams)
+    net = NNetWrapper((n, n), num_channels_1=channels, max_batch=1, seed=0)
+    precision = net.precision
     random.seed(0); np.random.seed(0)
     training.execute_episode(n, net, 1, 2, 1, 0.9)                 # untimed: first-call allocations, code object load
     random.seed(1); np.random.seed(1)
@@ -239,7 +242,8 @@ def dropin_config0(channels, precision):
     return {"workload": "BASELINE configs[0]: one 8x8 self-play game, 25 sims/move, random-init OthelloNN, through the reference's "
                         "execute_episode / OthelloMCTS / NNetWrapper.predict surface (one position per call)",
             "gpu_dropin": {"seconds": t_gpu, "moves": moves, "sims": moves * sims, "sims_per_s": moves * sims / t_gpu, "games_per_s": 1.0 / t_gpu,
-                           "path": "Python drop-in over the C ABI: per simulation one select + one predict (latency kernels, 16-way split-K) + one backup call"},
+                           "precision": precision,
+                           "path": "Python drop-in over the C ABI: OthelloMCTS.simulate -> select + NNetWrapper.predict (latency kernels: one position per call) + backup"},
             "cpu_port": {"seconds": t_cpu, "moves": int(ep["n_moves"]), "sims": int(ep["n_moves"]) * sims, "expansions": int(ep["stats"]["expansions"]),
                          "sims_per_s": int(ep["n_moves"]) * sims / t_cpu, "games_per_s": 1.0 / t_cpu, "cores": threads, "kind": "port"}}
 

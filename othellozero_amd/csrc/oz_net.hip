@@ -234,9 +234,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
 #define SK_COLS 128
 #define SK_KB_MAX 256
 __global__ __launch_bounds__(256) void k_gemm_f32_skinny(const float* __restrict__ A, const float* __restrict__ Wt, const int* __restrict__ d_count,
-                                                         int K, int N, int kb, float* __restrict__ partial, long long slab) {
+                                                         int K, int N, int kb, float* __restrict__ partial, long long slab, GemmGeom g) {
     __shared__ __attribute__((aligned(16))) float As[64 * (SK_KB_MAX + 4)];
-    const int M = *d_count;                                  // rows (boards) of this call, <= 64
+    const int P = g.Hout * g.Hout;
+    const int M = *d_count * P;                              // rows of this call: boards (dense) or boards x output pixels (3x3 conv), <= 64
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, half = lane >> 5;
     const int n0 = blockIdx.x * SK_COLS + wave * 32, k0 = blockIdx.y * kb, stride = kb + 4;
     // this lane's column: kb / 8 float4 of weights, k = k0 + 8 q + 4 half + {0..3}
@@ -247,10 +248,16 @@ __global__ __launch_bounds__(256) void k_gemm_f32_skinny(const float* __restrict
         if (q * 8 < kb) b[q] = *reinterpret_cast<const f32x4*>(wrow + 8 * q);
     // A rows [0, 32 * tiles) x kb -> LDS (zero rows beyond M)
     const int tiles = M > 32 ? 2 : 1, q4 = kb / 4;
+    // (a k-slice lies inside ONE tap of a 3x3 layer: kb divides Cin; row m of a convolution reads input pixel (oy - pad + dy, ox - pad + dx))
+    const int tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin, dy = g.taps == 9 ? tap / 3 : 0, dx = g.taps == 9 ? tap % 3 : 0;
     for (int u = tid; u < tiles * 32 * q4; u += 256) {
         const int m = u / q4, c = (u % q4) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < M) v = *reinterpret_cast<const f32x4*>(A + (size_t)m * K + k0 + c);
+        if (m < M) {
+            const int b = m / P, pix = m - b * P, iy = pix / g.Hout - g.pad + dy, ix = pix % g.Hout - g.pad + dx;
+            if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Hin)
+                v = *reinterpret_cast<const f32x4*>(A + (((size_t)b * g.Hin + iy) * g.Hin + ix) * g.Cin + ci0 + c);
+        }
         *reinterpret_cast<f32x4*>(&As[m * stride + c]) = v;
     }
     __syncthreads();
@@ -327,15 +334,17 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
     const int grid = ((num_mt + 7) / 8) * 8 * (N / GM_BN);
     // dense layers on at most 64 rows: the weight-stream kernel (the capacity decides, a per-network constant)
     static const bool skinny_env = !(getenv("OZ_GEMM_SKINNY") && atoi(getenv("OZ_GEMM_SKINNY")) == 0);
-    if (skinny_env && taps == 1 && partial && cap <= 64 && max_count <= 64 && Hout == 1 && g.K % 64 == 0 && N % SK_COLS == 0) {
+    const int Pout = Hout * Hout;
+    if (skinny_env && partial && (long long)cap * Pout <= 64 && (long long)max_count * Pout <= 64 && Cin % 64 == 0 && N % SK_COLS == 0) {
         int kb = SK_KB_MAX;
-        while (kb > 64 && (g.K % kb != 0 || (long long)(N / SK_COLS) * (g.K / kb) < 192)) kb /= 2;
+        while (kb > 64 && (Cin % kb != 0 || (long long)(N / SK_COLS) * (g.K / kb) < 192)) kb /= 2;
         const int ks = g.K / kb;
-        if ((long long)ks * max_count * N <= partial_floats) {
-            const long long slab = (long long)max_count * N;
-            hipLaunchKernelGGL(k_gemm_f32_skinny, dim3(N / SK_COLS, ks), dim3(256), 0, s, in, Wt, d_count, g.K, N, kb, partial, slab);
+        if ((long long)ks * max_count * Pout * N <= partial_floats) {
+            const long long slab = (long long)max_count * Pout * N;
+            g.ksplit = ks; g.slab = slab; g.pixmajor = 0;
+            hipLaunchKernelGGL(k_gemm_f32_skinny, dim3(N / SK_COLS, ks), dim3(256), 0, s, in, Wt, d_count, g.K, N, kb, partial, slab, g);
             const long long quads = (slab + 3) / 4;
-            hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, partial, slab, ks, N, 1, d_count, scale,
+            hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, partial, slab, ks, N, Pout, d_count, scale,
                                shift, relu, out);
             OZ_HIP(hipGetLastError());
             return OZ_OK;
@@ -526,11 +535,16 @@ struct OnnNet : oz_net {
                     int Hout, int pad, int Cin, int taps, int N, hipStream_t s) {
         // small and medium networks (max_batch <= 512) split K over the idle CUs: latency, not throughput
         return oz_gemm_f32_launch(in, Wt, d_scale[layer], d_shift[layer], out, d_count, max_count, Hin, Hout, pad, Cin, taps, N, 1, s,
-                                  d_part32, d_part32 ? (long long)part32_mult() * max_batch * 64 * 512 : 0, max_batch);
+                                  d_part32, d_part32 ? (long long)part32_floats() : 0, max_batch);
     }
 
     // precision f32: split-K slabs per position-row budget (small networks 16 slices, medium ones fewer; none for large batches)
     int part32_mult() const { return max_batch <= 32 ? 16 : max_batch <= 128 ? 8 : max_batch <= 512 ? 2 : 0; }
+    // ... in floats; layers of at most 64 rows run as weight streams with up to K / 64 = 128 k-slices of 64 rows x 1024 columns
+    size_t part32_floats() const {
+        const size_t split = (size_t)part32_mult() * max_batch * 64 * 512, stream = max_batch <= 64 ? (size_t)128 * 64 * 1024 : 0;
+        return split > stream ? split : stream;
+    }
     // k-split of a 3x3 convolution on BM-row tiles (N = C, 256-column tiles): the smallest power of two <= 8 that brings
     // the grid to >= 192 blocks, from max_batch (a per-network constant, so results do not depend on the size of a call)
     int conv_ksplit(int pixels, int BM) const {
@@ -927,7 +941,7 @@ OZ_API int oz_net_commit(oz_net* net) {
         if (!o->d_raw) { if (int rc = o->alloc(&o->d_raw, raw_max)) return rc; }
     }
     if (o->precision == 0 && !o->d_part32 && o->part32_mult() > 0) {
-        if (int rc = o->alloc(&o->d_part32, (size_t)o->part32_mult() * o->max_batch * 64 * 512)) return rc;
+        if (int rc = o->alloc(&o->d_part32, o->part32_floats())) return rc;
     }
     for (int i = 0; i < 5; ++i) {
         const auto& src = o->w[gl[i]];
