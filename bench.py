@@ -123,7 +123,8 @@ def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tabl
     for name, (ms, cnt) in tree_k.items():
         if name == "network" or cnt == 0:
             continue
-        out.append({"name": name, "kernel": {"select": "k_select", "compact": "k_compact", "expand_backup": "k_expand_backup",
+        out.append({"name": name, "kernel": {"select": "k_select (first simulation of a round) / k_backup_select (expand + backup of simulation s-1 fused with the descent of s)",
+                                             "compact": "k_compact", "expand_backup": "k_expand_backup (closing one of a round)",
                                              "roots_move": "k_sp_roots + k_sp_move"}[name],
                     "ms_per_step": ms / rounds, "launches_per_step": cnt / rounds, "bound": "hbm (latency-bound integer work)",
                     # the tree side as a whole moves ~1.3 KB of algorithmic HBM bytes per simulation; this kernel's share of it by time

@@ -445,6 +445,15 @@ __global__ __launch_bounds__(64) void k_expand_backup(MctsDev t, int slot_is_gam
     __shared__ TreeLds L;
     expand_backup_body(t, L, blockIdx.x, threadIdx.x, slot_is_game);
 }
+// expand + backup of simulation s-1 and the descent of simulation s in ONE launch (same wave, same game): one kernel boundary
+// less per simulation step, and the records the backup has just written are re-read by the descent while still in the CU's cache
+__global__ __launch_bounds__(64) void k_backup_select(MctsDev t) {
+    __shared__ TreeLds L;
+    expand_backup_body(t, L, blockIdx.x, threadIdx.x, 0);
+    wave_sync();                                           // the wave's own stores (records, child indices, table entry, root index) before its loads
+    __syncthreads();
+    select_body(t, L, blockIdx.x, threadIdx.x);
+}
 
 // ---------------------------------------------------------------- host object
 struct oz_mcts {
@@ -600,6 +609,38 @@ static int mcts_collect_eval_time(oz_mcts* m) {
     return OZ_OK;
 }
 
+// `nsims` lock-step simulations: descent | compaction | evaluator, then per further simulation the previous one's expand + backup
+// fused with the next descent (k_backup_select), and one closing expand + backup: nsims + 1 tree launches instead of 2 nsims.
+// OZ_FUSE_STEP=0 launches the two kernels separately (A/B runs); results are identical either way.
+static int mcts_steps_async(oz_mcts* m, oz_net* net, int nsims, bool time_eval) {
+    static const bool fuse = !(getenv("OZ_FUSE_STEP") && atoi(getenv("OZ_FUSE_STEP")) == 0);
+    if (!fuse || nsims < 2) {
+        for (int i = 0; i < nsims; ++i)
+            if (int rc = mcts_step_async(m, net, time_eval)) return rc;
+        return OZ_OK;
+    }
+    MctsDev& d = m->d;
+    hipStream_t s = m->stream;
+    const bool all = m->profile;
+    for (int k = 0; k < nsims; ++k) {
+        int i = all ? m->timer.begin(TS_SELECT, s) : -1;
+        if (k == 0) hipLaunchKernelGGL(k_select, dim3(d.G), dim3(64), 0, s, d);
+        else hipLaunchKernelGGL(k_backup_select, dim3(d.G), dim3(64), 0, s, d);
+        m->timer.end(i, s);
+        i = all ? m->timer.begin(TS_COMPACT, s) : -1;
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, d);
+        m->timer.end(i, s);
+        i = (time_eval || all) ? m->timer.begin(TS_NN, s) : -1;
+        if (int rc = oz_net_forward_device(net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, s)) { m->timer.cancel(i); return rc; }
+        m->timer.end(i, s);
+    }
+    const int i = all ? m->timer.begin(TS_BACKUP, s) : -1;
+    hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, s, d, 0);
+    m->timer.end(i, s);
+    OZ_HIP(hipGetLastError());
+    return OZ_OK;
+}
+
 OZ_API int oz_mcts_create(oz_mcts** out, int n, int num_games, int node_cap, int edge_cap, double c, int q_mode) {
     OZ_REQUIRE(out, "null out pointer");
     return mcts_create(out, n, num_games, node_cap, edge_cap, c, q_mode);
@@ -640,8 +681,7 @@ OZ_API int oz_mcts_simulate(oz_mcts* m, oz_net* net, int nsims) {
     std::lock_guard<std::mutex> lk(m->mu);
     std::lock_guard<std::mutex> lkn(net->mu);
     hipSetDevice(m->device);
-    for (int s = 0; s < nsims; ++s)
-        if (int rc = mcts_step_async(m, net, false)) return rc;
+    if (int rc = mcts_steps_async(m, net, nsims, false)) return rc;
     m->selected = false;
     return check_error_flag(m);
 }
@@ -1095,8 +1135,7 @@ static int selfplay_round_async(oz_selfplay* sp, int sims, int stagger_round) {
     if (stagger_round >= 0) hipLaunchKernelGGL(k_sp_roots_stagger, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, m->d, stagger_round, sp->stagger_period);
     else hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, m->d, 0);
     m->timer.end(ti, s);
-    for (int i = 0; i < sims; ++i)
-        if (int rc = mcts_step_async(m, sp->net, true)) return rc;
+    if (int rc = mcts_steps_async(m, sp->net, sims, true)) return rc;
     ti = m->profile ? m->timer.begin(TS_MOVE, s) : -1;
     hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, m->d, 0);
     m->timer.end(ti, s);
@@ -1385,11 +1424,11 @@ OZ_API int oz_arena_run(oz_arena* a) {
         if (a->nb) hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, mb->d, -1);
         if (a->na) {
             std::lock_guard<std::mutex> la(a->na->mu);
-            for (int i = 0; i < a->sims && !rc; ++i) rc = mcts_step_async(ma, a->na, false);
+            rc = mcts_steps_async(ma, a->na, a->sims, false);
         }
         if (!rc && a->nb) {
             std::lock_guard<std::mutex> lb(a->nb->mu);
-            for (int i = 0; i < a->sims && !rc; ++i) rc = mcts_step_async(mb, a->nb, false);
+            rc = mcts_steps_async(mb, a->nb, a->sims, false);
         }
         if (rc) break;
         if (a->na) hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, ma->d, 1);
