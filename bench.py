@@ -145,7 +145,7 @@ def tree_side(sims_per_s):
         tj = json.load(open(os.path.join(ROOT, "profiles", "tree_traffic.json")))
         t = tj["tree_side_bytes_per_sim"]
         r["measured"] = {"fetch_bytes_per_sim_raw": t["fetch_raw"], "fetch_bytes_per_sim_x2": t["fetch_x2"], "write_bytes_per_sim": t["write"],
-                         "k_select_fetch_bytes_per_sim_x2": tj["kernels"]["k_select"]["fetch_bytes_per_sim_x2"],
+                         "descent_kernel_fetch_bytes_per_sim_x2": (tj["kernels"].get("k_backup_select") or tj["kernels"]["k_select"])["fetch_bytes_per_sim_x2"],
                          "source": "profiles/tree_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, the 100 launches of one timed move round; "
                                    "x2 = the gfx950 rule for 16-byte-per-lane reads, an upper bound for this access mix); not re-measured in this run"}
     except Exception:

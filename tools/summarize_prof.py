@@ -126,12 +126,15 @@ def tree(src, out, games):
             vals[r["kernel"]][r["counter"]] = float(r["avg_per_launch"])
     j = {"round": 2, "simulations_per_launch": int(games), "algorithmic_bytes_per_sim": 1300, "source": src, "kernels": {}}
     tot_raw = tot_w = 0.0
-    for k in ("k_select", "k_expand_backup", "k_compact"):
-        if k not in vals:
+    # (k_backup_select = expand + backup of the previous simulation fused with the descent: 99 of the 100 launches of a round;
+    #  k_select / k_expand_backup = the first descent and the closing backup of a round, one launch each)
+    for k in ("k_backup_select", "k_select", "k_expand_backup", "k_compact"):
+        if k not in vals or "FETCH_SIZE" not in vals[k]:
             continue
         fr, wr = vals[k]["FETCH_SIZE"] * 1024 / int(games), vals[k]["WRITE_SIZE"] * 1024 / int(games)
         j["kernels"][k] = {"fetch_bytes_per_sim_raw": fr, "fetch_bytes_per_sim_x2": 2 * fr, "write_bytes_per_sim": wr}
-        tot_raw += fr; tot_w += wr
+        if k in ("k_backup_select", "k_compact"):               # the per-simulation kernels of a steady round
+            tot_raw += fr; tot_w += wr
     j["tree_side_bytes_per_sim"] = {"fetch_raw": tot_raw, "fetch_x2": 2 * tot_raw, "write": tot_w, "total_with_x2_fetch": 2 * tot_raw + tot_w}
     with open(out, "w") as f:
         json.dump(j, f, indent=1)
