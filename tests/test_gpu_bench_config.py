@@ -223,3 +223,19 @@ def test_config3_last_rank_shard_at_full_size(oz):
         ep = oracle.Mcts(n, 1.0, 1, salt=23).episode(sims, 1.0, 0.9, 1234, gid)
         assert np.array_equal(r["action"], ep["action"]) and np.array_equal(r["z"], ep["z"]), gid
         assert np.array_equal(r["black"], ep["black"]) and np.array_equal(r["white"], ep["white"]), gid
+
+
+def test_soak_two_generations_at_config2_size_vs_oracle(oz):
+    """tools/soak_check.py in small: 4096 concurrent 8x8 games x 100 sims with the device stub network, staggered start, 130
+    move rounds (every slot finishes its first game and most of a refilled one), 32 randomly sampled games -- first and second
+    generation, i.e. through table reset and slot refill -- equal the oracle's episodes move for move"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_check.py"), "--rounds", "130", "--sample", "32"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["mismatching_games"] == 0 and out["sampled"] == 32 and out["games_completed"] > 2 * 4096 - 200
