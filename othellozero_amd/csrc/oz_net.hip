@@ -558,7 +558,8 @@ struct OnnNet : oz_net {
         size_t need = (size_t)4 * max_batch * 1024;                                  // fc1
         const int px[3] = {n * n, (n - 2) * (n - 2), (n - 4) * (n - 4)}, bm[3] = {256, 192, 256};
         for (int i = 0; i < 3; ++i) {
-            const int k = conv_ksplit(px[i], bm[i]);
+            int k = conv_ksplit(px[i], bm[i]);
+            if (i == 1 && conv_ksplit(px[i], 256) > k) k = conv_ksplit(px[i], 256);          // conv3 may run on either tile
             if (k > 1 && (size_t)k * max_batch * px[i] * C > need) need = (size_t)k * max_batch * px[i] * C;
         }
         return need;
@@ -720,7 +721,11 @@ struct OnnNet : oz_net {
         // a per-network constant, so a position's result does not depend on the size of the call)
         // medium networks (arenas, evaluation batches, the loop's 100 episodes): a convolution whose grid would leave most
         // CUs idle splits its k loop (conv_ksplit: from max_batch, a per-network constant; 1 at the bench's 4096 games)
-        const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), 192), k4 = conv_ksplit((n - 4) * (n - 4), 256);
+        // conv3 tile: 192 rows on 8x8 (36 output pixels per board: 6.0 grid rounds at 4096 boards instead of 4.5); on 6x6 (16 pixels per board) the
+        // 256-row tile = 16 whole boards, 2.0 rounds instead of 2.7 (OZ_H2_CONV3_BIG=0 / 1 forces one: A/B runs)
+        static const int conv3_big_env = getenv("OZ_H2_CONV3_BIG") ? atoi(getenv("OZ_H2_CONV3_BIG")) : -1;
+        const bool conv3_big = conv3_big_env >= 0 ? conv3_big_env != 0 : n == 6;
+        const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), conv3_big ? 256 : 192), k4 = conv_ksplit((n - 4) * (n - 4), 256);
         mark(1, true);
         if (use_t2) {
             const long long threads = (long long)max_count * n * n * (C / 8);
@@ -737,6 +742,7 @@ struct OnnNet : oz_net {
         static const bool pp3 = getenv("OZ_H2_PP3") && atoi(getenv("OZ_H2_PP3")) != 0;
         if (int rc = small ? launch_small<H2Small, H2Small2>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, 16)
                      : pp && pp3 ? launch_gemm_h2<H2MidPP3>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
+                     : pp && conv3_big ? launch_gemm_h2<H2BigPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                      : pp  ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                            : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
         mark(2, false);
