@@ -35,10 +35,14 @@ def tensor_to_records(t):
     return a.view(RECORD_DTYPE).copy()
 
 
-def gather_records(local, group=None):
+def gather_records(local, group=None, single_rank_collective=False):
     """all-gather variable-length record tensors (uint8 [R_i, 48]) -> uint8 [sum R_i, 48] on every rank,
-    ordered by rank.  Counts are gathered first, payloads are padded to the per-rank maximum."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    ordered by rank.  Counts are gathered first, payloads are padded to the per-rank maximum.
+    A one-rank group returns `local` without a collective unless single_rank_collective is set (the one-GPU test of
+    the RCCL calls themselves)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    if dist.get_world_size(group) == 1 and not single_rank_collective:
         return local
     world = dist.get_world_size(group)
     dev = local.device
@@ -94,9 +98,10 @@ class GradientAllReduce:
 
     With the gloo backend (CPU rehearsal of the control flow) the arena is staged through host memory."""
 
-    def __init__(self, board_size, channels, in_channels=2, device="cuda", group=None):
+    def __init__(self, board_size, channels, in_channels=2, device="cuda", group=None, single_rank_collective=False):
         from .trainer import Trainer
         self.group = group
+        self.single_rank_collective = single_rank_collective    # run the all-reduce on a one-rank group too (one-GPU RCCL test)
         self.flat = torch.zeros(Trainer.arena_size(board_size, channels, in_channels), dtype=torch.float32, device=device)
         self.ptr = self.flat.data_ptr()
 
@@ -104,7 +109,7 @@ class GradientAllReduce:
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(self.group)
-        if world == 1:
+        if world == 1 and not self.single_rank_collective:
             return
         trainer.sync()                                   # the library's stream wrote the arena
         if dist.get_backend(self.group) == "gloo" and self.flat.is_cuda:

@@ -276,6 +276,68 @@ def test_data_parallel_two_ranks_equal_hand_averaged_gradients(tmp_path):
         assert p.returncode == 0 and f"RANK_OK {rank}" in out, out
 
 
+RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from othellozero_amd import _lib
+from othellozero_amd.NNet import NNetWrapper
+from othellozero_amd.distributed import (GradientAllReduce, engine_records_tensor, gather_records, tensor_to_records)
+from othellozero_amd.trainer import Trainer
+from othellozero_amd.training import SelfPlayEngine
+from othellozero_amd.weights import init_weights
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)            # backend "nccl" = RCCL
+assert dist.get_backend() == "nccl"
+# the self-play exchange: the engine's records, device to device, through all_gather + all_gather_into_tensor on uint8
+n, C = 6, 128
+net = NNetWrapper((n, n), num_channels_1=C, max_batch=16, seed=0)
+eng = SelfPlayEngine(net, n, 16, 8, 1.0, 1.0, 0.9, seed=7, q_mode=_lib.QMODE_F64)
+own = eng.play_to_end()
+local = engine_records_tensor(eng, dev)
+pooled = gather_records(local, single_rank_collective=True)
+assert pooled.is_cuda and pooled.shape == local.shape and torch.equal(pooled, local)
+rec = tensor_to_records(pooled)
+key = lambda a: a[np.lexsort((a["ply"], a["game_id"]))].tobytes()
+assert len(rec) == len(own) and key(rec) == key(np.ascontiguousarray(own))
+empty = gather_records(local[:0], single_rank_collective=True)                  # a rank with no finished game
+assert empty.shape[0] == 0
+# the training exchange: one all-reduce over the gradient arena the backward kernels wrote, in place
+ar = GradientAllReduce(n, C, 2, device="cuda", single_rank_collective=True)
+tr = Trainer(n, C, 2, max_batch=8, seed=9, external_grads_ptr=ar.ptr)
+tr.set_weights(init_weights(n, seed=3, channels=C, randomize_all=True))
+rs = np.random.RandomState(1)
+valid = np.uint64(sum(1 << (y * 8 + x) for y in range(n) for x in range(n)))
+o = rs.randint(0, 2**63, size=8, dtype=np.uint64) & valid
+p = rs.randint(0, 2**63, size=8, dtype=np.uint64) & valid & ~o
+pi = np.zeros((8, n * n), np.float32); pi[np.arange(8), rs.randint(0, n * n, 8)] = 1
+tr.forward_backward(o, p, pi, rs.choice([-1.0, 1.0], 8).astype(np.float32))
+tr.sync()
+before = ar.flat.clone()
+assert float(before.abs().sum()) > 0
+ar(tr)                                                                           # sum over one rank / 1: the same bits
+assert torch.equal(ar.flat, before)
+tr.apply()
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+'''
+
+
+def test_rccl_calls_on_one_rank(tmp_path):
+    """the two RCCL exchanges (all-gather of move records, all-reduce of the gradient arena) driven through a one-rank
+    "nccl" process group on the card: the calls, dtypes and device buffers the N-GPU job uses, on the hardware this box has"""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_trained_network_in_split_precision_matches_float64():
     """after real optimiser steps (weights, biases and BN statistics no longer at their initial values) the f16x2 inference
     kernels still reproduce the float64 forward of the trained weights within the 1e-5 tolerance of the hot path"""
