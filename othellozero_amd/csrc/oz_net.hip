@@ -358,7 +358,8 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
         const long long Ms = (long long)(sizing_count > 0 ? sizing_count : max_count) * Hout * Hout;
         // blocks that have rows to work on (the grid is padded to a multiple of 8 row tiles for the XCD mapping; padding blocks exit at once)
         const int grid_s = (int)((Ms + GM_BM - 1) / GM_BM) * (N / GM_BN);
-        while (ksplit < 16 && grid_s * ksplit < 256 && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * (Ms > Mmax ? Ms : Mmax) * N <= partial_floats) ksplit *= 2;
+        static const int split_blocks = getenv("OZ_GEMM_SPLIT_BLOCKS") ? atoi(getenv("OZ_GEMM_SPLIT_BLOCKS")) : 256;     // A/B runs
+        while (ksplit < 16 && grid_s * ksplit < split_blocks && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * (Ms > Mmax ? Ms : Mmax) * N <= partial_floats) ksplit *= 2;
     }
     g.ksplit = ksplit; g.slab = Mmax * N;
     hipLaunchKernelGGL(k_gemm_f32, dim3(grid, ksplit), dim3(256), 0, s, in, Wt, scale, shift, out, d_count, g, num_mt, partial);

@@ -3,12 +3,14 @@
 // Replaces MCTS/__init__.py:19-187 + othelo_mcts.py:9-88 (search) and training.py:26-72,
 // agents.py:44-84 (drivers).  Design (MI355X-first, not a translation):
 //   * every game owns one OthelloMCTS instance = one open-addressing table keyed by the exact
-//     128-bit (own, opp) pair (replaces sha1, MCTS/__init__.py:7-16) plus SoA node / edge pools,
-//     all resident in HBM; nothing is rebuilt between moves (sub-tree / transposition reuse);
+//     128-bit (own, opp) pair (replaces sha1, MCTS/__init__.py:7-16) plus a pool of fixed-stride node
+//     records (header + visit / Q / P rows, see "tree storage"), all resident in HBM; nothing is rebuilt
+//     between moves (sub-tree / transposition reuse);
 //   * ONE WAVEFRONT PER GAME: lane == board square.  PUCT argmax (MCTS/__init__.py:65,168-170)
 //     is a 64-lane max-reduction + ballot, lowest lane wins ties (== Python's first maximum in
-//     ascending square order); table probes are 64-wide ballots; the backup walks all path levels
-//     in parallel (one lane per level);
+//     ascending square order); a node record reaches LDS in one wave-wide load and the descent's
+//     frontier stays in LDS; table probes are 64-wide ballots; the backup walks all path levels in
+//     parallel (one lane per level);
 //   * lock step: every active game advances exactly one simulation per step (simulations of one
 //     game are sequential in the reference; no virtual loss), leaves that need the network are
 //     compacted by ballot + prefix sum into one dense batch (deterministic slot order), evaluated

@@ -107,7 +107,7 @@ __global__ void k_t_sum_partials(const float* __restrict__ partial, int S, long 
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float a = 0.f;
-    for (int s = 0; s < S; ++s) a += partial[(size_t)s * count + i];
+    _Pragma("unroll 8") for (int s = 0; s < S; ++s) a += partial[(size_t)s * count + i];     // the loads are independent: 8 in flight, the adds stay in order
     out[i] = a;
 }
 
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_t_colreduce(RedArgs r, const int* __res
     f32x4 mu = s0, rs = s0;
     if (MODE == 1 || MODE == 2) mu = *reinterpret_cast<const f32x4*>(r.mean + c);
     if (MODE == 2) rs = *reinterpret_cast<const f32x4*>(r.rstd + c);
-    for (long long m = (long long)sp * rpp + rsub; m < M; m += (long long)RED_S * rpp) {
+    for (long long m = (long long)sp * rpp + rsub; m < M; m += (long long)gridDim.y * rpp) {      // gridDim.y row splits (RED_S for the streaming passes)
         const size_t o = (size_t)m * r.C + c;
         if (MODE == 0) s0 += *reinterpret_cast<const f32x4*>(r.x + o);
         if (MODE == 1) {
@@ -576,6 +576,9 @@ struct oz_trainer {
     float* wpartial = nullptr;           // row-split scratch of the weight-gradient launches (they run on s2, beside the data-gradient chain)
     hipStream_t s2 = nullptr;
     hipEvent_t ev_dz[6] = {}, ev_w = nullptr;
+    hipEvent_t ev_pre = nullptr, ev_wt = nullptr, ev_wd = nullptr;      // derived weight operands are rebuilt on s2 beside the first forward kernels
+    bool wait_wt = false, wait_wd = false;
+    float* bnb2[6] = {};                 // per-layer row-block partials of the bias gradient (mid-size BN backward)
     bool overlap = true;                 // env OZ_TRAIN_OVERLAP=0: weight gradients on the main stream
     long long gpartial_floats = 40LL << 20;      // 160 MB each: 16 row-split slabs of a 3x3 x 512 x 512 weight gradient
     bool wconv_attr = false;
@@ -598,6 +601,7 @@ struct oz_trainer {
         for (void* q : {(void*)ds_own, (void*)ds_opp, (void*)ds_pi, (void*)ds_z, (void*)ds_order, (void*)ds_acc}) if (q) hipFree(q);
         for (hipEvent_t e : ev_dz) if (e) hipEventDestroy(e);
         if (ev_w) hipEventDestroy(ev_w);
+        for (hipEvent_t e : {ev_pre, ev_wt, ev_wd}) if (e) hipEventDestroy(e);
         if (s2) hipStreamDestroy(s2);
         if (s) hipStreamDestroy(s);
     }
@@ -686,6 +690,8 @@ OZ_API int oz_trainer_create(oz_trainer** out, int n, int channels, int in_chann
         OZ_HIP(hipStreamCreateWithFlags(&t->s2, hipStreamNonBlocking));
         for (int l = 0; l < 6; ++l) OZ_HIP(hipEventCreateWithFlags(&t->ev_dz[l], hipEventDisableTiming));
         OZ_HIP(hipEventCreateWithFlags(&t->ev_w, hipEventDisableTiming));
+        for (hipEvent_t* e : {&t->ev_pre, &t->ev_wt, &t->ev_wd}) OZ_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (int l = 0; l < 6; ++l) T_ALLOC(t->bnb2[l], (size_t)OZ_BNB_MAX_RB * t->Co[l]);
         { const char* e = getenv("OZ_TRAIN_OVERLAP"); t->overlap = !(e && atoi(e) == 0); }
         OZ_HIP(hipStreamSynchronize(t->s));
         return OZ_OK;
@@ -750,18 +756,32 @@ OZ_API int oz_trainer_step_count(oz_trainer* t, int64_t* step) {
     return OZ_OK;
 }
 
+// The weights changed (optimiser step, set_weight): rebuild the GEMM operands derived from them.  With the second stream
+// available the eight launches run THERE, after everything already queued on the main stream (the optimiser step that wrote
+// the weights, the previous step's readers of Wt / Wd), and the main stream only waits where it first needs them -- the
+// forward operands before conv2's GEMM, the data-gradient operands before conv4's dgrad -- so the uploads, conv1 and its BN
+// run beside them instead of behind them (~70 us of a 1.4 ms step at batch 32).
 static int t_refresh(oz_trainer* t) {
     const int C = t->C, F = (t->n - 4) * (t->n - 4) * C;
     const int Ks[6] = {0, 9 * C, 9 * C, 9 * C, F, 1024}, Ns[6] = {0, C, C, C, 1024, 512};
+    hipStream_t r = t->s;
+    if (t->overlap) {
+        OZ_HIP(hipEventRecord(t->ev_pre, t->s));
+        OZ_HIP(hipStreamWaitEvent(t->s2, t->ev_pre, 0));
+        r = t->s2;
+    }
     for (int l = 1; l < 6; ++l) {
-        hipLaunchKernelGGL(k_t_transpose, dim3((Ns[l] + 31) / 32, (Ks[l] + 31) / 32), dim3(256), 0, t->s, t->param(6 * l), Ks[l], Ns[l], t->Wt[l]);
+        hipLaunchKernelGGL(k_t_transpose, dim3((Ns[l] + 31) / 32, (Ks[l] + 31) / 32), dim3(256), 0, r, t->param(6 * l), Ks[l], Ns[l], t->Wt[l]);
         OZ_HIP(hipGetLastError());
     }
+    if (t->overlap) OZ_HIP(hipEventRecord(t->ev_wt, r));
     for (int l = 1; l < 4; ++l) {
         const long long cnt = 9LL * C * C;
-        hipLaunchKernelGGL(k_t_dgrad_operand, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, t->s, t->param(6 * l), C, C, t->Wd[l]);
+        hipLaunchKernelGGL(k_t_dgrad_operand, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, r, t->param(6 * l), C, C, t->Wd[l]);
         OZ_HIP(hipGetLastError());
     }
+    if (t->overlap) OZ_HIP(hipEventRecord(t->ev_wd, r));
+    t->wait_wt = t->wait_wd = t->overlap;
     t->dirty = false;
     return OZ_OK;
 }
@@ -811,6 +831,7 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
       OZ_HIP(hipGetLastError()); }
     if (int rc = t_bn_forward(t, 0, B)) return rc;
     const int Hin[6] = {n, n, n, n - 2, 1, 1}, pad[6] = {1, 1, 0, 0, 0, 0}, Cin[6] = {t->cin, C, C, C, F, 1024}, taps[6] = {9, 9, 9, 9, 1, 1};
+    if (t->wait_wt) { OZ_HIP(hipStreamWaitEvent(s, t->ev_wt, 0)); t->wait_wt = false; }
     for (int l = 1; l < 6; ++l) {
         if (int rc = oz_gemm_f32_launch(t->a[l - 1], t->Wt[l], t->ones, t->param(6 * l + 1), t->z[l], t->d_count, B, Hin[l], t->Hout[l], pad[l],
                                         Cin[l], taps[l], t->Co[l], 0, s, t->gpartial, (t->split_mask & 1) ? t->gpartial_floats : 0)) return rc;
@@ -830,7 +851,26 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
     for (int l = 5; l >= 0; --l) {
         const int Cc = t->Co[l], P = t->P_[l];
         const float post = l >= 4 && t->rate > 0.f ? 1.0f / (1.0f - t->rate) : 1.0f;
-        if ((long long)B * P <= OZ_BN_FUSED_MAX_ROWS) {  // small batch: BN backward, dgamma / dbeta / bias gradient in one launch
+        static const bool bnb_split = !(getenv("OZ_BN_BWD_SPLIT") && atoi(getenv("OZ_BN_BWD_SPLIT")) == 0);
+        if (bnb_split && (long long)B * P > OZ_BNB_MIN_ROWS && (long long)B * P <= OZ_BNB_MAX_ROWS) {
+            // mid-size: partial sums over row splits, then one launch that finishes the sums and writes dz (oz_train_fused.h)
+            const long long M = (long long)B * P;
+            const int Q = Cc / 4, lpr = Q < 64 ? Q : 64, rpp = 256 / lpr;
+            int RS = 16; while (RS < OZ_BNB_MAX_RB && M > (long long)RS * rpp * 8) RS *= 2;          // ~8 rows per thread
+            RedArgs r = {}; r.x = t->dA[cur]; r.a = t->a[l]; r.z = t->z[l]; r.mean = t->mean[l]; r.rstd = t->rstd[l]; r.post_scale = post; r.P = P; r.C = Cc;
+            hipLaunchKernelGGL(k_t_colreduce<2>, dim3((Q + 63) / 64, RS), dim3(256), 0, s, r, t->d_count, t->partial);
+            hipLaunchKernelGGL(k_t_bnb_apply, dim3((Q + 63) / 64, RS), dim3(256), 0, s, t->dA[cur], t->a[l], t->z[l], t->mean[l], t->rstd[l], t->param(6 * l + 2),
+                               post, t->d_count, t->Hout[l], Cc, t->Hz[l], t->zoff[l], t->partial, RS, t->dz[l], t->grad(6 * l + 2), t->grad(6 * l + 3), t->bnb2[l]);
+            // the bias gradient (column sums of dz) is off the dgrad chain: finished beside it
+            hipStream_t sb = s;
+            if (t->overlap && l > 0) {
+                OZ_HIP(hipEventRecord(t->ev_dz[l], s));
+                OZ_HIP(hipStreamWaitEvent(t->s2, t->ev_dz[l], 0));
+                sb = t->s2;
+            }
+            hipLaunchKernelGGL(k_t_sum_partials, dim3((unsigned)((Cc + 255) / 256)), dim3(256), 0, sb, t->bnb2[l], RS, (long long)Cc, t->grad(6 * l + 1));
+            OZ_HIP(hipGetLastError());
+        } else if ((long long)B * P <= OZ_BN_FUSED_MAX_ROWS) {  // small batch: BN backward, dgamma / dbeta / bias gradient in one launch
             hipLaunchKernelGGL(k_t_bn_bwd_fused, dim3(Cc / OZ_BN_COLS), dim3(1024), 0, s, t->dA[cur], t->a[l], t->z[l], t->mean[l], t->rstd[l],
                                t->param(6 * l + 2), post, t->d_count, t->Hout[l], Cc, t->Hz[l], t->zoff[l], t->dz[l], t->grad(6 * l + 2),
                                t->grad(6 * l + 3), t->grad(6 * l + 1));
@@ -902,6 +942,7 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
                 if (int rc = oz_gemm_f32_launch(t->dz[l], t->param(6 * l), t->ones, t->zeros, t->dA[cur ^ 1], t->d_count, B, 1, 1, 0, Cc, 1, Cin[l], 0, s, t->gpartial, (t->split_mask & 2) ? t->gpartial_floats : 0)) return rc;
             } else {               // 3x3 conv: conv of dz (zero-bordered for 'valid' layers) with the reversed, channel-swapped taps
                 const int same = pad[l];
+                if (t->wait_wd) { OZ_HIP(hipStreamWaitEvent(s, t->ev_wd, 0)); t->wait_wd = false; }
                 // (the non-zero core of the zero-bordered dz buffer: taps that only read the border are skipped at large batch)
                 if (int rc = oz_gemm_f32_launch(t->dz[l], t->Wd[l], t->ones, t->zeros, t->dA[cur ^ 1], t->d_count, B, t->Hz[l], Hin[l], same ? 1 : 0, Cc, 9,
                                                 Cin[l], 0, s, t->gpartial, (t->split_mask & 4) ? t->gpartial_floats : 0, 0, t->zoff[l],

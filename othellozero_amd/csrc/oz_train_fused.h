@@ -91,3 +91,60 @@ __global__ __launch_bounds__(1024) void k_t_bn_bwd_fused(const float* __restrict
     const float SB = t_block_sum4(sb, sh, lane4, c64);
     if (lane4 == 0) { dgamma[c] = S1; dbeta[c] = S0; dbias[c] = SB; }
 }
+
+// ---- mid-size batches (the reference's 32 boards on the 8x8 conv layers: 1152-2048 rows): one block per 16 channels leaves
+// 224 CUs idle and every thread walks ~100 dependent rows (35-64 us per layer, measured); here the rows are split over
+// the grid instead.  Launch 1 = k_t_colreduce<2> over RS row splits (partial sums of dy and dy * xhat), launch 2 = this
+// kernel: every block finishes the two sums from the RS partials (fixed order; 2 x RS independent 16-byte loads per thread),
+// writes dz for its rows and leaves the column sums of its dz rows in part2[split]; the bias gradient (sum of part2 over the
+// splits, k_t_sum_partials) is not on the data-gradient chain and is finished on the second stream.
+#define OZ_BNB_MIN_ROWS 256                // at most this many rows: the one-launch kernel above (a handful of rows per thread there)
+#define OZ_BNB_MAX_ROWS 4096
+#define OZ_BNB_MAX_RB 256
+__global__ __launch_bounds__(256) void k_t_bnb_apply(const float* __restrict__ dA, const float* __restrict__ a, const float* __restrict__ z,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     float post_scale, const int* __restrict__ d_count, int Hout, int C, int Hz, int zoff,
+                                                     const float* __restrict__ partial /*[RS][2][C]*/, int RS, float* __restrict__ dz,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part2 /*[RS][C]*/) {
+    const int Q = C / 4, lpr = Q < 64 ? Q : 64, rpp = 256 / lpr;
+    const int q = blockIdx.x * 64 + (int)(threadIdx.x % lpr), rsub = threadIdx.x / lpr, sp = blockIdx.y;
+    const bool valid = q < Q;
+    const int c = valid ? q * 4 : 0;
+    const int P = Hout * Hout;
+    const long long M = valid ? (long long)(*d_count) * P : 0;
+    f32x4 S0 = {0.f, 0.f, 0.f, 0.f}, S1 = S0;
+    _Pragma("unroll 8") for (int s = 0; s < RS; ++s) {
+        S0 += *reinterpret_cast<const f32x4*>(partial + ((size_t)s * 2 + 0) * C + c);
+        S1 += *reinterpret_cast<const f32x4*>(partial + ((size_t)s * 2 + 1) * C + c);
+    }
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c),
+                ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const float inv = 1.0f / (float)((long long)(*d_count) * P);
+    f32x4 sb = {0.f, 0.f, 0.f, 0.f};
+    for (long long m = (long long)sp * rpp + rsub; m < M; m += (long long)RS * rpp) {
+        const size_t i = (size_t)m * C + c;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + i), xv = *reinterpret_cast<const f32x4*>(dA + i), zv = *reinterpret_cast<const f32x4*>(z + i);
+        f32x4 g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dy = av[k] > 0.f ? xv[k] * post_scale : 0.f;
+            const float xh = (zv[k] - mu[k]) * rs[k];
+            g[k] = ga[k] * rs[k] * (dy - S0[k] * inv - xh * S1[k] * inv);
+            sb[k] += g[k];
+        }
+        const int b = (int)(m / P), pix = (int)(m % P);
+        *reinterpret_cast<f32x4*>(dz + (((size_t)b * Hz + pix / Hout + zoff) * Hz + pix % Hout + zoff) * C + c) = g;
+    }
+    __shared__ f32x4 sh[256];
+    sh[threadIdx.x] = sb;
+    __syncthreads();
+    if (rsub == 0 && valid) {
+        f32x4 t = sh[threadIdx.x];
+        for (int k = 1; k < rpp; ++k) t += sh[threadIdx.x + k * lpr];
+        *reinterpret_cast<f32x4*>(part2 + (size_t)sp * C + c) = t;
+        if (sp == 0) {
+            *reinterpret_cast<f32x4*>(dgamma + c) = S1;
+            *reinterpret_cast<f32x4*>(dbeta + c) = S0;
+        }
+    }
+}
