@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) void k_t_heads(const float* __restrict__ f2 /*[
     float logit = -INFINITY, vacc = 0.f;
     if (lane < A) {
         float acc = 0.f;
-        for (int k = 0; k < 512; ++k) acc = fmaf(x[k], Wpi[(size_t)k * A + lane], acc);
+        _Pragma("unroll 16") for (int k = 0; k < 512; ++k) acc = fmaf(x[k], Wpi[(size_t)k * A + lane], acc);      // 16 row loads in flight, the fmaf chain stays in k order
         logit = acc + bpi[lane];
     }
     for (int k = lane; k < 512; k += 64) vacc = fmaf(x[k], Wv[k], vacc);
@@ -853,7 +853,7 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
         const float post = l >= 4 && t->rate > 0.f ? 1.0f / (1.0f - t->rate) : 1.0f;
         static const bool bnb_split = !(getenv("OZ_BN_BWD_SPLIT") && atoi(getenv("OZ_BN_BWD_SPLIT")) == 0);
         if (bnb_split && (long long)B * P > OZ_BNB_MIN_ROWS && (long long)B * P <= OZ_BNB_MAX_ROWS) {
-            // mid-size: partial sums over row splits, then one launch that finishes the sums and writes dz (oz_train_fused.h)
+            // partial sums over row splits, then one launch that finishes the sums and writes dz (oz_train_fused.h)
             const long long M = (long long)B * P;
             const int Q = Cc / 4, lpr = Q < 64 ? Q : 64, rpp = 256 / lpr;
             int RS = 16; while (RS < OZ_BNB_MAX_RB && M > (long long)RS * rpp * 8) RS *= 2;          // ~8 rows per thread

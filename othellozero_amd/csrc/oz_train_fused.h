@@ -92,14 +92,14 @@ __global__ __launch_bounds__(1024) void k_t_bn_bwd_fused(const float* __restrict
     if (lane4 == 0) { dgamma[c] = S1; dbeta[c] = S0; dbias[c] = SB; }
 }
 
-// ---- mid-size batches (the reference's 32 boards on the 8x8 conv layers: 1152-2048 rows): one block per 16 channels leaves
+// ---- more than OZ_BNB_MIN_ROWS rows (from the reference's 32 boards on the 8x8 conv layers, 1152-2048 rows, upwards): one block per 16 channels leaves
 // 224 CUs idle and every thread walks ~100 dependent rows (35-64 us per layer, measured); here the rows are split over
 // the grid instead.  Launch 1 = k_t_colreduce<2> over RS row splits (partial sums of dy and dy * xhat), launch 2 = this
 // kernel: every block finishes the two sums from the RS partials (fixed order; 2 x RS independent 16-byte loads per thread),
 // writes dz for its rows and leaves the column sums of its dz rows in part2[split]; the bias gradient (sum of part2 over the
 // splits, k_t_sum_partials) is not on the data-gradient chain and is finished on the second stream.
 #define OZ_BNB_MIN_ROWS 256                // at most this many rows: the one-launch kernel above (a handful of rows per thread there)
-#define OZ_BNB_MAX_ROWS 4096
+#define OZ_BNB_MAX_ROWS (1LL << 40)      // (no upper bound: at large batch the same two launches replace five and one pass over dz)
 #define OZ_BNB_MAX_RB 256
 __global__ __launch_bounds__(256) void k_t_bnb_apply(const float* __restrict__ dA, const float* __restrict__ a, const float* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -112,11 +112,22 @@ __global__ __launch_bounds__(256) void k_t_bnb_apply(const float* __restrict__ d
     const int c = valid ? q * 4 : 0;
     const int P = Hout * Hout;
     const long long M = valid ? (long long)(*d_count) * P : 0;
+    // the two sums: row lane r adds the partials of splits r, r + rpp, ... in increasing order, the rpp lane sums are combined in lane order
+    // (fixed order; RS / rpp x 2 independent 16-byte loads per thread instead of RS x 2)
+    __shared__ f32x4 sh[2][256];
     f32x4 S0 = {0.f, 0.f, 0.f, 0.f}, S1 = S0;
-    _Pragma("unroll 8") for (int s = 0; s < RS; ++s) {
+    _Pragma("unroll 8") for (int s = rsub; s < RS; s += rpp) {
         S0 += *reinterpret_cast<const f32x4*>(partial + ((size_t)s * 2 + 0) * C + c);
         S1 += *reinterpret_cast<const f32x4*>(partial + ((size_t)s * 2 + 1) * C + c);
     }
+    sh[0][threadIdx.x] = S0; sh[1][threadIdx.x] = S1;
+    __syncthreads();
+    {
+        const int base = threadIdx.x % lpr;
+        S0 = sh[0][base]; S1 = sh[1][base];
+        for (int k = 1; k < rpp; ++k) { S0 += sh[0][base + k * lpr]; S1 += sh[1][base + k * lpr]; }
+    }
+    __syncthreads();
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c),
                 ga = *reinterpret_cast<const f32x4*>(gamma + c);
     const float inv = 1.0f / (float)((long long)(*d_count) * P);
@@ -135,12 +146,11 @@ __global__ __launch_bounds__(256) void k_t_bnb_apply(const float* __restrict__ d
         const int b = (int)(m / P), pix = (int)(m % P);
         *reinterpret_cast<f32x4*>(dz + (((size_t)b * Hz + pix / Hout + zoff) * Hz + pix % Hout + zoff) * C + c) = g;
     }
-    __shared__ f32x4 sh[256];
-    sh[threadIdx.x] = sb;
+    sh[0][threadIdx.x] = sb;
     __syncthreads();
     if (rsub == 0 && valid) {
-        f32x4 t = sh[threadIdx.x];
-        for (int k = 1; k < rpp; ++k) t += sh[threadIdx.x + k * lpr];
+        f32x4 t = sh[0][threadIdx.x];
+        for (int k = 1; k < rpp; ++k) t += sh[0][threadIdx.x + k * lpr];
         *reinterpret_cast<f32x4*>(part2 + (size_t)sp * C + c) = t;
         if (sp == 0) {
             *reinterpret_cast<f32x4*>(dgamma + c) = S1;
