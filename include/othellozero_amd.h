@@ -245,6 +245,12 @@ int oz_trainer_arena_size(int n, int channels, int in_channels, int64_t* nelem);
 int oz_trainer_create(oz_trainer** out, int n, int channels, int in_channels, int max_batch, float lr, float clipvalue /* <= 0: none */,
                       float dropout, float bn_momentum, uint64_t seed, float* external_grads);
 int oz_trainer_destroy(oz_trainer* t);
+/* arithmetic of the 3x3 layers' forward and data-gradient GEMMs: 0 = fp32 matrix cores (default), 1 = f16x2 -- every fp32 value as two
+ * fp16 planes, 3 fp16 MFMA products per fp32 product with fp32 accumulation (the inference kernels of precision f16x2; tensors
+ * are moved into the fp16 range by exact powers of two taken from their own maxima on the device, per step).  Weight gradients,
+ * dense layers, BN, losses and Adam stay fp32.  Needs channels % 256 == 0; an activation above 65504 raises OZ_ERR_STATE at the
+ * next synchronising call (forward_backward, fit_epoch). */
+int oz_trainer_set_precision(oz_trainer* t, int mode);
 int oz_trainer_set_weight(oz_trainer* t, int index, const float* data, int64_t nelem);
 int oz_trainer_get_weight(oz_trainer* t, int index, float* data, int64_t nelem);
 int oz_trainer_get_grad(oz_trainer* t, int index, float* data, int64_t nelem);      /* trainable arrays only */

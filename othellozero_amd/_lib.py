@@ -122,6 +122,7 @@ SIGNATURES = {
     "oz_trainer_outputs": [_vp, C.c_int, _f32p, _f32p],
     "oz_trainer_get_activation": [_vp, C.c_int, C.c_int, _f32p, C.c_int64],
     "oz_trainer_sync": [_vp],
+    "oz_trainer_set_precision": [_vp, C.c_int],
     "oz_trainer_step_count": [_vp, C.POINTER(C.c_int64)],
 }
 

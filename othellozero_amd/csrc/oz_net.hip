@@ -375,6 +375,56 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
 
 #include "oz_net_h2.h"
 
+// k_gemm_h2 for callers outside the network object (the trainer's f16x2 mode): out[M][N] fp32 rows = (A . Wh^T) * scale + shift, A and Wh
+// in the h2 layout.  Tile and k-split are chosen from `max_count` (the caller's capacity -- a constant of the trainer, so a
+// row's result does not depend on the size of one call): the 256 x 256 ping-pong tile once it fills the chip, else
+// 128 x 128 tiles with the k loop split until every CU has a block (raw slabs + the fixed-order fp32 reduce).
+int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, const float* shift, float* out, const int* d_count, int max_count,
+                      int Hin, int Hout, int pad, int Cin, int taps, int N, hipStream_t s, float* partial, long long partial_floats,
+                      const void* zero_line, int* flag) {
+    OZ_REQUIRE(N % 256 == 0 && Cin % 32 == 0, "gemm_h2: N %% 256 and Cin %% 32 must be 0 (N=%d Cin=%d)", N, Cin);
+    static bool attr_set = false;
+    if (!attr_set) {
+        OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2BigPP::LDS));
+        OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
+        OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small2::LDS));
+        attr_set = true;
+    }
+    H2Geom g;
+    g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.out_h2 = 0; g.relu = 0;
+    const long long Mmax = (long long)max_count * Hout * Hout;
+    g.slab = Mmax * N;
+    const long long big_blocks = ((Mmax + 255) / 256) * (N / 256);
+    const bool big = big_blocks >= 192;
+    const int BM = big ? 256 : 128, BN = big ? 256 : 128;
+    const int num_mt = (int)((Mmax + BM - 1) / BM);
+    int ksplit = 1;
+    if (!big && partial) {
+        const long long blocks = (long long)num_mt * (N / BN);
+        const int nk = g.K / H2_BK;
+        while (ksplit < 16 && blocks * ksplit < 256 && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * Mmax * N <= partial_floats) ksplit *= 2;
+    }
+    g.ksplit = ksplit;
+    const int grid = ((num_mt + 7) / 8) * 8 * (N / BN) * ksplit;
+    void* dst = ksplit > 1 ? (void*)partial : (void*)out;
+    if (big)
+        hipLaunchKernelGGL(k_gemm_h2<H2BigPP>, dim3(grid), dim3(H2BigPP::NT), H2BigPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
+                           d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned short*)nullptr);
+    else if (ksplit <= 4)
+        hipLaunchKernelGGL(k_gemm_h2<H2Small>, dim3(grid), dim3(H2Small::NT), H2Small::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
+                           d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned short*)nullptr);
+    else
+        hipLaunchKernelGGL(k_gemm_h2<H2Small2>, dim3(grid), dim3(H2Small2::NT), H2Small2::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
+                           d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned short*)nullptr);
+    if (ksplit > 1) {
+        const long long quads = (Mmax * N + 3) / 4;
+        hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float*)partial, g.slab, ksplit, N,
+                           Hout * Hout, d_count, scale, shift, 0, out);
+    }
+    OZ_HIP(hipGetLastError());
+    return OZ_OK;
+}
+
 // ---------------------------------------------------------------- heads
 // one 256-thread block per HEADS_P positions: wave w accumulates k in [128w, 128w+128) of logits[a] = f2 . Wpi[:,a]
 // (one policy column per lane, every coalesced Wpi row load feeds HEADS_P positions) and of v = f2 . Wv; the four

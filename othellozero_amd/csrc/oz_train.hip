@@ -540,6 +540,89 @@ __global__ __launch_bounds__(256) void k_t_dgrad_operand(const float* __restrict
     Wd[(size_t)ci * 9 * Cout + (size_t)(8 - t) * Cout + co] = W[i];
 }
 
+// ---------------------------------------------------------------- f16x2 mode of the 3x3 layers (forward and data gradient on k_gemm_h2)
+// An fp32 value travels as two fp16 planes (oz_net_h2.h: 22 significand bits, 3 fp16 MFMA products per fp32 product at 16x the fp32
+// matrix rate).  fp16 has 5 exponent bits, so every tensor is moved into range by an exact power of two taken from its own
+// maximum, on the device and per step: weights to max |w| ~ 2^9 (as at oz_net_commit), data gradients to max |dz| ~ 2^13; the
+// inverse powers ride in the GEMM's per-column scale, so scaling itself changes no bit.  Small elements of a gradient tensor
+// (below 2^-11 of its maximum) lose relative precision in the second plane -- an absolute error of 2^-37 of the tensor's
+// maximum, far below the fp32 rounding of the sums they enter.  Activations are post-ReLU values < 65504 (sticky flag otherwise).
+typedef _Float16 t_f16x8 __attribute__((ext_vector_type(8)));
+struct AbsMaxArgs { const float* p[3]; long long n[3]; };
+// out[l] = bits of max |p[l][i]| (non-negative floats order like their bit patterns); out is zeroed by the caller
+__global__ __launch_bounds__(256) void k_t_absmax(AbsMaxArgs a, unsigned* __restrict__ out) {
+    const int l = blockIdx.y;
+    const float* p = a.p[l];
+    float m = 0.f;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n[l]; i += (long long)gridDim.x * 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+        m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out + l, __float_as_uint(m));
+}
+__device__ __forceinline__ int t_exp_for(unsigned max_bits, float target) {
+    const float mx = __uint_as_float(max_bits);
+    return mx > 0.f ? (int)floorf(log2f(target / mx)) : 0;
+}
+__device__ __forceinline__ void t_store_h2(uint4* dst, const float* v) {
+    t_f16x8 h1, h2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const _Float16 a = (_Float16)v[j]; h1[j] = a; h2[j] = (_Float16)(v[j] - (float)a); }
+    dst[0] = *reinterpret_cast<uint4*>(&h1);
+    dst[1] = *reinterpret_cast<uint4*>(&h2);
+}
+// GEMM operand rows [N][K] fp32 (k = tap * Cch + ch: Wt of the forward, Wd of the data gradient) -> the h2 layout in k_gemm_h2's
+// k order k' = (slice * taps + tap) * 32 + c32, scaled by 2^kexp (kexp from the tensor's maximum); scale_out[n] = 2^-kexp
+__global__ __launch_bounds__(256) void k_t_rows_to_h2(const float* __restrict__ src, int K, int N, int taps, const unsigned* __restrict__ wmax,
+                                                      uint4* __restrict__ out, float* __restrict__ scale_out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ng = K >> 3, grp = (int)(idx % ng);
+    const long long nrow = idx / ng;
+    if (nrow >= N) return;
+    const int kexp = t_exp_for(*wmax, 1000.0f), Cch = K / taps;
+    const int kp = grp * 8, tile = kp >> 5, c32 = kp & 31, slice = tile / taps, tap = tile - slice * taps;
+    const float* q = src + (size_t)nrow * K + (size_t)tap * Cch + slice * 32 + c32;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ldexpf(q[j], kexp);
+    t_store_h2(out + ((size_t)nrow * ng + grp) * 2, v);
+    if (grp == 0 && scale_out) scale_out[nrow] = ldexpf(1.0f, -kexp);
+}
+// activation rows [M][C] fp32 -> h2 layout (the next layer's A operand)
+__global__ __launch_bounds__(256) void k_t_act_to_h2(const float* __restrict__ a, const int* __restrict__ d_count, int P, int C,
+                                                     uint4* __restrict__ out, int* __restrict__ flag) {
+    const int cg = C >> 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, m = idx / cg;
+    if (m >= (long long)(*d_count) * P) return;
+    const int g8 = (int)(idx % cg);
+    const float* q = a + (size_t)m * C + g8 * 8;
+    float v[8];
+    bool over = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = q[j]; over |= fabsf(v[j]) > 65504.0f; }
+    t_store_h2(out + ((size_t)m * cg + g8) * 2, v);
+    if (over) atomicOr(flag, 1);
+}
+// dz (zero-bordered [B][Hz][Hz][C] fp32, interior Hout^2 at offset zoff) -> the same geometry in the h2 layout, scaled by 2^ez with ez
+// from the tensor's maximum (dzmax, left by the BN backward); dscale[c] = 2^-(ez + kexp of the data-gradient weights)
+__global__ __launch_bounds__(256) void k_t_dz_to_h2(const float* __restrict__ dz, const int* __restrict__ d_count, int Hout, int Hz, int zoff, int C,
+                                                    const unsigned* __restrict__ dzmax, const unsigned* __restrict__ wmax,
+                                                    uint4* __restrict__ out, float* __restrict__ dscale, int ncols) {
+    const int cg = C >> 3, P = Hout * Hout;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, m = idx / cg;
+    const int ez = t_exp_for(*dzmax, 8192.0f);
+    if (idx < ncols) dscale[idx] = ldexpf(1.0f, -(ez + t_exp_for(*wmax, 1000.0f)));
+    if (m >= (long long)(*d_count) * P) return;
+    const int g8 = (int)(idx % cg), b = (int)(m / P), pix = (int)(m % P);
+    const size_t row = ((size_t)b * Hz + pix / Hout + zoff) * Hz + pix % Hout + zoff;
+    const float* q = dz + row * C + g8 * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ldexpf(q[j], ez);
+    t_store_h2(out + (row * cg + g8) * 2, v);
+}
+
 // ---------------------------------------------------------------- Adam (tf.keras formulation) with clipvalue
 __global__ __launch_bounds__(256) void k_t_adam(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M1, float* __restrict__ V2,
                                                 long long count, float lr_t, float clip) {
@@ -578,6 +661,12 @@ struct oz_trainer {
     hipEvent_t ev_dz[6] = {}, ev_w = nullptr;
     hipEvent_t ev_pre = nullptr, ev_wt = nullptr, ev_wd = nullptr;      // derived weight operands are rebuilt on s2 beside the first forward kernels
     bool wait_wt = false, wait_wd = false;
+    // f16x2 mode (oz_trainer_set_precision 1): conv2..4 forward and data gradient on k_gemm_h2
+    int h2 = 0;
+    uint4 *Wh[4] = {}, *Whd[4] = {}, *a_h2[3] = {}, *dz_h2[4] = {};
+    float *wscale[4] = {}, *dscale[4] = {};
+    unsigned *wmax = nullptr, *dzmax = nullptr;          // [3] max |w| of conv2..4, [6] max |dz| per layer (bit patterns)
+    int* h2flag = nullptr;
     float* bnb2[6] = {};                 // per-layer row-block partials of the bias gradient (mid-size BN backward)
     bool overlap = true;                 // env OZ_TRAIN_OVERLAP=0: weight gradients on the main stream
     long long gpartial_floats = 40LL << 20;      // 160 MB each: 16 row-split slabs of a 3x3 x 512 x 512 weight gradient
@@ -703,6 +792,42 @@ OZ_API int oz_trainer_create(oz_trainer** out, int n, int channels, int in_chann
 
 OZ_API int oz_trainer_destroy(oz_trainer* t) { delete t; return OZ_OK; }
 
+// sticky range flag of the f16x2 mode (an activation above the fp16 range): reported at the synchronising calls
+static int t_check_range(oz_trainer* t) {
+    if (!t->h2 || !t->h2flag) return OZ_OK;
+    int f = 0;
+    OZ_HIP(hipMemcpyAsync(&f, t->h2flag, sizeof(int), hipMemcpyDeviceToHost, t->s));
+    OZ_HIP(hipStreamSynchronize(t->s));
+    if (f) {
+        oz_set_error("an activation exceeded the fp16 range (65504) in the trainer's f16x2 mode: the step is invalid; use precision 0 (f32)");
+        return OZ_ERR_STATE;
+    }
+    return OZ_OK;
+}
+
+OZ_API int oz_trainer_set_precision(oz_trainer* t, int mode) {
+    OZ_REQUIRE(t && (mode == 0 || mode == 1), "oz_trainer_set_precision: mode 0 (f32) or 1 (f16x2)");
+    T_LOCK(t);
+    OZ_REQUIRE(t->C % 256 == 0 || mode == 0, "oz_trainer_set_precision: f16x2 needs channels %% 256 == 0 (got %d)", t->C);
+    OZ_HIP(hipSetDevice(t->device));
+    OZ_HIP(hipStreamSynchronize(t->s));
+    if (mode == 1 && !t->wmax) {
+        const int C = t->C;
+        const size_t wq = (size_t)C * 9 * C / 4;             // uint4 units of a 3x3 kernel in the h2 layout (4 B per value)
+        for (int l = 1; l < 4; ++l) {
+            T_ALLOC(t->Wh[l], wq); T_ALLOC(t->Whd[l], wq);
+            T_ALLOC(t->wscale[l], C); T_ALLOC(t->dscale[l], C);
+            T_ALLOC(t->a_h2[l - 1], (size_t)t->Bmax * t->P_[l - 1] * C / 4);
+            T_ALLOC(t->dz_h2[l], (size_t)t->Bmax * t->Hz[l] * t->Hz[l] * C / 4);      // zeroed: the border stays zero
+        }
+        T_ALLOC(t->wmax, 4); T_ALLOC(t->dzmax, 8); T_ALLOC(t->h2flag, 1);
+        OZ_HIP(hipStreamSynchronize(t->s));
+    }
+    t->h2 = mode;
+    t->dirty = true;
+    return OZ_OK;
+}
+
 OZ_API int oz_trainer_set_weight(oz_trainer* t, int index, const float* data, int64_t nelem) {
     OZ_REQUIRE(t && data && index >= 0 && index < 40, "oz_trainer_set_weight: bad argument");
     T_LOCK(t);
@@ -774,10 +899,24 @@ static int t_refresh(oz_trainer* t) {
         hipLaunchKernelGGL(k_t_transpose, dim3((Ns[l] + 31) / 32, (Ks[l] + 31) / 32), dim3(256), 0, r, t->param(6 * l), Ks[l], Ns[l], t->Wt[l]);
         OZ_HIP(hipGetLastError());
     }
+    const long long h2_threads = (long long)C * (9 * C / 8);
+    if (t->h2) {         // per-tensor maxima -> power-of-two scales, then the h2 images of the forward operands
+        OZ_HIP(hipMemsetAsync(t->wmax, 0, 3 * sizeof(unsigned), r));
+        AbsMaxArgs am;
+        for (int l = 1; l < 4; ++l) { am.p[l - 1] = t->param(6 * l); am.n[l - 1] = 9LL * C * C; }
+        hipLaunchKernelGGL(k_t_absmax, dim3(64, 3), dim3(256), 0, r, am, t->wmax);
+        for (int l = 1; l < 4; ++l)
+            hipLaunchKernelGGL(k_t_rows_to_h2, dim3((unsigned)((h2_threads + 255) / 256)), dim3(256), 0, r, t->Wt[l], 9 * C, C, 9, t->wmax + (l - 1),
+                               t->Wh[l], t->wscale[l]);
+        OZ_HIP(hipGetLastError());
+    }
     if (t->overlap) OZ_HIP(hipEventRecord(t->ev_wt, r));
     for (int l = 1; l < 4; ++l) {
         const long long cnt = 9LL * C * C;
         hipLaunchKernelGGL(k_t_dgrad_operand, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, r, t->param(6 * l), C, C, t->Wd[l]);
+        if (t->h2)
+            hipLaunchKernelGGL(k_t_rows_to_h2, dim3((unsigned)((h2_threads + 255) / 256)), dim3(256), 0, r, t->Wd[l], 9 * C, C, 9, t->wmax + (l - 1),
+                               t->Whd[l], (float*)nullptr);
         OZ_HIP(hipGetLastError());
     }
     if (t->overlap) OZ_HIP(hipEventRecord(t->ev_wd, r));
@@ -833,6 +972,12 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
     const int Hin[6] = {n, n, n, n - 2, 1, 1}, pad[6] = {1, 1, 0, 0, 0, 0}, Cin[6] = {t->cin, C, C, C, F, 1024}, taps[6] = {9, 9, 9, 9, 1, 1};
     if (t->wait_wt) { OZ_HIP(hipStreamWaitEvent(s, t->ev_wt, 0)); t->wait_wt = false; }
     for (int l = 1; l < 6; ++l) {
+        if (t->h2 && l < 4) {      // f16x2: the previous layer's activation in the h2 layout, then the GEMM on the fp16 matrix cores
+            const long long thr = (long long)B * t->P_[l - 1] * (C / 8);
+            hipLaunchKernelGGL(k_t_act_to_h2, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, s, t->a[l - 1], t->d_count, t->P_[l - 1], C, t->a_h2[l - 1], t->h2flag);
+            if (int rc = oz_gemm_h2_launch(t->a_h2[l - 1], t->Wh[l], t->wscale[l], t->param(6 * l + 1), t->z[l], t->d_count, B, Hin[l], t->Hout[l], pad[l],
+                                           Cin[l], 9, t->Co[l], s, t->gpartial, t->gpartial_floats, t->zeros, t->h2flag)) return rc;
+        } else
         if (int rc = oz_gemm_f32_launch(t->a[l - 1], t->Wt[l], t->ones, t->param(6 * l + 1), t->z[l], t->d_count, B, Hin[l], t->Hout[l], pad[l],
                                         Cin[l], taps[l], t->Co[l], 0, s, t->gpartial, (t->split_mask & 1) ? t->gpartial_floats : 0)) return rc;
         if (int rc = t_bn_forward(t, l, B)) return rc;
@@ -848,7 +993,9 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
                        t->param(38), t->d_count, A, t->dA[1]);
     OZ_HIP(hipGetLastError());
     int cur = 1;                                   // dA[cur] = gradient wrt a[l]
+    if (t->h2) OZ_HIP(hipMemsetAsync(t->dzmax, 0, 6 * sizeof(unsigned), s));
     for (int l = 5; l >= 0; --l) {
+        bool have_dzmax = false;
         const int Cc = t->Co[l], P = t->P_[l];
         const float post = l >= 4 && t->rate > 0.f ? 1.0f / (1.0f - t->rate) : 1.0f;
         static const bool bnb_split = !(getenv("OZ_BN_BWD_SPLIT") && atoi(getenv("OZ_BN_BWD_SPLIT")) == 0);
@@ -860,7 +1007,9 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
             RedArgs r = {}; r.x = t->dA[cur]; r.a = t->a[l]; r.z = t->z[l]; r.mean = t->mean[l]; r.rstd = t->rstd[l]; r.post_scale = post; r.P = P; r.C = Cc;
             hipLaunchKernelGGL(k_t_colreduce<2>, dim3((Q + 63) / 64, RS), dim3(256), 0, s, r, t->d_count, t->partial);
             hipLaunchKernelGGL(k_t_bnb_apply, dim3((Q + 63) / 64, RS), dim3(256), 0, s, t->dA[cur], t->a[l], t->z[l], t->mean[l], t->rstd[l], t->param(6 * l + 2),
-                               post, t->d_count, t->Hout[l], Cc, t->Hz[l], t->zoff[l], t->partial, RS, t->dz[l], t->grad(6 * l + 2), t->grad(6 * l + 3), t->bnb2[l]);
+                               post, t->d_count, t->Hout[l], Cc, t->Hz[l], t->zoff[l], t->partial, RS, t->dz[l], t->grad(6 * l + 2), t->grad(6 * l + 3), t->bnb2[l],
+                               t->h2 ? t->dzmax + l : (unsigned*)nullptr);
+            have_dzmax = t->h2 != 0;
             // the bias gradient (column sums of dz) is off the dgrad chain: finished beside it
             hipStream_t sb = s;
             if (t->overlap && l > 0) {
@@ -943,6 +1092,14 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
             } else {               // 3x3 conv: conv of dz (zero-bordered for 'valid' layers) with the reversed, channel-swapped taps
                 const int same = pad[l];
                 if (t->wait_wd) { OZ_HIP(hipStreamWaitEvent(s, t->ev_wd, 0)); t->wait_wd = false; }
+                if (have_dzmax) {  // f16x2: dz scaled into the fp16 range by its own maximum, h2 layout, same zero-bordered geometry
+                    long long thr = (long long)B * P * (Cc / 8);
+                    if (thr < Cin[l]) thr = Cin[l];
+                    hipLaunchKernelGGL(k_t_dz_to_h2, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, s, t->dz[l], t->d_count, t->Hout[l], t->Hz[l], t->zoff[l], Cc,
+                                       t->dzmax + l, t->wmax + (l - 1), t->dz_h2[l], t->dscale[l], Cin[l]);
+                    if (int rc = oz_gemm_h2_launch(t->dz_h2[l], t->Whd[l], t->dscale[l], t->zeros, t->dA[cur ^ 1], t->d_count, B, t->Hz[l], Hin[l], same ? 1 : 0, Cc, 9,
+                                                   Cin[l], s, t->gpartial, t->gpartial_floats, t->zeros, t->h2flag)) return rc;
+                } else
                 // (the non-zero core of the zero-bordered dz buffer: taps that only read the border are skipped at large batch)
                 if (int rc = oz_gemm_f32_launch(t->dz[l], t->Wd[l], t->ones, t->zeros, t->dA[cur ^ 1], t->d_count, B, t->Hz[l], Hin[l], same ? 1 : 0, Cc, 9,
                                                 Cin[l], 0, s, t->gpartial, (t->split_mask & 4) ? t->gpartial_floats : 0, 0, t->zoff[l],
@@ -976,7 +1133,7 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
     OZ_HIP(hipMemcpyAsync(h, t->losses, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     OZ_HIP(hipStreamSynchronize(s));
     if (losses3) { losses3[0] = h[0]; losses3[1] = h[1]; losses3[2] = h[2]; }
-    return OZ_OK;
+    return t_check_range(t);
 }
 
 // ---------------------------------------------------------------- HBM-resident data set: one upload per fit, one read-back per epoch
@@ -1049,7 +1206,7 @@ OZ_API int oz_trainer_fit_epoch(oz_trainer* t, const int32_t* order, int64_t cou
     OZ_HIP(hipMemcpyAsync(h, t->ds_acc, sizeof h, hipMemcpyDeviceToHost, s));
     OZ_HIP(hipStreamSynchronize(s));
     if (losses3) for (int k = 0; k < 3; ++k) losses3[k] = (float)(h[k] / (h[3] > 0 ? h[3] : 1.0));
-    return OZ_OK;
+    return t_check_range(t);
 }
 
 static int t_apply_locked(oz_trainer* t) {

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void k_t_bnb_apply(const float* __restrict__ d
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      float post_scale, const int* __restrict__ d_count, int Hout, int C, int Hz, int zoff,
                                                      const float* __restrict__ partial /*[RS][2][C]*/, int RS, float* __restrict__ dz,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part2 /*[RS][C]*/) {
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part2 /*[RS][C]*/,
+                                                     unsigned* __restrict__ dzmax /* nullable: atomic max of |dz| (bit pattern) for the f16x2 data gradient */) {
     const int Q = C / 4, lpr = Q < 64 ? Q : 64, rpp = 256 / lpr;
     const int q = blockIdx.x * 64 + (int)(threadIdx.x % lpr), rsub = threadIdx.x / lpr, sp = blockIdx.y;
     const bool valid = q < Q;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void k_t_bnb_apply(const float* __restrict__ d
                 ga = *reinterpret_cast<const f32x4*>(gamma + c);
     const float inv = 1.0f / (float)((long long)(*d_count) * P);
     f32x4 sb = {0.f, 0.f, 0.f, 0.f};
+    float amax = 0.f;
     for (long long m = (long long)sp * rpp + rsub; m < M; m += (long long)RS * rpp) {
         const size_t i = (size_t)m * C + c;
         const f32x4 av = *reinterpret_cast<const f32x4*>(a + i), xv = *reinterpret_cast<const f32x4*>(dA + i), zv = *reinterpret_cast<const f32x4*>(z + i);
@@ -142,9 +144,14 @@ __global__ __launch_bounds__(256) void k_t_bnb_apply(const float* __restrict__ d
             const float xh = (zv[k] - mu[k]) * rs[k];
             g[k] = ga[k] * rs[k] * (dy - S0[k] * inv - xh * S1[k] * inv);
             sb[k] += g[k];
+            amax = fmaxf(amax, fabsf(g[k]));
         }
         const int b = (int)(m / P), pix = (int)(m % P);
         *reinterpret_cast<f32x4*>(dz + (((size_t)b * Hz + pix / Hout + zoff) * Hz + pix % Hout + zoff) * C + c) = g;
+    }
+    if (dzmax) {
+        for (int o = 32; o; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(dzmax, __float_as_uint(amax));
     }
     sh[0][threadIdx.x] = sb;
     __syncthreads();

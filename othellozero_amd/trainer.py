@@ -25,7 +25,10 @@ class History:
 
 class Trainer:
     def __init__(self, board_size=8, channels=512, in_channels=2, max_batch=32, lr=1e-3, clipvalue=0.5, dropout=0.3,
-                 bn_momentum=0.99, seed=0, external_grads_ptr=None):
+                 bn_momentum=0.99, seed=0, external_grads_ptr=None, precision="f32"):
+        """precision: arithmetic of the 3x3 layers' forward / data-gradient GEMMs -- "f32" (fp32 matrix cores) or "f16x2"
+        (fp32 values as two fp16 planes on the fp16 matrix cores, the inference kernels' arithmetic; channels % 256 == 0)"""
+        assert precision in ("f32", "f16x2"), precision
         lib = _lib.require_gpu()
         self.n, self.channels, self.in_channels, self.max_batch = board_size, channels, in_channels, int(max_batch)
         self._h = C.c_void_p()
@@ -33,6 +36,9 @@ class Trainer:
                                          clipvalue if clipvalue else 0.0, dropout, bn_momentum, seed,
                                          C.c_void_p(external_grads_ptr) if external_grads_ptr else None))
         self.shapes = onn_shapes(board_size, channels, in_channels)
+        self.precision = precision
+        if precision == "f16x2":
+            _lib.check(lib.oz_trainer_set_precision(self._h, 1))
 
     def __del__(self):
         try:

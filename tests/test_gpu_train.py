@@ -39,13 +39,13 @@ def _both(ref, gpu, batch):
     return lg, lr_
 
 
-def _pair(n, C, cin, B, seed, dropout=0.3, clip=0.5):
+def _pair(n, C, cin, B, seed, dropout=0.3, clip=0.5, precision="f32"):
     from oracle.train_ref import TrainRef
     from othellozero_amd.trainer import Trainer
     from othellozero_amd.weights import init_weights
     w = init_weights(n, seed=seed, channels=C, randomize_all=True, in_channels=cin)
     ref = TrainRef(w, n, lr=1e-3, clipvalue=clip, dropout=dropout, seed=77)
-    gpu = Trainer(n, C, cin, max_batch=B, lr=1e-3, clipvalue=clip, dropout=dropout, seed=77)
+    gpu = Trainer(n, C, cin, max_batch=B, lr=1e-3, clipvalue=clip, dropout=dropout, seed=77, precision=precision)
     gpu.set_weights(w)
     return ref, gpu
 
@@ -77,6 +77,33 @@ def test_forward_backward_matches_autograd(n, C, cin, B):
     p, v = gpu.outputs(B)
     assert np.abs(p - ref.outputs["p"]).max() <= 2e-5 and np.abs(v - ref.outputs["v"]).max() <= 2e-5
     _check_grads(ref, gpu)
+
+
+@pytest.mark.parametrize("n,C,cin,B", [(8, 256, 2, 32), (8, 512, 2, 6), (6, 256, 1, 40), (8, 256, 2, 192)])
+def test_forward_backward_f16x2_matches_autograd(n, C, cin, B):
+    """precision "f16x2" (3x3 layers' forward and data gradient on the fp16 matrix cores, fp32 values as two fp16 planes, per-tensor
+    power-of-two scaling): the same tolerances against the float64 oracle as the fp32 kernels"""
+    ref, gpu = _pair(n, C, cin, B, seed=3, precision="f16x2")
+    lg, lr_ = _both(ref, gpu, _batch(n, B, 11, cin))
+    assert np.allclose(lg, lr_, atol=2e-5, rtol=2e-5), (lg, lr_)
+    p, v = gpu.outputs(B)
+    assert np.abs(p - ref.outputs["p"]).max() <= 2e-5 and np.abs(v - ref.outputs["v"]).max() <= 2e-5
+    _check_grads(ref, gpu)
+
+
+def test_f16x2_step_at_a_large_batch():
+    """512 boards x 512 filters (the 256 x 256 ping-pong tile of the f16x2 GEMM) against the float64 oracle, same tolerances; a second
+    call reproduces the first bit for bit"""
+    n, C, B = 8, 512, 512
+    ref, gpu = _pair(n, C, 2, B, seed=2, precision="f16x2")
+    batch = _batch(n, B, 5)
+    lg, lr_ = _both(ref, gpu, batch)
+    assert np.allclose(lg, lr_, atol=2e-5, rtol=2e-5), (lg, lr_)
+    _check_grads(ref, gpu)
+    g1 = gpu.get_grads()
+    l2 = gpu.forward_backward(*batch)
+    g2 = gpu.get_grads()
+    assert lg == l2 and all(np.array_equal(g1[i], g2[i]) for i in g1)
 
 
 def test_no_dropout_no_clip_and_determinism():

@@ -24,13 +24,14 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="f32", choices=("f32", "f16x2"), help="arithmetic of the 3x3 layers' forward / data-gradient GEMMs")
     ap.add_argument("--fit-examples", type=int, default=0,
                     help="also time trainer.fit over this many examples (2 epochs) both ways: step-wise host loop vs HBM-resident data set")
     args = ap.parse_args()
     from othellozero_amd.trainer import Trainer
     from othellozero_amd.weights import init_weights
     n, C, B = args.board, args.channels, args.batch
-    tr = Trainer(n, C, 2, max_batch=B, seed=1)
+    tr = Trainer(n, C, 2, max_batch=B, seed=1, precision=args.precision)
     tr.set_weights(init_weights(n, seed=0, channels=C))
     rs = np.random.RandomState(0)
     valid = np.uint64(sum(1 << (r * 8 + c) for r in range(n) for c in range(n)))
@@ -77,7 +78,7 @@ def main():
                       # contraction FLOP of forward + data gradient + weight gradient / wall time of the whole step (BN, losses, Adam included)
                       "roofline": {"bound": "mfma", "achieved": flop * args.steps / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                                    "frac": flop * args.steps / dt / 1e12 / 157.3, "traffic": None},
-                      "adam_bytes_per_step": params * 4 * 7, "last_loss": loss[0], "dtype": "f32", "data": "synthetic"}))
+                      "adam_bytes_per_step": params * 4 * 7, "last_loss": loss[0], "dtype": args.precision, "data": "synthetic"}))
 
 
 if __name__ == "__main__":
