@@ -572,22 +572,34 @@ __device__ __forceinline__ void t_store_h2(uint4* dst, const float* v) {
     dst[0] = *reinterpret_cast<uint4*>(&h1);
     dst[1] = *reinterpret_cast<uint4*>(&h2);
 }
-// GEMM operand rows [N][K] fp32 (k = tap * Cch + ch: Wt of the forward, Wd of the data gradient) -> the h2 layout in k_gemm_h2's
-// k order k' = (slice * taps + tap) * 32 + c32, scaled by 2^kexp (kexp from the tensor's maximum); scale_out[n] = 2^-kexp
-__global__ __launch_bounds__(256) void k_t_rows_to_h2(const float* __restrict__ src, int K, int N, int taps, const unsigned* __restrict__ wmax,
-                                                      uint4* __restrict__ out, float* __restrict__ scale_out) {
+// Keras kernel W[9][Cin][Cout] fp32 -> a k_gemm_h2 weight operand in the h2 layout, k order k' = (slice * 9 + tap) * 32 + c32,
+// scaled by 2^kexp (kexp from the tensor's maximum), straight from the master weights (no fp32 intermediate):
+//   DGRAD = 0  forward operand:       row n = co, channel of k' = ci:  W[tap][ci][co]        (threads adjacent in co: coalesced reads)
+//   DGRAD = 1  data-gradient operand: row n = ci, channel of k' = co:  W[8 - tap][ci][co]    (the reversed, channel-swapped taps;
+//              a thread's 8 values are 8 consecutive co = one 32-byte read)
+// scale_out[n] = 2^-kexp (forward only).  One thread per (row, group of 8 k').
+template <int DGRAD>
+__global__ __launch_bounds__(256) void k_t_w_to_h2(const float* __restrict__ W, int Cin, int Cout, const unsigned* __restrict__ wmax,
+                                                   uint4* __restrict__ out, float* __restrict__ scale_out) {
+    const int N = DGRAD ? Cin : Cout, Cch = DGRAD ? Cout : Cin, ng = 9 * Cch / 8;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int ng = K >> 3, grp = (int)(idx % ng);
-    const long long nrow = idx / ng;
-    if (nrow >= N) return;
-    const int kexp = t_exp_for(*wmax, 1000.0f), Cch = K / taps;
-    const int kp = grp * 8, tile = kp >> 5, c32 = kp & 31, slice = tile / taps, tap = tile - slice * taps;
-    const float* q = src + (size_t)nrow * K + (size_t)tap * Cch + slice * 32 + c32;
+    int nrow, grp;
+    if (DGRAD) { grp = (int)(idx % ng); nrow = (int)(idx / ng); }
+    else { nrow = (int)(idx % N); grp = (int)(idx / N); }
+    if (idx >= (long long)N * ng) return;
+    const int kexp = t_exp_for(*wmax, 1000.0f);
+    const int kp = grp * 8, tile = kp >> 5, c32 = kp & 31, slice = tile / 9, tap = tile - slice * 9, ch = slice * 32 + c32;
     float v[8];
+    if (DGRAD) {
+        const float* q = W + ((size_t)(8 - tap) * Cin + nrow) * Cout + ch;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = ldexpf(q[j], kexp);
+        for (int j = 0; j < 8; ++j) v[j] = ldexpf(q[j], kexp);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ldexpf(W[((size_t)tap * Cin + ch + j) * Cout + nrow], kexp);
+    }
     t_store_h2(out + ((size_t)nrow * ng + grp) * 2, v);
-    if (grp == 0 && scale_out) scale_out[nrow] = ldexpf(1.0f, -kexp);
+    if (!DGRAD && grp == 0) scale_out[nrow] = ldexpf(1.0f, -kexp);
 }
 // activation rows [M][C] fp32 -> h2 layout (the next layer's A operand)
 __global__ __launch_bounds__(256) void k_t_act_to_h2(const float* __restrict__ a, const int* __restrict__ d_count, int P, int C,
@@ -895,28 +907,28 @@ static int t_refresh(oz_trainer* t) {
         OZ_HIP(hipStreamWaitEvent(t->s2, t->ev_pre, 0));
         r = t->s2;
     }
-    for (int l = 1; l < 6; ++l) {
-        hipLaunchKernelGGL(k_t_transpose, dim3((Ns[l] + 31) / 32, (Ks[l] + 31) / 32), dim3(256), 0, r, t->param(6 * l), Ks[l], Ns[l], t->Wt[l]);
-        OZ_HIP(hipGetLastError());
-    }
-    const long long h2_threads = (long long)C * (9 * C / 8);
-    if (t->h2) {         // per-tensor maxima -> power-of-two scales, then the h2 images of the forward operands
+    const unsigned h2_blocks = (unsigned)(((long long)C * (9 * C / 8) + 255) / 256);
+    if (t->h2) {         // f16x2: per-tensor maxima -> power-of-two scales -> the h2 forward operands, straight from the masters
         OZ_HIP(hipMemsetAsync(t->wmax, 0, 3 * sizeof(unsigned), r));
         AbsMaxArgs am;
         for (int l = 1; l < 4; ++l) { am.p[l - 1] = t->param(6 * l); am.n[l - 1] = 9LL * C * C; }
-        hipLaunchKernelGGL(k_t_absmax, dim3(64, 3), dim3(256), 0, r, am, t->wmax);
+        hipLaunchKernelGGL(k_t_absmax, dim3(256, 3), dim3(256), 0, r, am, t->wmax);
         for (int l = 1; l < 4; ++l)
-            hipLaunchKernelGGL(k_t_rows_to_h2, dim3((unsigned)((h2_threads + 255) / 256)), dim3(256), 0, r, t->Wt[l], 9 * C, C, 9, t->wmax + (l - 1),
-                               t->Wh[l], t->wscale[l]);
+            hipLaunchKernelGGL(k_t_w_to_h2<0>, dim3(h2_blocks), dim3(256), 0, r, t->param(6 * l), C, C, t->wmax + (l - 1), t->Wh[l], t->wscale[l]);
+        OZ_HIP(hipGetLastError());
+    }
+    for (int l = t->h2 ? 4 : 1; l < 6; ++l) {      // fp32 forward operands (the dense layers; the 3x3 layers too in f32 mode)
+        hipLaunchKernelGGL(k_t_transpose, dim3((Ns[l] + 31) / 32, (Ks[l] + 31) / 32), dim3(256), 0, r, t->param(6 * l), Ks[l], Ns[l], t->Wt[l]);
         OZ_HIP(hipGetLastError());
     }
     if (t->overlap) OZ_HIP(hipEventRecord(t->ev_wt, r));
     for (int l = 1; l < 4; ++l) {
-        const long long cnt = 9LL * C * C;
-        hipLaunchKernelGGL(k_t_dgrad_operand, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, r, t->param(6 * l), C, C, t->Wd[l]);
         if (t->h2)
-            hipLaunchKernelGGL(k_t_rows_to_h2, dim3((unsigned)((h2_threads + 255) / 256)), dim3(256), 0, r, t->Wd[l], 9 * C, C, 9, t->wmax + (l - 1),
-                               t->Whd[l], (float*)nullptr);
+            hipLaunchKernelGGL(k_t_w_to_h2<1>, dim3(h2_blocks), dim3(256), 0, r, t->param(6 * l), C, C, t->wmax + (l - 1), t->Whd[l], (float*)nullptr);
+        else {
+            const long long cnt = 9LL * C * C;
+            hipLaunchKernelGGL(k_t_dgrad_operand, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, r, t->param(6 * l), C, C, t->Wd[l]);
+        }
         OZ_HIP(hipGetLastError());
     }
     if (t->overlap) OZ_HIP(hipEventRecord(t->ev_wd, r));
@@ -999,7 +1011,7 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
         const int Cc = t->Co[l], P = t->P_[l];
         const float post = l >= 4 && t->rate > 0.f ? 1.0f / (1.0f - t->rate) : 1.0f;
         static const bool bnb_split = !(getenv("OZ_BN_BWD_SPLIT") && atoi(getenv("OZ_BN_BWD_SPLIT")) == 0);
-        if (bnb_split && (long long)B * P > OZ_BNB_MIN_ROWS && (long long)B * P <= OZ_BNB_MAX_ROWS) {
+        if ((bnb_split || t->h2) && (long long)B * P > OZ_BNB_MIN_ROWS && (long long)B * P <= OZ_BNB_MAX_ROWS) {
             // partial sums over row splits, then one launch that finishes the sums and writes dz (oz_train_fused.h)
             const long long M = (long long)B * P;
             const int Q = Cc / 4, lpr = Q < 64 ? Q : 64, rpp = 256 / lpr;
@@ -1022,7 +1034,8 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
         } else if ((long long)B * P <= OZ_BN_FUSED_MAX_ROWS) {  // small batch: BN backward, dgamma / dbeta / bias gradient in one launch
             hipLaunchKernelGGL(k_t_bn_bwd_fused, dim3(Cc / OZ_BN_COLS), dim3(1024), 0, s, t->dA[cur], t->a[l], t->z[l], t->mean[l], t->rstd[l],
                                t->param(6 * l + 2), post, t->d_count, t->Hout[l], Cc, t->Hz[l], t->zoff[l], t->dz[l], t->grad(6 * l + 2),
-                               t->grad(6 * l + 3), t->grad(6 * l + 1));
+                               t->grad(6 * l + 3), t->grad(6 * l + 1), t->h2 ? t->dzmax + l : (unsigned*)nullptr);
+            have_dzmax = t->h2 != 0;
             OZ_HIP(hipGetLastError());
         } else {
         RedArgs r = {}; r.x = t->dA[cur]; r.a = t->a[l]; r.z = t->z[l]; r.mean = t->mean[l]; r.rstd = t->rstd[l]; r.post_scale = post; r.P = P; r.C = Cc;
@@ -1099,6 +1112,9 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
                                        t->dzmax + l, t->wmax + (l - 1), t->dz_h2[l], t->dscale[l], Cin[l]);
                     if (int rc = oz_gemm_h2_launch(t->dz_h2[l], t->Whd[l], t->dscale[l], t->zeros, t->dA[cur ^ 1], t->d_count, B, t->Hz[l], Hin[l], same ? 1 : 0, Cc, 9,
                                                    Cin[l], s, t->gpartial, t->gpartial_floats, t->zeros, t->h2flag)) return rc;
+                } else if (t->h2) {
+                    oz_set_error("trainer f16x2: no |dz| maximum for layer %d", l);        // (every BN backward path of this mode leaves one)
+                    return OZ_ERR_STATE;
                 } else
                 // (the non-zero core of the zero-bordered dz buffer: taps that only read the border are skipped at large batch)
                 if (int rc = oz_gemm_f32_launch(t->dz[l], t->Wd[l], t->ones, t->zeros, t->dA[cur ^ 1], t->d_count, B, t->Hz[l], Hin[l], same ? 1 : 0, Cc, 9,

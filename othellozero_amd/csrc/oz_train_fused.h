@@ -62,7 +62,8 @@ __global__ __launch_bounds__(1024) void k_t_bn_bwd_fused(const float* __restrict
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, float post_scale, const int* __restrict__ d_count,
                                                         int Hout, int C, int Hz, int zoff, float* __restrict__ dz,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
+                                                        unsigned* __restrict__ dzmax /* nullable: atomic max of |dz| (bit pattern), f16x2 data gradient */) {
     __shared__ float sh[OZ_BN_RL][OZ_BN_COLS];
     const int c64 = threadIdx.x & (OZ_BN_COLS - 1), lane4 = threadIdx.x / OZ_BN_COLS, c = blockIdx.x * OZ_BN_COLS + c64;
     const int P = Hout * Hout;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(1024) void k_t_bn_bwd_fused(const float* __restrict
     const float S0 = t_block_sum4(s0, sh, lane4, c64);
     const float S1 = t_block_sum4(s1, sh, lane4, c64);
     const float inv = 1.0f / (float)M, gr = gamma[c] * rs;
-    float sb = 0.f;
+    float sb = 0.f, amax = 0.f;
     _Pragma("unroll 4") for (long long m = lane4; m < M; m += OZ_BN_RL) {
         const size_t i = (size_t)m * C + c;
         const float dy = a[i] > 0.f ? dA[i] * post_scale : 0.f;
@@ -87,6 +88,11 @@ __global__ __launch_bounds__(1024) void k_t_bn_bwd_fused(const float* __restrict
         const int b = (int)(m / P), pix = (int)(m % P);
         dz[(((size_t)b * Hz + pix / Hout + zoff) * Hz + pix % Hout + zoff) * C + c] = g;
         sb += g;
+        amax = fmaxf(amax, fabsf(g));
+    }
+    if (dzmax) {
+        for (int o = 32; o; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(dzmax, __float_as_uint(amax));
     }
     const float SB = t_block_sum4(sb, sh, lane4, c64);
     if (lane4 == 0) { dgamma[c] = S1; dbeta[c] = S0; dbias[c] = SB; }
