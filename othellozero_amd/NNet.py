@@ -108,8 +108,9 @@ class NNetWrapper(_NetHandle):
 
     def train(self, examples, verbose=None, seed=None, allreduce=None):
         """Net/NNet.py:53-68: model.fit(x=boards, y=[pis, vs], batch_size=self.batch_size, epochs=self.epochs) on the GPU
-        (oz_trainer_*: fp32 MFMA forward / backward, Adam lr=self.lr with clipvalue 0.5 for ONN / none for BNN, Dropout
-        self.dropout, BN momentum 0.99).  Returns a History-like object (`.history['loss']`, ...).  The TensorBoard
+        (oz_trainer_*: MFMA forward / backward in the wrapper's precision -- "f16x2" runs the 3x3 layers' forward and data
+        gradient on the fp16 matrix cores like the inference kernels (needs num_channels % 256 == 0, else fp32) -- Adam
+        lr=self.lr with clipvalue 0.5 for ONN / none for BNN, Dropout self.dropout, BN momentum 0.99).  Returns a History-like object (`.history['loss']`, ...).  The TensorBoard
         callback of the reference is not reproduced.  Optimiser state persists across calls like the compiled Keras model's."""
         from . import trainer as T
         if not examples:
@@ -121,7 +122,8 @@ class NNetWrapper(_NetHandle):
             self._trainer = T.Trainer(self.board_size_x, self.num_channels, self.in_channels, max_batch=self.batch_size, lr=self.lr,
                                       clipvalue=0.5 if self.network_type is NeuralNets.ONN else 0.0, dropout=self.dropout,
                                       seed=self._model_index if seed is None else seed,
-                                      external_grads_ptr=getattr(allreduce, "ptr", None))
+                                      external_grads_ptr=getattr(allreduce, "ptr", None),
+                                      precision="f16x2" if self.precision == "f16x2" and self.num_channels % 256 == 0 else "f32")
             self._trainer_arena = getattr(allreduce, "ptr", None)
             self._fit_calls = 0
         assert getattr(allreduce, "ptr", None) == self._trainer_arena, "train() must keep using the GradientAllReduce it started with"

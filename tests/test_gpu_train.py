@@ -117,14 +117,15 @@ def test_no_dropout_no_clip_and_determinism():
     assert l1 == l2 and all(np.array_equal(g1[i], g2[i]) for i in g1)          # fixed-order reductions: bit-reproducible
 
 
-def test_adam_steps_and_moving_statistics_match():
+@pytest.mark.parametrize("precision,C", [("f32", 128), ("f16x2", 256)])
+def test_adam_steps_and_moving_statistics_match(precision, C):
     """Step-locked comparison: at every step the gradients are checked against autograd at the (matched) weights, then
     BOTH sides apply Adam to the GPU's gradients, so the update rule and the BN statistics are compared exactly.
     (Letting each side use its own gradients is not a parity test: where |g| is at rounding level Adam's m / sqrt(v)
     amplifies the noise to steps of +-lr, in TensorFlow as much as here.)"""
     import torch
-    n, C, B, steps = 6, 128, 8, 4
-    ref, gpu = _pair(n, C, 2, B, seed=5)
+    n, B, steps = 6, 8, 4             # (f16x2: the weight operands and their power-of-two scales are rebuilt from the moved weights every step)
+    ref, gpu = _pair(n, C, 2, B, seed=5, precision=precision)
     w0 = ref.weights()
     for s in range(steps):
         lg, lr_ = _both(ref, gpu, _batch(n, B, 20 + s))
@@ -210,17 +211,18 @@ def test_nnetwrapper_train_drop_in():
     assert net._trainer.step == 6 * 3 + 6 * 2 and np.isfinite(hist2.history["loss"]).all()
 
 
-def test_resident_dataset_fit_equals_stepwise_fit():
+@pytest.mark.parametrize("precision,C", [("f32", 128), ("f16x2", 256)])
+def test_resident_dataset_fit_equals_stepwise_fit(precision, C):
     """trainer.fit with the examples resident in HBM (one upload, one library call per epoch, batches gathered by index on
     the device, no per-step synchronisation) takes exactly the optimiser steps of the step-wise loop: identical weights
     bit for bit after two epochs with a short last batch, the same epoch-mean losses"""
     from othellozero_amd.trainer import Trainer, fit
     from othellozero_amd.weights import init_weights
-    n, C, N, bs = 6, 128, 75, 16
+    n, N, bs = 6, 75, 16
     own, opp, pi, z = _batch(n, N, seed=77)
     runs = []
     for resident in (False, True):
-        tr = Trainer(n, C, 2, max_batch=bs, seed=9)
+        tr = Trainer(n, C, 2, max_batch=bs, seed=9, precision=precision)
         tr.set_weights(init_weights(n, seed=1, channels=C))
         h = fit(tr, own, opp, pi, z, batch_size=bs, epochs=2, shuffle_seed=5, resident=resident)
         runs.append((tr.get_weights(), h.history, tr.step))
