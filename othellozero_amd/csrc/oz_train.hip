@@ -85,18 +85,34 @@ __global__ __launch_bounds__(256) void k_t_conv1_wgrad(const uint64_t* __restric
     float acc[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) acc[i] = 0.f;
-    for (long long m = sp; m < M; m += S) {
-        const int b = (int)(m / P), pix = (int)(m % P), y0 = pix / n, x0 = pix % n;
-        const uint64_t o = own[b], p = opp[b];
-        const float d = dz[(size_t)m * C + co];
+    // four rows of the split per trip: their loads (a dz element and two bitboards each) are issued together, the sums stay in row order
+    for (long long m0 = sp; m0 < M; m0 += 4LL * S) {
+        float d[4];
+        uint64_t o[4], p[4];
+        int pixs[4];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int y = y0 + t / 3 - 1, x = x0 + t % 3 - 1;
-            if (y < 0 || y >= n || x < 0 || x >= n) continue;
-            const int sq = y * 8 + x;
-            const float a = (float)((o >> sq) & 1), bb = (float)((p >> sq) & 1);
-            if (cin == 2) { acc[2 * t] = fmaf(a, d, acc[2 * t]); acc[2 * t + 1] = fmaf(bb, d, acc[2 * t + 1]); }
-            else acc[t] = fmaf(a - bb, d, acc[t]);
+        for (int u = 0; u < 4; ++u) {
+            const long long m = m0 + (long long)u * S;
+            const bool in = m < M;
+            const long long mm = in ? m : m0;
+            const int b = (int)(mm / P);
+            pixs[u] = in ? (int)(mm % P) : -1;
+            o[u] = own[b]; p[u] = opp[b];
+            d[u] = dz[(size_t)mm * C + co];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (pixs[u] < 0) continue;
+            const int y0 = pixs[u] / n, x0 = pixs[u] % n;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int y = y0 + t / 3 - 1, x = x0 + t % 3 - 1;
+                if (y < 0 || y >= n || x < 0 || x >= n) continue;
+                const int sq = y * 8 + x;
+                const float a = (float)((o[u] >> sq) & 1), bb = (float)((p[u] >> sq) & 1);
+                if (cin == 2) { acc[2 * t] = fmaf(a, d[u], acc[2 * t]); acc[2 * t + 1] = fmaf(bb, d[u], acc[2 * t + 1]); }
+                else acc[t] = fmaf(a - bb, d[u], acc[t]);
+            }
         }
     }
     for (int tc = 0; tc < 9 * cin; ++tc) partial[((size_t)sp * 9 * cin + tc) * C + co] = acc[tc];
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(128) void k_t_heads_wgrad(const float* __restrict__
     const int k = blockIdx.x, a = threadIdx.x, B = *d_count;
     if (a > A) return;
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc = fmaf(f2[(size_t)b * 512 + k], a < A ? dlogit[(size_t)b * A + a] : dvpre[b], acc);
+    _Pragma("unroll 8") for (int b = 0; b < B; ++b) acc = fmaf(f2[(size_t)b * 512 + k], a < A ? dlogit[(size_t)b * A + a] : dvpre[b], acc);    // 8 loads in flight, sums in batch order
     if (a < A) dWpi[(size_t)k * A + a] = acc; else dWv[k] = acc;
 }
 // dbpi[a] = sum_b dlogit[b][a]; dbv = sum_b dvpre[b]; losses[0..2] = total, pi, v (batch means)
@@ -326,11 +342,11 @@ __global__ __launch_bounds__(128) void k_t_heads_bias(const float* __restrict__ 
                                                       const int* __restrict__ d_count, int A, float* __restrict__ dbpi, float* __restrict__ dbv,
                                                       float* __restrict__ losses) {
     const int a = threadIdx.x, B = *d_count;
-    if (a < A) { float s = 0.f; for (int b = 0; b < B; ++b) s += dlogit[(size_t)b * A + a]; dbpi[a] = s; }
-    if (a == A) { float s = 0.f; for (int b = 0; b < B; ++b) s += dvpre[b]; dbv[0] = s; }
+    if (a < A) { float s = 0.f; _Pragma("unroll 8") for (int b = 0; b < B; ++b) s += dlogit[(size_t)b * A + a]; dbpi[a] = s; }
+    if (a == A) { float s = 0.f; _Pragma("unroll 8") for (int b = 0; b < B; ++b) s += dvpre[b]; dbv[0] = s; }
     if (a == A + 1) {
         float lp = 0.f, lv = 0.f;
-        for (int b = 0; b < B; ++b) { lp += loss[2 * b]; lv += loss[2 * b + 1]; }
+        _Pragma("unroll 8") for (int b = 0; b < B; ++b) { lp += loss[2 * b]; lv += loss[2 * b + 1]; }
         lp /= (float)B; lv /= (float)B;
         losses[0] = lp + lv; losses[1] = lp; losses[2] = lv;
     }

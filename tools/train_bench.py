@@ -77,7 +77,10 @@ def main():
                       # the step as a whole against the fp32 matrix-core roof (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md): algorithmic
                       # contraction FLOP of forward + data gradient + weight gradient / wall time of the whole step (BN, losses, Adam included)
                       "roofline": {"bound": "mfma", "achieved": flop * args.steps / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                                   "frac": flop * args.steps / dt / 1e12 / 157.3, "traffic": None},
+                                   "frac": flop * args.steps / dt / 1e12 / 157.3, "traffic": None,
+                                   "note": ("fp32 matrix roof; precision f16x2 runs the 3x3 layers' forward and data gradient as 3 fp16 MFMA products per "
+                                            "fp32 product (roof 2500 / 3 = 833 TFLOP/s for that share of the FLOP), the weight gradients and dense layers "
+                                            "on the fp32 matrix cores -- frac may exceed 1") if args.precision == "f16x2" else "fp32 matrix roof"},
                       "adam_bytes_per_step": params * 4 * 7, "last_loss": loss[0], "dtype": args.precision, "data": "synthetic"}))
 
 
