@@ -20,7 +20,8 @@ loop.evaluate_against_random_batch = timed("evaluation vs random, lock-step aren
 
 batched = "--batched-eval" in sys.argv
 n = 6
-net = NNetWrapper((n, n), num_channels_1=512, batch_size=32, epochs=10, max_batch=128, precision="f16x2")
+precision = "f32" if "--f32" in sys.argv else "f16x2"        # inference AND training arithmetic of the wrapper
+net = NNetWrapper((n, n), num_channels_1=512, batch_size=32, epochs=10, max_batch=128, precision=precision)
 net.train = timed("fit (10 epochs, batch 32)", net.train)
 os.chdir(tempfile.mkdtemp())
 t0 = time.perf_counter()
@@ -30,7 +31,7 @@ hist = loop.training(board_size=n, num_iterations=1, num_episodes=100, num_simul
                      checkpoint_filepath="./othelo_model_weights.h5", training_buffer_size=8 * 32 * 100 * 3, seed=1,
                      batched_evaluation=batched)
 total = time.perf_counter() - t0
-out = {"metric": "seconds_per_training_iteration", "value": total, "settings": "main.py defaults (board 6)", "batched_eval": batched,
+out = {"metric": "seconds_per_training_iteration", "value": total, "settings": "main.py defaults (board 6)", "batched_eval": batched, "precision": precision,
        "phases": {}, "historic": hist}
 for name, dt in marks:
     out["phases"][name] = round(out["phases"].get(name, 0.0) + dt, 3)
