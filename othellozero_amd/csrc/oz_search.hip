@@ -970,15 +970,18 @@ __global__ __launch_bounds__(64) void k_sp_move(GamesDev gm, MctsDev t, int aren
 // moves and random draws is exactly the lock-step one (games are independent, streams are keyed by game id and ply, a
 // position's (pi, v) does not depend on the batch it sits in), so records are identical; only the interleaving of the
 // games changes.  OZ_ADVANCE_CAP bounds the work of one call (late-game positions whose whole remaining tree is known
-// can run many network-free simulations); a game that hits the cap simply contributes no leaf to this batch.
-#define OZ_ADVANCE_CAP 24
-__global__ __launch_bounds__(64) void k_advance(GamesDev gm, MctsDev t, int sims, int* __restrict__ sims_done) {
+// can run many network-free simulations); a game that hits the cap simply contributes no leaf to this batch.  The launch lasts
+// as long as its slowest wave, so the cap trades batch fill for launch time -- measured at 4096 games x 100 simulations
+// (bench.py --driver free): cap 24 -> 4081 leaves per batch but 367 us per launch, 1.40 M expansions/s; cap 8 -> 1.56 M;
+// cap 4 -> 1.585 M; cap 2 -> 3908 leaves per batch, 1.59 M (the lock-step driver: 1.56 M).  env OZ_ADVANCE_CAP overrides.
+#define OZ_ADVANCE_CAP 2
+__global__ __launch_bounds__(64) void k_advance(GamesDev gm, MctsDev t, int sims, int* __restrict__ sims_done, int cap) {
     __shared__ TreeLds L;
     const int g = blockIdx.x, lane = threadIdx.x;
     int done = sims_done[g];
     if (t.leaf_status[g] == OZ_LEAF_EVAL) ++done;          // the simulation whose leaf the previous step evaluated and backed up
     int status = OZ_LEAF_IDLE;
-    for (int it = 0; it < OZ_ADVANCE_CAP; ++it) {
+    for (int it = 0; it < cap; ++it) {
         if (gm.finished[g]) { if (lane == 0) { t.active[g] = 0; t.leaf_status[g] = OZ_LEAF_IDLE; } status = OZ_LEAF_IDLE; break; }
         // roots of the position to move in (k_sp_roots)
         const int p = gm.player[g];
@@ -1212,7 +1215,8 @@ OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
         const bool all = m->profile;
         hipStream_t s = m->stream;
         int ti = all ? m->timer.begin(TS_SELECT, s) : -1;
-        hipLaunchKernelGGL(k_advance, dim3(d.G), dim3(64), 0, s, sp->gm, d, sp->cfg.sims, sp->d_sims_done);
+        static const int adv_cap = getenv("OZ_ADVANCE_CAP") && atoi(getenv("OZ_ADVANCE_CAP")) > 0 ? atoi(getenv("OZ_ADVANCE_CAP")) : OZ_ADVANCE_CAP;     // A/B runs
+        hipLaunchKernelGGL(k_advance, dim3(d.G), dim3(64), 0, s, sp->gm, d, sp->cfg.sims, sp->d_sims_done, adv_cap);
         m->timer.end(ti, s);
         ti = all ? m->timer.begin(TS_COMPACT, s) : -1;
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, d);
