@@ -19,7 +19,7 @@ size different from --gpus is an error (exit 2), never a silent 1-GPU run.
 Prints ONE JSON line on rank 0: value = node expansions per second over all GPUs (the BASELINE metric; the same line
 carries games/s and sims/s), `roofline` for the dominant kernel (HIP events on the launch stream, in the timed region),
 and -- at N = 1 -- `kernels` (every kernel of a step against its own roof), `exact_fp32` (the same workload in exact fp32
-arithmetic), `config4` (6x6 boards), `cross_game_dedup`, `all_layers_as_gemm`, `dropin_config0` (configs[0] through the
+arithmetic), `config4` (6x6 boards), `other_driver` (the free-running driver), `cross_game_dedup`, `all_layers_as_gemm`, `dropin_config0` (configs[0] through the
 reference's Python surface), `parity_sample_max_err` and `cpu_baseline` (the CPU oracle -- the reference algorithm with
 batch-1 leaf evaluation -- timed on this host's cores on a bounded sample).  In the timed region the network evaluates
 EVERY expansion (cross-game de-duplication off).
@@ -413,18 +413,19 @@ def main():
         torch.cuda.synchronize()
 
     # one bench step = `sims` network batches of up to G leaves: a move round in lock step; in free-running mode the same
-    # number of batches, each full (network-free simulations and moves ride along).  Measured: no throughput difference --
-    # a batch's cost is proportional to its leaves, so filling the ~8 % empty slots buys nothing
-    def advance(e, k, sync):
-        if args.driver == "free":
+    # number of batches, each nearly full (network-free simulations and moves ride along).  Measured: +1 % expansions/s,
+    # +3 % games/s for the free-running driver (the `other_driver` leg) -- a batch's cost is close to proportional to its
+    # leaves, so filling the ~8 % empty slots buys little
+    def advance(e, k, sync, driver=None):
+        if (driver or args.driver) == "free":
             e.run_steps(k * args.sims, sync=sync)
         else:
             e.run(k, sync=sync)
 
-    def measure(e, steps, the_net=None):
+    def measure(e, steps, the_net=None, driver=None):
         """warm-up + `steps` timed move rounds on engine e (single rank, secondary legs) -> (stats delta, seconds);
         with the_net: HIP events around its dominant launch during the timed rounds only"""
-        advance(e, args.warmup, True)
+        advance(e, args.warmup, True, driver)
         e.sync()
         if the_net is not None:
             the_net.profile_kernels(reset=True)
@@ -432,7 +433,7 @@ def main():
         a = e.stats()
         torch.cuda.synchronize()
         t = time.perf_counter()
-        advance(e, steps, False)
+        advance(e, steps, False, driver)
         e.sync()
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t
@@ -571,6 +572,23 @@ def main():
                         "network evaluation (k_compact). Not the headline: `value` above evaluates every expansion"}
             del eng2
             wall["dedup_compare_s"] = round(time.perf_counter() - t_sec, 2)
+        if secondary:
+            # the same workload under the library's other driver (identical records per game: tests/test_gpu_bench_config.py)
+            t_sec = time.perf_counter()
+            other = "free" if args.driver == "lockstep" else "lockstep"
+            engo = make_engine(args.dedup == "on")
+            engo.stagger(cheap_pre)
+            qo, dto = measure(engo, args.steps, driver=other)
+            out["other_driver"] = {
+                "driver": other, "value": qo["expansions"] / dto, "unit": "node-expansions/s", "ms_per_step": dto / args.steps * 1e3,
+                "games_per_s": qo["games_completed"] / dto, "sims_per_s": qo["simulations"] / dto,
+                "leaves_per_batch": qo["leaves_evaluated"] / (args.steps * args.sims),
+                "note": ("oz_selfplay_run_steps: every game runs on by itself (network-free simulations and its move ride in the same launch), "
+                         "so nearly every slot of a batch carries a leaf; a game's records are those of lock step bit for bit"
+                         if other == "free" else "oz_selfplay_run: one simulation per game per batch, moves aligned")
+                        + f"; slots staggered at {cheap_pre} sims/move"}
+            del engo
+            wall["other_driver_s"] = round(time.perf_counter() - t_sec, 2)
         if secondary and layer == 3:
             # the same steps with conv1 / conv2 evaluated the plain way (conv1 kernel + conv2 as an MFMA implicit GEMM,
             # no pattern tables): what the table form buys, and a number for readers who want every layer as a GEMM

@@ -973,11 +973,9 @@ __global__ __launch_bounds__(64) void k_sp_move(GamesDev gm, MctsDev t, int aren
 // can run many network-free simulations); a game that hits the cap simply contributes no leaf to this batch.  The launch lasts
 // as long as its slowest wave, so the cap trades batch fill for launch time -- measured at 4096 games x 100 simulations
 // (bench.py --driver free): cap 24 -> 4081 leaves per batch but 367 us per launch, 1.40 M expansions/s; cap 8 -> 1.56 M;
-// cap 4 -> 1.585 M; cap 2 -> 3908 leaves per batch, 1.59 M (the lock-step driver: 1.56 M).  env OZ_ADVANCE_CAP overrides.
+// cap 4 -> 1.585 M; cap 2 -> 3908 leaves per batch, 1.59 M (1.60 M with k_backup_advance; the lock-step driver: 1.56-1.58 M).  env OZ_ADVANCE_CAP overrides.
 #define OZ_ADVANCE_CAP 2
-__global__ __launch_bounds__(64) void k_advance(GamesDev gm, MctsDev t, int sims, int* __restrict__ sims_done, int cap) {
-    __shared__ TreeLds L;
-    const int g = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void advance_body(const GamesDev& gm, const MctsDev& t, TreeLds& L, int g, int lane, int sims, int* __restrict__ sims_done, int cap) {
     int done = sims_done[g];
     if (t.leaf_status[g] == OZ_LEAF_EVAL) ++done;          // the simulation whose leaf the previous step evaluated and backed up
     int status = OZ_LEAF_IDLE;
@@ -1007,6 +1005,19 @@ __global__ __launch_bounds__(64) void k_advance(GamesDev gm, MctsDev t, int sims
         wave_sync();
     }
     if (lane == 0) sims_done[g] = done;
+}
+__global__ __launch_bounds__(64) void k_advance(GamesDev gm, MctsDev t, int sims, int* __restrict__ sims_done, int cap) {
+    __shared__ TreeLds L;
+    advance_body(gm, t, L, blockIdx.x, threadIdx.x, sims, sims_done, cap);
+}
+// expand + backup of the leaves the previous batch evaluated and the advance to the next batch's leaves in ONE launch (the free-running
+// counterpart of k_backup_select: one kernel boundary less per batch, the records just written are re-read from the CU's cache)
+__global__ __launch_bounds__(64) void k_backup_advance(GamesDev gm, MctsDev t, int sims, int* __restrict__ sims_done, int cap) {
+    __shared__ TreeLds L;
+    expand_backup_body(t, L, blockIdx.x, threadIdx.x, 0);
+    wave_sync();
+    __syncthreads();
+    advance_body(gm, t, L, blockIdx.x, threadIdx.x, sims, sims_done, cap);
 }
 
 // RandomOthelloAgent.play (agents.py:20-24) for every live game whose mover is `side`: random.choice over the valid
@@ -1211,12 +1222,15 @@ OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
     MctsDev& d = m->d;
     if (sp->mode == 1) OZ_HIP(hipMemsetAsync(d.leaf_status, 0, sizeof(int) * d.G, m->stream));    // no simulation is pending after whole rounds
     sp->mode = 2;
+    static const bool fuse = !(getenv("OZ_FUSE_STEP") && atoi(getenv("OZ_FUSE_STEP")) == 0);
     for (int i = 0; i < steps; ++i) {
         const bool all = m->profile;
         hipStream_t s = m->stream;
         int ti = all ? m->timer.begin(TS_SELECT, s) : -1;
         static const int adv_cap = getenv("OZ_ADVANCE_CAP") && atoi(getenv("OZ_ADVANCE_CAP")) > 0 ? atoi(getenv("OZ_ADVANCE_CAP")) : OZ_ADVANCE_CAP;     // A/B runs
-        hipLaunchKernelGGL(k_advance, dim3(d.G), dim3(64), 0, s, sp->gm, d, sp->cfg.sims, sp->d_sims_done, adv_cap);
+        // (from the second batch of a call on, the previous batch's expand + backup rides in the same launch; one closing k_expand_backup per call)
+        if (fuse && i > 0) hipLaunchKernelGGL(k_backup_advance, dim3(d.G), dim3(64), 0, s, sp->gm, d, sp->cfg.sims, sp->d_sims_done, adv_cap);
+        else hipLaunchKernelGGL(k_advance, dim3(d.G), dim3(64), 0, s, sp->gm, d, sp->cfg.sims, sp->d_sims_done, adv_cap);
         m->timer.end(ti, s);
         ti = all ? m->timer.begin(TS_COMPACT, s) : -1;
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, d);
@@ -1224,9 +1238,11 @@ OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
         ti = m->timer.begin(TS_NN, s);
         if (int rc = oz_net_forward_device(sp->net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, s)) { m->timer.cancel(ti); return rc; }
         m->timer.end(ti, s);
-        ti = all ? m->timer.begin(TS_BACKUP, s) : -1;
-        hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, s, d, 0);
-        m->timer.end(ti, s);
+        if (!fuse || i == steps - 1) {
+            ti = all ? m->timer.begin(TS_BACKUP, s) : -1;
+            hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, s, d, 0);
+            m->timer.end(ti, s);
+        }
         OZ_HIP(hipGetLastError());
         if (m->timer.backlog() > 8192) { if (int rc = mcts_collect_eval_time(m)) return rc; }
     }

@@ -202,6 +202,37 @@ def test_stagger_spreads_games_and_keeps_records_exact(oz):
         assert np.array_equal(r["action"], ep["action"]) and np.array_equal(r["z"], ep["z"]), g
 
 
+def test_free_running_driver_at_config2_size_equals_lock_step(oz, monkeypatch):
+    """bench.py's default driver (oz_selfplay_run_steps: a game runs on by itself, batches stay full) at the bench's own size -- 4096
+    staggered 8x8 games x 100 simulations on the 512-filter network, f16x2, one evaluation per expansion: every game that completes
+    under both drivers has the records of the lock-step driver (whose games the tests above replay with the oracle) bit for bit"""
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    n, G, sims = 8, B, 100
+    monkeypatch.setenv("OZ_DEDUP", "0")
+    net = NNetWrapper((n, n), num_channels_1=C, max_batch=G, seed=0, precision="f16x2")
+
+    def make():
+        return SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=0, game_id_stride=G, q_mode=1, refill=True,
+                              record_cap=G * 16)
+    lock = make()
+    lock.stagger(8)
+    lock.run(3)
+    rl, sl = lock.records(), lock.stats()
+    del lock
+    free = make()
+    free.stagger(8)
+    free.run_steps(3 * sims + 40)
+    rf, sf = free.records(), free.stats()
+    assert sl["overflow"] == 0 and sf["overflow"] == 0
+    il, jf = set(int(x) for x in np.unique(rl["game_id"])), set(int(x) for x in np.unique(rf["game_id"]))
+    both = sorted(il & jf)
+    assert len(both) >= 150, (len(il), len(jf), len(both))                  # ~68 games complete per move round
+    order = lambda r: r[np.lexsort((r["ply"], r["game_id"]))]
+    a, b = order(rl[np.isin(rl["game_id"], both)]), order(rf[np.isin(rf["game_id"], both)])
+    assert a.tobytes() == b.tobytes()
+
+
 def test_config3_last_rank_shard_at_full_size(oz):
     """BASELINE configs[2] (32768 games over 8 GPUs) as ONE rank sees it: the engine of rank 7 of 8 -- 4096 slots holding
     global game ids [28672, 32768), refills stepping by the job-wide 32768 -- at 100 sims/move: per-game RNG streams are keyed

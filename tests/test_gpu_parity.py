@@ -908,6 +908,7 @@ def test_bench_single_rank_contract(tmp_path):
     e32 = out["exact_fp32"]
     assert e32["value"] > 0 and e32["dtype"] == "f32" and e32["roofline"]["peak"] == 157.3 and 0 < e32["roofline"]["frac"] < 1
     assert out["config4"]["value"] > 0 and out["config4"]["games_per_s"] > 0
+    assert out["other_driver"]["driver"] == "free" and out["other_driver"]["value"] > 0 and out["other_driver"]["leaves_per_batch"] > 0.5 * 256
     names = [k["name"] for k in out["kernels"]]
     for k in ("conv2", "conv3", "conv4", "fc1", "fc2", "heads", "select", "compact", "expand_backup", "roots_move"):
         assert k in names, k
