@@ -383,7 +383,10 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
                       int Hin, int Hout, int pad, int Cin, int taps, int N, hipStream_t s, float* partial, long long partial_floats,
                       const void* zero_line, int* flag) {
     OZ_REQUIRE(N % 256 == 0 && Cin % 32 == 0, "gemm_h2: N %% 256 and Cin %% 32 must be 0 (N=%d Cin=%d)", N, Cin);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};                       // per device: function attributes belong to the device the caller is on
+    int dev_now = 0;
+    OZ_HIP(hipGetDevice(&dev_now));
+    bool& attr_set = attr_set_dev[dev_now & 63];
     if (!attr_set) {
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2BigPP::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
