@@ -202,14 +202,15 @@ def test_stagger_spreads_games_and_keeps_records_exact(oz):
         assert np.array_equal(r["action"], ep["action"]) and np.array_equal(r["z"], ep["z"]), g
 
 
-def test_free_running_driver_at_config2_size_equals_lock_step(oz, monkeypatch):
+@pytest.mark.parametrize("dedup", [False, True])
+def test_free_running_driver_at_config2_size_equals_lock_step(oz, monkeypatch, dedup):
     """bench.py's default driver (oz_selfplay_run_steps: a game runs on by itself, batches stay full) at the bench's own size -- 4096
     staggered 8x8 games x 100 simulations on the 512-filter network, f16x2, one evaluation per expansion: every game that completes
     under both drivers has the records of the lock-step driver (whose games the tests above replay with the oracle) bit for bit"""
     from othellozero_amd.NNet import NNetWrapper
     from othellozero_amd.training import SelfPlayEngine
     n, G, sims = 8, B, 100
-    monkeypatch.setenv("OZ_DEDUP", "0")
+    monkeypatch.setenv("OZ_DEDUP", "1" if dedup else "0")       # bench headline (off) and the library default (on)
     net = NNetWrapper((n, n), num_channels_1=C, max_batch=G, seed=0, precision="f16x2")
 
     def make():

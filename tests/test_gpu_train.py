@@ -243,7 +243,9 @@ from othellozero_amd.weights import init_weights
 rank = int(os.environ["RANK"])
 dist.init_process_group("gloo", rank=rank, world_size=2)          # control-flow rehearsal: both ranks share GPU 0
 torch.cuda.set_device(0)
-n, C, B, N = 6, 128, 8, 24
+n, B, N = 6, 8, 24
+precision = sys.argv[2]
+C = 256 if precision == "f16x2" else 128
 w = init_weights(n, seed=3, channels=C, randomize_all=True)
 def shard(r):
     rs = np.random.RandomState(100 + r)
@@ -253,7 +255,7 @@ def shard(r):
     pi = np.zeros((N, n * n), np.float32); pi[np.arange(N), rs.randint(0, n * n, N)] = 1
     return own, opp, pi, rs.choice([-1.0, 1.0], N).astype(np.float32)
 ar = GradientAllReduce(n, C, 2, device="cuda")
-tr = Trainer(n, C, 2, max_batch=B, seed=9, external_grads_ptr=ar.ptr)
+tr = Trainer(n, C, 2, max_batch=B, seed=9, external_grads_ptr=ar.ptr, precision=precision)
 tr.set_weights(w)
 hist = fit(tr, *shard(rank), batch_size=B, epochs=2, shuffle_seed=5, allreduce=ar)
 mine = tr.get_weights()
@@ -265,7 +267,7 @@ avg = average_moving_statistics(mine)
 if rank == 0:
     # single-process emulation of the same job: two trainers, gradients averaged by hand between backward and apply
     g = [torch.zeros(Trainer.arena_size(n, C, 2), dtype=torch.float32, device="cuda") for _ in range(2)]
-    t2 = [Trainer(n, C, 2, max_batch=B, seed=9, external_grads_ptr=g[r].data_ptr()) for r in range(2)]
+    t2 = [Trainer(n, C, 2, max_batch=B, seed=9, external_grads_ptr=g[r].data_ptr(), precision=precision) for r in range(2)]
     data = [shard(r) for r in range(2)]
     for t in t2: t.set_weights(w)
     for ep in range(2):
@@ -288,9 +290,10 @@ print("RANK_OK", rank)
 '''
 
 
-def test_data_parallel_two_ranks_equal_hand_averaged_gradients(tmp_path):
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+def test_data_parallel_two_ranks_equal_hand_averaged_gradients(tmp_path, precision):
     """GradientAllReduce + fit on two ranks (gloo, both on GPU 0): weights stay identical across ranks and equal, bit
-    for bit, a single-process run that averages the two gradient arenas by hand."""
+    for bit, a single-process run that averages the two gradient arenas by hand -- in both trainer precisions."""
     import os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "dp_gpu_worker.py"
@@ -299,7 +302,7 @@ def test_data_parallel_two_ranks_equal_hand_averaged_gradients(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        procs.append(subprocess.Popen([sys.executable, str(script), root, precision], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {rank}" in out, out
