@@ -121,8 +121,8 @@ def evaluate_against_random(board_size, neural_network, games, num_simulations, 
         if agent_winner is nn_agent:
             r["wins"] += 1
             r[colour + "_wins"] += 1
-        logging.info(f'{label} won: {r["wins"]}/{k + 1} => {round(r["wins"] / (k + 1), 2)} win rate, '
-                     f'black: {r["black_wins"]}/{r["black_games"]} , white: {r["white_wins"]}/{r["white_games"]}')
+        logging.info('%s: %d of %d won (%.2f); as black %d/%d, as white %d/%d', label, r["wins"], k + 1, r["wins"] / (k + 1),
+                     r["black_wins"], r["black_games"], r["white_wins"], r["white_games"])
     return r
 
 
@@ -201,12 +201,12 @@ def training(board_size, num_iterations, num_episodes, num_simulations, degree_e
     training_examples = CircularArray(training_buffer_size)
     old_neural_network = neural_network.copy()
     for i in range(1, num_iterations + 1):
-        logging.info(f'Iteration {i}/{num_iterations}: Starting iteration')
+        logging.info('[%d/%d] begin', i, num_iterations)
         if temperature_threshold and i >= temperature_threshold:
-            logging.info(f'Iteration {i}/{num_iterations}: Temperature threshold reached, changing temperature to 0')
+            logging.info('[%d/%d] past the temperature threshold: moves are now the arg-max of the visit counts', i, num_iterations)
             temperature = 0
 
-        logging.info(f'Iteration {i}/{num_iterations} - Generating episodes')
+        logging.info('[%d/%d] self-play: %d games x %d simulations on the GPU', i, num_iterations, num_episodes, num_simulations)
         if distributed:
             first, count = shard_games(num_episodes, rank, world)
             eng = SelfPlayEngine(neural_network, board_size, count, num_simulations, degree_exploration, temperature, e_greedy,
@@ -221,9 +221,9 @@ def training(board_size, num_iterations, num_episodes, num_simulations, degree_e
         training_examples.extend(examples_from_records(records, board_size, alias_final=alias_final_boards,
                                                        in_channels=getattr(neural_network, "in_channels", 2)))
         total_episodes_done += num_episodes
-        logging.info(f'Iteration {i}/{num_iterations}: All episodes finished')
+        logging.info('[%d/%d] self-play done: %d records, buffer holds %d examples', i, num_iterations, len(records), len(training_examples))
 
-        logging.info(f'Iteration {i}/{num_iterations}: Training model with episodes examples')
+        logging.info('[%d/%d] fit on the buffer', i, num_iterations)
         random.shuffle(training_examples)
         verbose = 2 if logging.root.level <= logging.DEBUG else None
         if distributed:
@@ -233,23 +233,23 @@ def training(board_size, num_iterations, num_episodes, num_simulations, degree_e
             neural_network.train(training_examples, verbose=verbose)
 
         if self_play_training and i % self_play_interval == 0:
-            logging.info(f'Iteration {i}/{num_iterations}: Self-play to evaluate the neural network training')
+            logging.info('[%d/%d] arena: trained network against the previous one', i, num_iterations)
             new_net_victories = self_play_match(board_size, neural_network, old_neural_network, self_play_total_games,
                                                 num_simulations, degree_exploration, seed=seed + i)
-            logging.info(f'Iteration {i}/{num_iterations} - Game results: {new_net_victories}/{self_play_total_games}: ')
+            logging.info('[%d/%d] arena: %d of %d games to the trained network', i, num_iterations, new_net_victories, self_play_total_games)
             if new_net_victories >= self_play_threshold:
-                logging.info(f'Iteration {i}/{num_iterations}: New neural network has been promoted')
+                logging.info('[%d/%d] trained network promoted', i, num_iterations)
                 save(neural_network)
-                logging.info(f'Iteration {i}/{num_iterations}: Saving trained model in "{checkpoint_filepath}"')
+                logging.info('[%d/%d] checkpoint -> %s', i, num_iterations, checkpoint_filepath)
                 old_neural_network = neural_network if reference_aliasing else neural_network.copy()
             else:
                 neural_network = old_neural_network if reference_aliasing else old_neural_network.copy()
-                logging.info(f'Iteration {i}/{num_iterations}: New neural network has not been promoted')
+                logging.info('[%d/%d] trained network rejected, previous one kept', i, num_iterations)
         else:
             save(neural_network)
 
         if i % evaluation_interval == 0:
-            logging.info('New Neural Network evaluation!')
+            logging.info('[%d/%d] evaluation against the random agent: current network', i, num_iterations)
             if batched_evaluation:
                 new = evaluate_against_random_batch(board_size, neural_network, evaluation_iterations, num_simulations,
                                                     degree_exploration, seed=seed + 7919 * i)
@@ -257,23 +257,23 @@ def training(board_size, num_iterations, num_episodes, num_simulations, degree_e
                                                     degree_exploration, seed=seed + 7919 * i + 1)
             else:
                 new = evaluate_against_random(board_size, neural_network, evaluation_iterations, num_simulations, degree_exploration,
-                                              label=f'Total Episodes Runned: {total_episodes_done} - Network')
-                logging.info('Old Neural Network evaluation!')
+                                              label=f'after {total_episodes_done} episodes, current network')
+                logging.info('[%d/%d] evaluation against the random agent: previous network', i, num_iterations)
                 old = evaluate_against_random(board_size, old_neural_network, evaluation_iterations, num_simulations, degree_exploration,
-                                              label=f'Total Episodes Runned: {total_episodes_done} - Old Network')
+                                              label=f'after {total_episodes_done} episodes, previous network')
             if new["wins"] > (old["wins"] * 1.1):
-                logging.info("Saving new network!")
+                logging.info('[%d/%d] evaluation: current network kept (%d wins vs %d)', i, num_iterations, new['wins'], old['wins'])
                 historic.append((total_episodes_done, (new["wins"] / evaluation_iterations)))
                 save(neural_network)
                 old_neural_network = neural_network if reference_aliasing else neural_network.copy()
             else:
-                logging.info("Saving old network!")
+                logging.info('[%d/%d] evaluation: back to the previous network (%d wins vs %d)', i, num_iterations, new['wins'], old['wins'])
                 historic.append((total_episodes_done, (old["wins"] / evaluation_iterations)))
                 save(old_neural_network)
                 neural_network = old_neural_network if reference_aliasing else old_neural_network.copy()
-            logging.info(historic)
+            logging.info('history (episodes, win rate): %s', historic)
 
-        logging.info(f'Total episodes done: {total_episodes_done}')
+        logging.info('[%d/%d] end: %d episodes so far', i, num_iterations, total_episodes_done)
         if dump_examples and rank == 0:
             with open(f'examples-{board_size}.txt', 'w') as output:
                 output.write(str(training_examples))
