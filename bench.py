@@ -2,12 +2,15 @@
 """bench.py -- self-play hot path on MI355X: BASELINE.json configs[1]
 (4096 concurrent 8x8 self-play games per GPU, 100 MCTS sims/move, random-init OthelloNN, batched leaf eval).
 
-One *step* = one move round: every one of the 4096 resident games runs 100 lock-step simulations (select ->
-leaf compaction -> one batched OthelloNN evaluation -> expand/backup, x100), then chooses, records and plays
-one move; a finished game is replaced by a fresh one in the same slot (continuous self-play).  Before the timed
-region the slots are spread over the plies of a game (oz_selfplay_stagger: slot g starts (g*60)/4096 plies into its
-first game, played untimed by the same searched self-play), so the engine is in the steady state of a long-running
-service: every move round completes ~G/60 games, and games/s, sims/s and expansions/s are all measured in any window.
+One *step* = 100 network batches (one per simulation of a move).  Every batch: each of the 4096 resident games advances on its
+own -- plays, records its move when its 100 simulations are complete (a finished game is replaced by a fresh one in the same
+slot: continuous self-play), runs simulations that end on finished boards, descends to its next first-visit leaf -- the leaves
+are compacted into one batch (at most 3640 of them: conv3's grid is then 4.0 rounds of the chip; a leaf without a slot waits for
+the next batch), ONE batched OthelloNN evaluation, expand / backup (oz_selfplay_run_steps, the free-running driver; every game's
+simulations, moves and records are exactly those of the lock-step driver, `--driver lockstep`, whose rate rides along as
+`other_driver`).  Before the timed region the slots are spread over the plies of a game (oz_selfplay_stagger: slot g starts
+(g*60)/4096 plies into its first game, played untimed by the same searched self-play), so the engine is in the steady state of a
+long-running service: games complete in any window, and games/s, sims/s and expansions/s are all measured.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -19,7 +22,7 @@ size different from --gpus is an error (exit 2), never a silent 1-GPU run.
 Prints ONE JSON line on rank 0: value = node expansions per second over all GPUs (the BASELINE metric; the same line
 carries games/s and sims/s), `roofline` for the dominant kernel (HIP events on the launch stream, in the timed region),
 and -- at N = 1 -- `kernels` (every kernel of a step against its own roof), `exact_fp32` (the same workload in exact fp32
-arithmetic), `config4` (6x6 boards), `other_driver` (the free-running driver), `cross_game_dedup`, `all_layers_as_gemm`, `dropin_config0` (configs[0] through the
+arithmetic), `config4` (6x6 boards), `other_driver` (the lock-step driver), `cross_game_dedup`, `all_layers_as_gemm`, `dropin_config0` (configs[0] through the
 reference's Python surface), `parity_sample_max_err` and `cpu_baseline` (the CPU oracle -- the reference algorithm with
 batch-1 leaf evaluation -- timed on this host's cores on a bounded sample).  In the timed region the network evaluates
 EVERY expansion (cross-game de-duplication off).
@@ -50,7 +53,16 @@ def conv_flop_per_leaf(layer, n, C):
     return 2 * px * (9 * C) * C                            # 8x8: conv2 301 989 888, conv3 169 869 312, conv4 75 497 472 FLOP
 
 
-def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, channels):
+def conv3_tile_rows(n, capacity, C):
+    """the row-tile height oz_net.hip picks for conv3 at a launch capacity of `capacity` leaves: the one that pays fewer tile rows
+    (rounds of 256 CUs x tile height); 6x6 boards always use 256"""
+    def cost(bm):
+        blocks = -(-capacity * (n - 2) ** 2 // bm) * (C // 256)
+        return -(-blocks // 256) * bm
+    return 256 if n == 6 or cost(256) < cost(192) else 192
+
+
+def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, channels, conv3_rows=192):
     """Dominant kernel.  precision f32 / f16x2 with the pattern tables (default): conv1 + conv2 run as a table gather-sum
     (k_conv2_lut), so the dominant launch is the conv3 implicit GEMM; without the tables it is the conv2 implicit GEMM.
     `achieved` is ALGORITHMIC fp32 TFLOP/s (2*M*K*N per launch / HIP-event time on the launch stream).
@@ -78,7 +90,9 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
         lut = os.environ.get("OZ_H2_LUT", "1") != "0" and pp
         tail = "implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, " + ("4-phase ping-pong loop" if pp else "one barrier per k-tile")
         if layer == 3:
-            kernel = f"k_gemm_h2<{'H2MidPP' if pp else 'H2Mid'}> (conv3: 3x3 valid, 512->512, 8x8 -> 6x6, {tail}); conv1 + conv2 = k_conv2_lut table gather-sum"
+            cfg = ("H2BigPP" if conv3_rows == 256 else "H2MidPP") if pp else ("H2Big" if conv3_rows == 256 else "H2Mid")
+            kernel = (f"k_gemm_h2<{cfg}> (conv3: 3x3 valid, 512->512, {n}x{n} -> {n - 2}x{n - 2}, {conv3_rows} x 256 tiles, {tail}); "
+                      "conv1 + conv2 = k_conv2_lut table gather-sum")
         elif lut:
             kernel = f"k_gemm_h2<H2BigPPLut> (conv2: 3x3 same, 512->512, {tail}; A rows gathered from the conv1 pattern table)"
         else:
@@ -90,7 +104,7 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
     return r
 
 
-def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tables):
+def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tables, driver="lockstep"):
     """every kernel of a move round against its own roof.  net_k / tree_k: {name: (ms_total, launches)} over `rounds` move
     rounds that evaluated `leaves` positions and ran `sims_done` simulations."""
     peak_mm = PEAK_F32_MATRIX_TFLOPS if precision == "f32" else PEAK_F16_MATRIX_TFLOPS
@@ -123,9 +137,13 @@ def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tabl
     for name, (ms, cnt) in tree_k.items():
         if name == "network" or cnt == 0:
             continue
-        out.append({"name": name, "kernel": {"select": "k_select (first simulation of a round) / k_backup_select (expand + backup of simulation s-1 fused with the descent of s)",
-                                             "compact": "k_compact", "expand_backup": "k_expand_backup (closing one of a round)",
-                                             "roots_move": "k_sp_roots + k_sp_move"}[name],
+        label = ({"select": "k_advance (first batch of a call) / k_backup_advance (expand + backup of the previous batch's leaves fused with every game's "
+                            "advance: its move when due, network-free simulations, the descent to its next leaf)",
+                  "compact": "k_compact (slot order rotating under the batch cap)", "expand_backup": "k_expand_backup (closing one of a call)",
+                  "roots_move": "k_sp_roots + k_sp_move"} if driver == "free" else
+                 {"select": "k_select (first simulation of a round) / k_backup_select (expand + backup of simulation s-1 fused with the descent of s)",
+                  "compact": "k_compact", "expand_backup": "k_expand_backup (closing one of a round)", "roots_move": "k_sp_roots + k_sp_move"})
+        out.append({"name": name, "kernel": label[name],
                     "ms_per_step": ms / rounds, "launches_per_step": cnt / rounds, "bound": "hbm (latency-bound integer work)",
                     # the tree side as a whole moves ~1.3 KB of algorithmic HBM bytes per simulation; this kernel's share of it by time
                     "achieved": sims_done * TREE_BYTES_PER_SIM / (tree_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -145,7 +163,7 @@ def tree_side(sims_per_s):
         tj = json.load(open(os.path.join(ROOT, "profiles", "tree_traffic.json")))
         t = tj["tree_side_bytes_per_sim"]
         r["measured"] = {"fetch_bytes_per_sim_raw": t["fetch_raw"], "fetch_bytes_per_sim_x2": t["fetch_x2"], "write_bytes_per_sim": t["write"],
-                         "descent_kernel_fetch_bytes_per_sim_x2": (tj["kernels"].get("k_backup_select") or tj["kernels"]["k_select"])["fetch_bytes_per_sim_x2"],
+                         "descent_kernel_fetch_bytes_per_sim_x2": (tj["kernels"].get("k_backup_advance") or tj["kernels"].get("k_backup_select") or tj["kernels"]["k_select"])["fetch_bytes_per_sim_x2"],
                          "source": "profiles/tree_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, the 100 launches of one timed move round; "
                                    "x2 = the gfx950 rule for 16-byte-per-lane reads, an upper bound for this access mix); not re-measured in this run"}
     except Exception:
@@ -350,7 +368,10 @@ def main():
                          "every expansion -- no output is shared or cached; on: the library default (a board reached by several "
                          "games in the same step is evaluated once).  With off, the on-rate is measured afterwards and reported "
                          "next to it (N = 1 only)")
-    ap.add_argument("--driver", default="lockstep", choices=["free", "lockstep"],
+    ap.add_argument("--batch-cap", type=int, default=-1,
+                    help="free-running driver: leaves per network batch; -1 = the cap at which conv3's grid is a whole number of rounds "
+                         "(training.preferred_batch_cap: 3640 for 4096 8x8 games, none on 6x6), 0 = none")
+    ap.add_argument("--driver", default="free", choices=["free", "lockstep"],
                     help="free: oz_selfplay_run_steps (every game runs on by itself, full leaf batches; identical records); "
                          "lockstep: oz_selfplay_run (one simulation per game per step, moves aligned)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)")
@@ -400,22 +421,30 @@ def main():
     net = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0, precision=args.precision)   # same weights on every rank
     net.profile(1)          # HIP events around the dominant launch from the first launch on; the timed region is the difference of two readings
 
+    from othellozero_amd.training import preferred_batch_cap
+
+    def batch_cap(board, games):
+        """leaves per network batch of the free-running driver (0: none)"""
+        return preferred_batch_cap(board, games, args.channels) if args.batch_cap < 0 else args.batch_cap
+
     def make_engine(dedup, the_net=net, board=n, games=G, steps=args.steps):
         os.environ["OZ_DEDUP"] = "1" if dedup else "0"          # read when the engine's search object is created
-        return SelfPlayEngine(the_net, board, games, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * games,
-                              game_id_stride=world * games, q_mode=_lib.QMODE_F64, refill=True,
-                              record_cap=int(games * (steps + args.warmup + board * board + 2) * 1.25))
+        e = SelfPlayEngine(the_net, board, games, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * games,
+                           game_id_stride=world * games, q_mode=_lib.QMODE_F64, refill=True,
+                           record_cap=int(games * (steps + args.warmup + board * board + 2) * 1.25))
+        e.set_batch_cap(batch_cap(board, games))                # used by the free-running driver only
+        return e
     eng = make_engine(args.dedup == "on")
+    cap_main = batch_cap(n, G) if args.driver == "free" else 0
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # one bench step = `sims` network batches of up to G leaves: a move round in lock step; in free-running mode the same
-    # number of batches, each nearly full (network-free simulations and moves ride along).  Measured: +1 % expansions/s,
-    # +3 % games/s for the free-running driver (the `other_driver` leg) -- a batch's cost is close to proportional to its
-    # leaves, so filling the ~8 % empty slots buys little
+    # one bench step = `sims` network batches: in free-running mode (default) every batch holds exactly the batch cap (3640 leaves at
+    # 4096 8x8 games: conv3 = 1024 tiles = 4.0 rounds of the chip); in lock step a step is a move round whose batches are ~91 % full and
+    # whose conv3 grid pays 6 rounds for 5.5 (the `other_driver` leg: -4 % expansions/s; DESIGN.md section 4)
     def advance(e, k, sync, driver=None):
         if (driver or args.driver) == "free":
             e.run_steps(k * args.sims, sync=sync)
@@ -495,13 +524,15 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{G} concurrent {n}x{n} self-play games per GPU, {args.sims} sims/move, batched leaf eval "
-                            "(BASELINE configs[1]); step = " + (f"{args.sims} network batches of up to {G} leaves, games free-running "
-                                                                  "(a game plays its move as soon as its simulations are complete; records identical to lock step), "
+                            "(BASELINE configs[1]); step = " + (f"{args.sims} network batches of up to {cap_main or G} leaves, games free-running "
+                                                                  "(a game plays its move as soon as its simulations are complete, a leaf that finds no slot "
+                                                                  "waits for the next batch; every game's records identical to lock step), "
                                                                   if args.driver == "free" else
                                                                   "one move round (100 lock-step simulations + one move per game), ") +
                             f"finished games refilled; leaf evaluator = the reference's OthelloNN ({args.channels} filters), random init seed 0",
                 "games_per_gpu": G, "sims_per_move": args.sims, "board": n,
-                "q_mode": "float64 (NumPy 1.18.5 promotion)", "driver": args.driver, "parallelism": f"games sharded x{world}, all-gather of move records",
+                "q_mode": "float64 (NumPy 1.18.5 promotion)", "driver": args.driver, "batch_cap": cap_main or None,
+                "parallelism": f"games sharded x{world}, all-gather of move records",
                 "backend": (args.backend if world > 1 else None),
                 "steady_state": (f"untimed oz_selfplay_stagger({stagger_sims}): slot g starts (g*{period})/{G} plies into its first game, those plies "
                                  f"played by searched self-play at {stagger_sims} sims/move; then {args.warmup} untimed warm-up rounds"
@@ -520,7 +551,8 @@ def main():
             "whole_net_tflops_rank0": d["leaves_evaluated"] * flop_exec / max(nn_ms * 1e-3, 1e-9) / 1e12,
             "flop_per_expansion": {"reference_network": flop_ref, "executed": flop_exec,
                                    "note": "executed < reference when conv1 + conv2 are evaluated as pattern-table lookups (exact refactoring, no GEMM)"},
-            "roofline": dict(roofline(args.precision, layer, achieved, dom_ms, dom_launches, d["leaves_evaluated"], n, args.channels),
+            "roofline": dict(roofline(args.precision, layer, achieved, dom_ms, dom_launches, d["leaves_evaluated"], n, args.channels,
+                                      conv3_rows=conv3_tile_rows(n, cap_main or G, args.channels)),
                              all_launches={"launches": int(dom_all_launches), "avg_launch_ms": dom_all_ms / max(dom_all_launches, 1),
                                            "leaves_per_launch": s1["leaves_evaluated"] / max(dom_all_launches, 1),
                                            "note": "every launch of this kernel since process start, incl. the untimed stagger and warm-up rounds "
@@ -548,7 +580,7 @@ def main():
             tree_k, net_k = eng.profile_read(), net.profile_kernels()
             eng.profile(False); net.profile(0)
             out["kernels"] = kernel_table(net_k, tree_k, rounds, b["leaves_evaluated"] - a["leaves_evaluated"], b["simulations"] - a["simulations"],
-                                          n, args.channels, args.precision, layer == 3)
+                                          n, args.channels, args.precision, layer == 3, args.driver)
             out["kernels_note"] = (f"HIP events around every launch, {rounds} further move rounds of the same engine after the timed region "
                                    "(events between launches add a few us each: the sum is slightly above ms_per_step)")
             wall["kernels_s"] = round(time.perf_counter() - t_sec, 2)

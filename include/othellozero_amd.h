@@ -39,6 +39,7 @@ extern "C" {
 #define OZ_LEAF_IDLE 0       /* game slot not searching                          */
 #define OZ_LEAF_TERMINAL 1   /* simulation ended on a finished board (MCTS/__init__.py:39-40) */
 #define OZ_LEAF_EVAL 2       /* first visit: needs NN evaluation (MCTS/__init__.py:44-57)     */
+#define OZ_LEAF_WAIT 3       /* free-running driver with a batch cap: the leaf is chosen and waits for a slot of a later batch */
 
 const char* oz_last_error(void);
 int oz_version(void);
@@ -184,6 +185,12 @@ int oz_selfplay_run(oz_selfplay* sp, int rounds);
  * leaf of its next first-visit simulation -- batches stay full instead of ~92 % full, moves are no longer aligned across
  * games, every game's simulations / moves / records are exactly those of oz_selfplay_run (training.py:39-67). */
 int oz_selfplay_run_steps(oz_selfplay* sp, int steps);
+/* batch cap of the free-running driver (0 = none, the default): a network batch holds at most `cap` leaves; a game whose leaf finds no
+ * slot keeps it (OZ_LEAF_WAIT) and offers it again in the next batch -- slots are handed out in game order from a start that rotates by
+ * `cap` games per batch, so every game is served.  A game's simulations / moves / records do not change; what changes is the size of the
+ * launches: the convolution grids are a whole number of rounds of the chip at the right cap (4096 8x8 games on the 512-filter network:
+ * cap 3640 = 1024 conv3 tiles of 256 x 256 = 4.0 rounds of 256 CUs, against 5.5 rounds paid as 6 without it). */
+int oz_selfplay_set_batch_cap(oz_selfplay* sp, int cap);
 int oz_selfplay_sync(oz_selfplay* sp);
 /* continuous self-play (cfg.refill): bring a fresh engine to the steady state of a long-running one before measuring it --
  * slot g is advanced (g * P) / num_games plies into its first game, P = n*n - 4, by searched self-play moves at `sims_pre`

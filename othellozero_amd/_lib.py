@@ -93,7 +93,7 @@ SIGNATURES = {
     "oz_mcts_stats": [_vp, _i64p],
     "oz_selfplay_create": [C.POINTER(_vp), C.POINTER(SelfplayConfig), _vp],
     "oz_selfplay_destroy": [_vp], "oz_selfplay_run": [_vp, C.c_int], "oz_selfplay_run_steps": [_vp, C.c_int], "oz_selfplay_sync": [_vp],
-    "oz_selfplay_stagger": [_vp, C.c_int], "oz_selfplay_profile": [_vp, C.c_int],
+    "oz_selfplay_stagger": [_vp, C.c_int], "oz_selfplay_profile": [_vp, C.c_int], "oz_selfplay_set_batch_cap": [_vp, C.c_int],
     "oz_selfplay_profile_read": [_vp, _f64p, _i64p, C.c_int],
     "oz_selfplay_get_stats": [_vp, C.POINTER(SelfplayStats)],
     "oz_selfplay_state": [_vp, _u64p, _u64p, _i8p, _u8p, _i32p, _u64p],

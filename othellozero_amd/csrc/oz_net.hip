@@ -778,8 +778,18 @@ struct OnnNet : oz_net {
         // conv3 tile: 192 rows on 8x8 (36 output pixels per board: 6.0 grid rounds at 4096 boards instead of 4.5); on 6x6 (16 pixels per board) the
         // 256-row tile = 16 whole boards, 2.0 rounds instead of 2.7 (OZ_H2_CONV3_BIG=0 / 1 forces one: A/B runs)
         static const int conv3_big_env = getenv("OZ_H2_CONV3_BIG") ? atoi(getenv("OZ_H2_CONV3_BIG")) : -1;
-        const bool conv3_big = conv3_big_env >= 0 ? conv3_big_env != 0 : n == 6;
-        const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), conv3_big ? 256 : 192), k4 = conv_ksplit((n - 4) * (n - 4), 256);
+        // ... and on either board the tile whose grid pays fewer tile-rows for the batch this call may hold: rounds of 256 CUs x tile height
+        // (4096 boards of 8x8: 192 rows -> 6 rounds x 192; a caller that caps its batches at 3640 gets 256 rows -> 4.0 rounds x 256, -13 % per launch).
+        // Both tiles add every output element's products in the same order: bit-identical results.
+        auto tile_cost = [&](int BM) {
+            const long long blocks = (((long long)max_count * (n - 2) * (n - 2) + BM - 1) / BM) * (C / 256);
+            return ((blocks + 255) / 256) * BM;
+        };
+        const bool conv3_big = conv3_big_env >= 0 ? conv3_big_env != 0 : (n == 6 || tile_cost(256) < tile_cost(192));
+        // (the k-split stays a constant of the network -- max_batch and the board decide it, not the tile this call picked -- so a position's
+        //  result does not depend on the size of the call it sits in)
+        const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), (conv3_big_env >= 0 ? conv3_big_env != 0 : n == 6) ? 256 : 192),
+                  k4 = conv_ksplit((n - 4) * (n - 4), 256);
         mark(1, true);
         if (use_t2) {
             const long long threads = (long long)max_count * n * n * (C / 8);

@@ -74,6 +74,7 @@ struct MctsDev {
     int* error_flag;
     unsigned long long* eval_leaves;    // positions handed to the network so far (after cross-game de-duplication)
     int dedup;                 // k_compact: evaluate a board reached by several games in the same step once
+    int batch_cap, batch_rot;  // k_compact (free-running driver): at most batch_cap slots (0: no cap), handed out in game order starting at game batch_rot
 };
 
 __device__ __forceinline__ unsigned char* rec_ptr(const MctsDev& t, int g, int node) {
@@ -303,9 +304,13 @@ __global__ __launch_bounds__(1024) void k_compact(MctsDev t) {
         }
     }
     __syncthreads();
+    const int cap = t.batch_cap > 0 ? t.batch_cap : t.G;
     for (int start = 0; start < t.G; start += 1024) {
-        const int g = start + tid;
-        const bool leaf = g < t.G && t.leaf_status[g] == OZ_LEAF_EVAL;
+        // game order, starting at game batch_rot (the start rotates from batch to batch when a cap defers leaves: every game gets served)
+        const int seq = start + tid;
+        int g = seq + t.batch_rot;
+        if (g >= t.G) g -= t.G;
+        const bool leaf = seq < t.G && t.leaf_status[g] == OZ_LEAF_EVAL;
         int first = g;
         if (leaf && dedup) {
             const uint64_t own = t.leaf_own[g], opp = t.leaf_opp[g];
@@ -326,11 +331,16 @@ __global__ __launch_bounds__(1024) void k_compact(MctsDev t) {
         const int base = base_s;
         if (flag) {
             const int slot = base + woff + pre;
-            t.leaf_slot[g] = slot;
-            t.batch_own[slot] = t.leaf_own[g];
-            t.batch_opp[slot] = t.leaf_opp[g];
+            if (slot < cap) {
+                t.leaf_slot[g] = slot;
+                t.batch_own[slot] = t.leaf_own[g];
+                t.batch_opp[slot] = t.leaf_opp[g];
+            } else {
+                t.leaf_slot[g] = 0;
+                t.leaf_status[g] = OZ_LEAF_WAIT;                            // no slot in this batch: the leaf is offered again in the next one
+            }
         } else if (leaf) {
-            t.leaf_slot[g] = -1 - first;                                   // resolved below: first < g, but maybe in this chunk
+            t.leaf_slot[g] = -1 - first;                                   // resolved below (the first occurrence may sit in a later chunk)
         }
         __syncthreads();
         if (tid == 0) base_s = base + total;
@@ -340,9 +350,13 @@ __global__ __launch_bounds__(1024) void k_compact(MctsDev t) {
         __threadfence_block();
         __syncthreads();
         for (int g = tid; g < t.G; g += 1024)
-            if (t.leaf_status[g] == OZ_LEAF_EVAL && t.leaf_slot[g] < 0) t.leaf_slot[g] = t.leaf_slot[-1 - t.leaf_slot[g]];
+            if (t.leaf_status[g] == OZ_LEAF_EVAL && t.leaf_slot[g] < 0) {
+                const int first = -1 - t.leaf_slot[g];
+                if (t.leaf_status[first] == OZ_LEAF_WAIT) { t.leaf_slot[g] = 0; t.leaf_status[g] = OZ_LEAF_WAIT; }     // shares the deferred board: waits with it
+                else t.leaf_slot[g] = t.leaf_slot[first];
+            }
     }
-    if (tid == 0) { *t.batch_count = base_s; *t.eval_leaves += (unsigned long long)base_s; }
+    if (tid == 0) { const int used = base_s < cap ? base_s : cap; *t.batch_count = used; *t.eval_leaves += (unsigned long long)used; }
 }
 
 // ---------------------------------------------------------------- K5 + K6: expand and backup
@@ -386,7 +400,7 @@ __device__ __forceinline__ void backup_body(const MctsDev& t, int g, int lane, d
 // slot_is_game != 0: pi / v are indexed by game (host evaluator path); else by compacted slot.
 __device__ __forceinline__ void expand_backup_body(const MctsDev& t, TreeLds& L, int g, int lane, int slot_is_game) {
     const int status = unii(t.leaf_status[g]);
-    if (status == OZ_LEAF_IDLE) return;
+    if (status == OZ_LEAF_IDLE || status == OZ_LEAF_WAIT) return;           // (WAIT: the leaf was not in the batch, nothing to expand yet)
     double value;
     int vt;
     if (status == OZ_LEAF_EVAL) {
@@ -532,6 +546,7 @@ static int mcts_create(oz_mcts** out, int n, int G, int node_cap, int edge_cap, 
     if (!rc) rc = m->alloc(&m->rc_counts, (size_t)G * 64);
     if (!rc) rc = m->alloc(&m->rc_legal, (size_t)G);
     if (!rc) rc = m->alloc(&m->rc_rc, (size_t)G);
+    d.batch_cap = 0; d.batch_rot = 0;
     { const char* e = getenv("OZ_DEDUP"); d.dedup = !(e && atoi(e) == 0); }      // OZ_DEDUP=0: one evaluation per game and step (A/B runs, tests)
     if (!rc && hipStreamCreate(&m->stream) != hipSuccess) { oz_set_error("hipStreamCreate failed"); rc = OZ_ERR_HIP; }
     if (!rc) {
@@ -976,6 +991,10 @@ __global__ __launch_bounds__(64) void k_sp_move(GamesDev gm, MctsDev t, int aren
 // cap 4 -> 1.585 M; cap 2 -> 3908 leaves per batch, 1.59 M (1.60 M with k_backup_advance; the lock-step driver: 1.56-1.58 M).  env OZ_ADVANCE_CAP overrides.
 #define OZ_ADVANCE_CAP 2
 __device__ __forceinline__ void advance_body(const GamesDev& gm, const MctsDev& t, TreeLds& L, int g, int lane, int sims, int* __restrict__ sims_done, int cap) {
+    if (unii(t.leaf_status[g]) == OZ_LEAF_WAIT) {          // batch cap: the leaf of the simulation in progress found no slot -- offer it again, unchanged
+        if (lane == 0) t.leaf_status[g] = OZ_LEAF_EVAL;
+        return;
+    }
     int done = sims_done[g];
     if (t.leaf_status[g] == OZ_LEAF_EVAL) ++done;          // the simulation whose leaf the previous step evaluated and backed up
     int status = OZ_LEAF_IDLE;
@@ -1054,6 +1073,8 @@ struct oz_selfplay {
     GamesDev gm;
     int* d_sims_done = nullptr;      // free-running mode: simulations completed for the move in progress, per game
     int mode = 0;                    // 0 fresh, 1 driven by oz_selfplay_run (lock step), 2 by oz_selfplay_run_steps (free-running)
+    int batch_cap = 0;               // free-running driver: leaves per network batch (0: up to G)
+    long long batch_no = 0;          // batches launched by the free-running driver (rotation of the slot order under a cap)
     int stagger_period = 0;
     std::vector<void*> allocs;
     std::mutex mu;
@@ -1233,10 +1254,16 @@ OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
         else hipLaunchKernelGGL(k_advance, dim3(d.G), dim3(64), 0, s, sp->gm, d, sp->cfg.sims, sp->d_sims_done, adv_cap);
         m->timer.end(ti, s);
         ti = all ? m->timer.begin(TS_COMPACT, s) : -1;
-        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, d);
+        MctsDev dc = d;                                    // this batch's cap and slot order (the kernels take the struct by value)
+        const int cap = sp->batch_cap > 0 && sp->batch_cap < d.G ? sp->batch_cap : 0;
+        dc.batch_cap = cap;
+        dc.batch_rot = cap ? (int)((sp->batch_no * (long long)cap) % d.G) : 0;
+        sp->batch_no += 1;
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, dc);
         m->timer.end(ti, s);
         ti = m->timer.begin(TS_NN, s);
-        if (int rc = oz_net_forward_device(sp->net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, s)) { m->timer.cancel(ti); return rc; }
+        // (the network's launches are sized for the cap: it picks its tile shapes from the batch it is asked to hold)
+        if (int rc = oz_net_forward_device(sp->net, d.batch_own, d.batch_opp, d.batch_count, cap ? cap : d.G, d.pi, d.v, s)) { m->timer.cancel(ti); return rc; }
         m->timer.end(ti, s);
         if (!fuse || i == steps - 1) {
             ti = all ? m->timer.begin(TS_BACKUP, s) : -1;
@@ -1246,6 +1273,15 @@ OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
         OZ_HIP(hipGetLastError());
         if (m->timer.backlog() > 8192) { if (int rc = mcts_collect_eval_time(m)) return rc; }
     }
+    return OZ_OK;
+}
+
+OZ_API int oz_selfplay_set_batch_cap(oz_selfplay* sp, int cap) {
+    OZ_REQUIRE(sp, "null selfplay");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    OZ_REQUIRE(cap >= 0, "oz_selfplay_set_batch_cap: cap %d", cap);
+    OZ_REQUIRE(cap == 0 || cap >= 8, "oz_selfplay_set_batch_cap: a cap below 8 leaves (got %d)", cap);
+    sp->batch_cap = cap;
     return OZ_OK;
 }
 

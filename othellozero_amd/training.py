@@ -156,6 +156,12 @@ class SelfPlayEngine:
         if sync:
             self.sync()
 
+    def set_batch_cap(self, cap):
+        """free-running driver: at most `cap` leaves per network batch (0 = no cap); a leaf that finds no slot waits for the next batch,
+        the slot order rotates so that every game is served.  Records do not change; the launches become whole grid rounds at the right
+        cap (see `preferred_batch_cap`)"""
+        _lib.check(_lib.load().oz_selfplay_set_batch_cap(self._h, int(cap)))
+
     def stagger(self, sims_pre=None, sync=True):
         """continuous self-play (refill=True), first call only: advance slot g (g * P) // num_games plies into its first game
         (P = n*n - 4) by searched moves at `sims_pre` simulations each (default: num_simulations), so that the engine holds
@@ -223,6 +229,20 @@ class SelfPlayEngine:
             if self.stats()["live_games"] == 0:
                 break
         return self.records()
+
+
+def preferred_batch_cap(board_size, num_games, channels=512):
+    """the batch cap at which conv3 -- the dominant launch -- is a whole number of rounds of 256 x 256 tiles on the chip's 256 CUs:
+    the largest L <= num_games with ceil((n-2)^2 * L / 256) * (channels / 256) = 256 * r; 0 (no cap) when that is num_games itself or the
+    network does not use those tiles (4096 8x8 games, 512 filters: 3640 = 4.0 rounds; 6x6: no cap)"""
+    if channels % 256 or num_games < 1024:
+        return 0
+    P, cols = (board_size - 2) ** 2, channels // 256
+    rounds = (num_games * P // 256) * cols // 256
+    if rounds < 1:
+        return 0
+    cap = (256 * rounds // cols) * 256 // P
+    return 0 if cap >= num_games else int(cap)
 
 
 def expand_examples(records, board_size, alias_final=False):

@@ -202,8 +202,8 @@ def test_stagger_spreads_games_and_keeps_records_exact(oz):
         assert np.array_equal(r["action"], ep["action"]) and np.array_equal(r["z"], ep["z"]), g
 
 
-@pytest.mark.parametrize("dedup", [False, True])
-def test_free_running_driver_at_config2_size_equals_lock_step(oz, monkeypatch, dedup):
+@pytest.mark.parametrize("dedup,cap", [(False, 0), (True, 0), (False, 3640), (True, 3640)])
+def test_free_running_driver_at_config2_size_equals_lock_step(oz, monkeypatch, dedup, cap):
     """bench.py's default driver (oz_selfplay_run_steps: a game runs on by itself, batches stay full) at the bench's own size -- 4096
     staggered 8x8 games x 100 simulations on the 512-filter network, f16x2, one evaluation per expansion: every game that completes
     under both drivers has the records of the lock-step driver (whose games the tests above replay with the oracle) bit for bit"""
@@ -222,8 +222,10 @@ def test_free_running_driver_at_config2_size_equals_lock_step(oz, monkeypatch, d
     rl, sl = lock.records(), lock.stats()
     del lock
     free = make()
+    if cap:                                                                 # bench.py's cap: conv3 on 1024 tiles of 256 x 256 = 4.0 grid rounds
+        free.set_batch_cap(cap)
     free.stagger(8)
-    free.run_steps(3 * sims + 40)
+    free.run_steps(3 * sims + (80 if cap else 40))
     rf, sf = free.records(), free.stats()
     assert sl["overflow"] == 0 and sf["overflow"] == 0
     il, jf = set(int(x) for x in np.unique(rl["game_id"])), set(int(x) for x in np.unique(rf["game_id"]))

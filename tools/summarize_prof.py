@@ -124,16 +124,19 @@ def tree(src, out, games):
     with open(src) as f:
         for r in csv.DictReader(l for l in f if not l.startswith("#")):
             vals[r["kernel"]][r["counter"]] = float(r["avg_per_launch"])
-    j = {"round": 2, "simulations_per_launch": int(games), "algorithmic_bytes_per_sim": 1300, "source": src, "kernels": {}}
+    j = {"round": 2, "simulations_per_launch": float(games), "algorithmic_bytes_per_sim": 1300, "source": src, "kernels": {}}
     tot_raw = tot_w = 0.0
     # (k_backup_select = expand + backup of the previous simulation fused with the descent: 99 of the 100 launches of a round;
     #  k_select / k_expand_backup = the first descent and the closing backup of a round, one launch each)
-    for k in ("k_backup_select", "k_select", "k_expand_backup", "k_compact"):
+    # free-running driver (bench.py's default): k_backup_advance = expand + backup of the previous batch fused with every game's advance
+    # (99 of the 100 launches of a step), k_advance / k_expand_backup = the first advance and the closing backup of a call; `games` = the
+    # simulations a launch completes on average (passed by the caller: simulations of the step / launches)
+    for k in ("k_backup_advance", "k_advance", "k_backup_select", "k_select", "k_expand_backup", "k_compact"):
         if k not in vals or "FETCH_SIZE" not in vals[k]:
             continue
-        fr, wr = vals[k]["FETCH_SIZE"] * 1024 / int(games), vals[k]["WRITE_SIZE"] * 1024 / int(games)
+        fr, wr = vals[k]["FETCH_SIZE"] * 1024 / float(games), vals[k]["WRITE_SIZE"] * 1024 / float(games)
         j["kernels"][k] = {"fetch_bytes_per_sim_raw": fr, "fetch_bytes_per_sim_x2": 2 * fr, "write_bytes_per_sim": wr}
-        if k in ("k_backup_select", "k_compact"):               # the per-simulation kernels of a steady round
+        if k in ("k_backup_advance", "k_backup_select", "k_compact"):               # the per-batch kernels of a steady step
             tot_raw += fr; tot_w += wr
     j["tree_side_bytes_per_sim"] = {"fetch_raw": tot_raw, "fetch_x2": 2 * tot_raw, "write": tot_w, "total_with_x2_fetch": 2 * tot_raw + tot_w}
     with open(out, "w") as f:
