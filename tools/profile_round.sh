@@ -13,8 +13,8 @@ run() { # name, rocprof args..., then bench args
   timeout -k 10 300 rocprofv3 "$@" --output-format csv -d $OUT/$name -o run -- python3 bench.py --precision $PREC --no-cpu-baseline --no-compare $EXTRA $BENCH_ARGS > $OUT/$name.log 2>&1
   echo "$name done"
 }
-BENCH_ARGS="" run trace --kernel-trace --stats          # the default command: staggered slots, 2 warm-up + 20 timed move rounds
-# counter passes: one timed move round after a cheap stagger (every launch is serialised under --pmc)
+BENCH_ARGS="" run trace --kernel-trace --stats          # the default command: staggered slots, 2 warm-up + 20 timed steps (free-running driver, capped batches; EXTRA="--driver lockstep" for the other one)
+# counter passes: one timed step (100 batches) after a cheap stagger (every launch is serialised under --pmc)
 BENCH_ARGS="--steps 1 --warmup 0 --stagger-sims 8" run fetch --kernel-trace --pmc FETCH_SIZE
 BENCH_ARGS="--steps 1 --warmup 0 --stagger-sims 8" run write --kernel-trace --pmc WRITE_SIZE
 BENCH_ARGS="--steps 1 --warmup 0 --stagger-sims 8" run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY
