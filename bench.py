@@ -71,6 +71,9 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
     hbm, src = None, None
     try:      # HBM-side bytes per leaf from the committed PMC profile of this kernel (profiles/), scaled per launch
         rel = os.path.join("profiles", f"conv{layer}_traffic_{precision}.json")
+        alt = os.path.join("profiles", f"conv{layer}_traffic_{precision}_lockstep_192row_tile.json")      # the counters of the 192-row tile (lock-step batches)
+        if layer == 3 and conv3_rows == 192 and os.path.exists(os.path.join(ROOT, alt)):
+            rel = alt
         tj = json.load(open(os.path.join(ROOT, rel)))
         hbm = tj["hbm_bytes_per_leaf"] * expansions / max(launches, 1)
         src = f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel, separate passes, gfx950 x2 read correction) x leaves per launch of this run; not re-measured in this run"
