@@ -1011,6 +1011,7 @@ __device__ __forceinline__ void advance_body(const GamesDev& gm, const MctsDev& 
         if (done >= sims) {                                // training.py:42-67: the move after num_simulations simulations
             sp_move_body(gm, t, g, lane, 0);
             done = 0;
+            if (lane == 0) t.leaf_status[g] = OZ_LEAF_IDLE;    // the evaluated leaf is consumed: nothing pending if the cap ends the loop here
             wave_sync();
             continue;                                      // (a finished game is refilled by the move, or goes idle above)
         }
@@ -1248,7 +1249,10 @@ OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
         const bool all = m->profile;
         hipStream_t s = m->stream;
         int ti = all ? m->timer.begin(TS_SELECT, s) : -1;
-        static const int adv_cap = getenv("OZ_ADVANCE_CAP") && atoi(getenv("OZ_ADVANCE_CAP")) > 0 ? atoi(getenv("OZ_ADVANCE_CAP")) : OZ_ADVANCE_CAP;     // A/B runs
+        static const int adv_env = getenv("OZ_ADVANCE_CAP") && atoi(getenv("OZ_ADVANCE_CAP")) > 0 ? atoi(getenv("OZ_ADVANCE_CAP")) : 0;     // A/B runs
+        // under a batch cap the leaves on offer exceed the slots anyway (waiting games re-offer theirs), so one descent per game and call is
+        // enough to keep the batches full and the launch is as short as the lock-step one (measured: +1.2 % expansions/s, +3 % games/s over 2)
+        const int adv_cap = adv_env ? adv_env : (sp->batch_cap > 0 && sp->batch_cap < d.G ? 1 : OZ_ADVANCE_CAP);
         // (from the second batch of a call on, the previous batch's expand + backup rides in the same launch; one closing k_expand_backup per call)
         if (fuse && i > 0) hipLaunchKernelGGL(k_backup_advance, dim3(d.G), dim3(64), 0, s, sp->gm, d, sp->cfg.sims, sp->d_sims_done, adv_cap);
         else hipLaunchKernelGGL(k_advance, dim3(d.G), dim3(64), 0, s, sp->gm, d, sp->cfg.sims, sp->d_sims_done, adv_cap);
