@@ -214,3 +214,17 @@ def test_bench_parent_reports_failing_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode != 0 and "rank" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_preferred_batch_cap_makes_conv3_whole_grid_rounds():
+    """the cap bench.py gives the free-running driver: the largest batch whose conv3 grid (256 x 256 tiles, 256 CUs) is a whole number of
+    rounds -- 3640 leaves for 4096 8x8 games on 512 or 256 filters; nothing to cap where the games themselves already are (6x6, 8192 games)"""
+    from othellozero_amd.training import preferred_batch_cap
+    assert preferred_batch_cap(8, 4096, 512) == 3640 and preferred_batch_cap(8, 4096, 256) == 3640
+    for n, G, C in ((8, 4096, 512), (8, 2048, 512), (8, 6000, 512), (8, 4096, 256)):
+        cap = preferred_batch_cap(n, G, C)
+        tiles = -(-cap * (n - 2) ** 2 // 256) * (C // 256)
+        assert 0 < cap < G and tiles % 256 == 0
+        assert (-(-(cap + 1) * (n - 2) ** 2 // 256) * (C // 256)) > tiles          # one more leaf would open another round
+    assert preferred_batch_cap(6, 4096, 512) == 0 and preferred_batch_cap(8, 8192, 512) == 0
+    assert preferred_batch_cap(8, 512, 512) == 0 and preferred_batch_cap(8, 4096, 128) == 0
