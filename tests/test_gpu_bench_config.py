@@ -259,7 +259,8 @@ def test_config3_last_rank_shard_at_full_size(oz):
         assert np.array_equal(r["black"], ep["black"]) and np.array_equal(r["white"], ep["white"]), gid
 
 
-def test_soak_two_generations_at_config2_size_vs_oracle(oz):
+@pytest.mark.parametrize("driver", ["lockstep", "free_capped"])
+def test_soak_two_generations_at_config2_size_vs_oracle(oz, driver):
     """tools/soak_check.py in small: 4096 concurrent 8x8 games x 100 sims with the device stub network, staggered start, 130
     move rounds (every slot finishes its first game and most of a refilled one), 32 randomly sampled games -- first and second
     generation, i.e. through table reset and slot refill -- equal the oracle's episodes move for move"""
@@ -268,7 +269,8 @@ def test_soak_two_generations_at_config2_size_vs_oracle(oz):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_check.py"), "--rounds", "130", "--sample", "32"],
+    extra = ["--driver", "free", "--batch-cap", "3640", "--rounds", "150"] if driver == "free_capped" else ["--rounds", "130"]      # bench.py's driver and cap
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_check.py"), "--sample", "32"] + extra,
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

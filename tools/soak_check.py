@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=600)
     ap.add_argument("--sample", type=int, default=200)
     ap.add_argument("--q-mode", type=int, default=1)
+    ap.add_argument("--driver", default="lockstep", choices=["lockstep", "free"], help="free: oz_selfplay_run_steps (rounds x sims batches)")
+    ap.add_argument("--batch-cap", type=int, default=0, help="free-running driver: leaves per batch (0 = none)")
     args = ap.parse_args()
     import oracle
     from othellozero_amd.NNet import StubNetWrapper
@@ -30,12 +32,17 @@ def main():
     gens = args.rounds // (n * n - 4) + 2
     eng = SelfPlayEngine(StubNetWrapper((n, n), 41, 0, max_batch=G), n, G, args.sims, 1.0, 1.0, 0.9, seed=77, first_game_id=0,
                          game_id_stride=G, q_mode=args.q_mode, refill=True, record_cap=G * gens * (n * n - 3))
+    if args.batch_cap:
+        eng.set_batch_cap(args.batch_cap)
     eng.stagger(8)
     t0 = time.perf_counter()
     done = 0
     while done < args.rounds:
         k = min(50, args.rounds - done)
-        eng.run(k)
+        if args.driver == "free":
+            eng.run_steps(k * args.sims)       # as many network batches as k move rounds (capped batches serve fewer games each)
+        else:
+            eng.run(k)
         done += k
         print(f"round {done}: {eng.stats()['games_completed']} games", flush=True)
     dt = time.perf_counter() - t0
