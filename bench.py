@@ -89,17 +89,13 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
                          if layer == 3 else "k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)"),
                  peak=PEAK_F32_MATRIX_TFLOPS, frac=achieved / PEAK_F32_MATRIX_TFLOPS)
     else:
-        pp = os.environ.get("OZ_H2_PP", "1") != "0"
-        lut = os.environ.get("OZ_H2_LUT", "1") != "0" and pp
-        tail = "implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, " + ("4-phase ping-pong loop" if pp else "one barrier per k-tile")
+        tail = "implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, 4-phase ping-pong loop"
         if layer == 3:
-            cfg = ("H2BigPP" if conv3_rows == 256 else "H2MidPP") if pp else ("H2Big" if conv3_rows == 256 else "H2Mid")
+            cfg = "H2BigPP" if conv3_rows == 256 else "H2MidPP"
             kernel = (f"k_gemm_h2<{cfg}> (conv3: 3x3 valid, 512->512, {n}x{n} -> {n - 2}x{n - 2}, {conv3_rows} x 256 tiles, {tail}); "
                       "conv1 + conv2 = k_conv2_lut table gather-sum")
-        elif lut:
-            kernel = f"k_gemm_h2<H2BigPPLut> (conv2: 3x3 same, 512->512, {tail}; A rows gathered from the conv1 pattern table)"
         else:
-            kernel = f"k_gemm_h2<{'H2BigPP' if pp else 'H2Big'}> (conv2: 3x3 same, 512->512, {tail})"
+            kernel = f"k_gemm_h2<H2BigPP> (conv2: 3x3 same, 512->512, {tail}; oz_net_set_tables(0): conv1 as a kernel)"
         r.update(kernel=kernel, peak=PEAK_F16_MATRIX_TFLOPS, frac=achieved / PEAK_F16_MATRIX_TFLOPS,
                  mfma_products_per_fp32_product=3, matrix_pipe_tflops=3 * achieved,
                  matrix_pipe_frac=3 * achieved / PEAK_F16_MATRIX_TFLOPS,
@@ -270,43 +266,143 @@ def dropin_config0(channels, precision):
                          "sims_per_s": int(ep["n_moves"]) * sims / t_cpu, "games_per_s": 1.0 / t_cpu, "cores": threads, "kind": "port"}}
 
 
-def parity_sample(net, eng, n, channels, count=256):
-    """the checker, after the timed region: `count` of the positions the engine holds right now, evaluated by the network
-    object the timed region used (same kernels, same max_batch) and by the float64 oracle"""
+def parity_sample(net, eng, n, channels, call_size, check=384):
+    """the checker, after the timed region: ONE network call of `call_size` positions -- the size of the timed region's batches (the
+    batch cap: conv3 on the tile the roofline row is about), positions the engine holds right now, evaluated by the network object
+    the timed region used (same kernels, same max_batch) -- against the float64 oracle on `check` rows spread over the call (every
+    output row is an independent accumulation), and bit-compared with a second, shorter call (another conv3 tile, same sums)"""
     import numpy as np
     from oracle import nn_numpy
     from othellozero_amd.weights import init_weights
     st = eng.state()
-    idx = np.linspace(0, st["black"].size - 1, count).astype(np.int64)
+    idx = np.linspace(0, st["black"].size - 1, call_size).astype(np.int64)
     own = np.where(st["player"][idx] == 1, st["black"][idx], st["white"][idx])
     opp = np.where(st["player"][idx] == 1, st["white"][idx], st["black"][idx])
-    pi, v = net.predict_batch(own, opp)
-    pi64, v64 = nn_numpy.forward_chunked(init_weights(n, seed=0, channels=channels), own, opp, n, chunk=128)
-    return {"max_abs_err_pi": float(np.abs(pi.reshape(count, -1) - pi64).max()), "max_abs_err_v": float(np.abs(v - v64).max()),
-            "positions": int(count), "plies_sampled": [int(st["ply"][idx].min()), int(st["ply"][idx].max())], "tolerance": 1e-5,
+    pi, v = net.predict_batch(own, opp)                                       # one call: call_size <= max_batch
+    tile = net.conv3_tile_rows()
+    rows = np.linspace(0, call_size - 1, min(check, call_size)).astype(np.int64)
+    pi64, v64 = nn_numpy.forward_chunked(init_weights(n, seed=0, channels=channels), own[rows], opp[rows], n, chunk=128)
+    short = min(256, call_size)
+    p2, v2 = net.predict_batch(own[:short], opp[:short])
+    return {"max_abs_err_pi": float(np.abs(pi.reshape(call_size, -1)[rows] - pi64).max()), "max_abs_err_v": float(np.abs(v[rows] - v64).max()),
+            "positions_in_the_call": int(call_size), "conv3_tile_rows_of_the_call": int(tile), "rows_checked_vs_float64": int(rows.size),
+            "bit_identical_to_a_shorter_call": bool(np.array_equal(p2, pi[:short]) and np.array_equal(v2, v[:short])),
+            "shorter_call": {"positions": int(short), "conv3_tile_rows": int(net.conv3_tile_rows())},
+            "plies_sampled": [int(st["ply"][idx].min()), int(st["ply"][idx].max())], "tolerance": 1e-5,
             "checker": "oracle/nn_numpy.py (float64 restatement of Net/OthelloNN.py:42-56)"}
 
 
+def config5_arena(channels, precision, plies, games=512, sims=800, sample=2):
+    """BASELINE configs[4]: arena evaluation (agents.py:44-84, duel_between_agents) -- `games` parallel 8x8 games, `sims` simulations per
+    move per agent, two REAL networks (seeds 0 / 1: best vs candidate), deterministic play (temperature 0, RNG_TIE stream), bounded
+    to `plies` plies per game so that the leg fits the run's time budget; `sample` games are replayed by the CPU oracle's arena fed
+    with the GPU networks' own (pi, v) -> sample_mismatches must be 0."""
+    import numpy as np
+    import oracle
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.agents import arena_batch
+    n = 8
+    nets = [NNetWrapper((n, n), num_channels_1=channels, max_batch=games, seed=sd, precision=precision) for sd in (0, 1)]
+    arena_batch(nets[0], nets[1], n, games, 8, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=2)      # untimed: allocation, code load
+    t0 = time.perf_counter()
+    r = arena_batch(nets[0], nets[1], n, games, sims, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=plies)
+    dt = time.perf_counter() - t0
+    moves = int(r["n_moves"].sum())
+    st = r["stats_black"] + r["stats_white"]
+    caches = [{}, {}]
+
+    def evaluator(k):
+        def ev(own, opp, nn):
+            if (own, opp) not in caches[k]:
+                p, v = nets[k].predict_batch([own], [opp])
+                caches[k][(own, opp)] = (p[0].ravel(), float(v[0]))
+            return caches[k][(own, opp)]
+        return ev
+    t1 = time.perf_counter()
+    bad = 0
+    for gi in range(sample):
+        o = oracle.arena(oracle.Mcts(n, 1.0, 1, evaluator=evaluator(0)), oracle.Mcts(n, 1.0, 1, evaluator=evaluator(1)), sims, 11, gi, max_plies=plies)
+        k = o["n_moves"]
+        ok = (int(r["n_moves"][gi]) == k and np.array_equal(r["actions"][gi][:k], o["action"]) and np.array_equal(r["players"][gi][:k], o["player"])
+              and (int(r["final_black"][gi]), int(r["final_white"][gi])) == (int(o["final_black"]), int(o["final_white"])))
+        bad += 0 if ok else 1
+    return {"workload": f"BASELINE configs[4]: {games} parallel 8x8 arena games, {sims} sims/move per agent, two {channels}-filter OthelloNN "
+                        f"(random init, seeds 0 / 1), temperature 0, deterministic; first {plies} plies of every game (bounded for the run's time budget)",
+            "seconds": dt, "plies_per_game": plies, "moves": moves, "simulations": int(st[0]), "expansions": int(st[2]),
+            "sims_per_s": float(st[0]) / dt, "value": float(st[2]) / dt, "unit": "node-expansions/s", "moves_per_s": moves / dt,
+            "games_per_s_extrapolated_60_plies": games / (dt * 60.0 / plies), "precision": precision,
+            "sample_games_replayed_by_oracle": sample, "sample_mismatches": bad, "oracle_replay_s": round(time.perf_counter() - t1, 2),
+            "note": "oz_arena_run_rounds: BLACK movers search in net A's trees, WHITE movers in net B's, one searched ply per game and round; "
+                    "the oracle's arena (agents.py restated, oracle/oz_oracle.c orc_arena_plies) is fed the GPU networks' own (pi, v), so "
+                    "actions, movers and boards must agree bit for bit"}
+
+
 # ---------------------------------------------------------------------------------------------------------------- launcher
+BENCH_TIMEOUT_S = float(os.environ.get("OZ_BENCH_TIMEOUT", "520"))          # below the driver's own 600 s limit: a hang is reported by us, with its phase
+COLLECTIVE_TIMEOUT_S = float(os.environ.get("OZ_BENCH_COLLECTIVE_TIMEOUT", "150"))
+
+_PHASE = {"name": "start", "t": time.time(), "rank": int(os.environ.get("RANK", "0")), "done": False}
+
+
+def phase(name):
+    """rank side: the phase this rank is in (init / build / stagger / warmup / timed / gather / reduce / report), for the watchdog below
+    and -- when bench.py launched the ranks itself -- for the parent (one small file per rank)"""
+    _PHASE.update(name=name, t=time.time())
+    d = os.environ.get("OZ_BENCH_PHASE_DIR")
+    if d:
+        try:
+            with open(os.path.join(d, f"rank{_PHASE['rank']}"), "w") as f:
+                f.write(f"{name} {time.time():.1f}\n")
+        except OSError:
+            pass
+
+
+def start_watchdog(limit_s):
+    """a rank that has not finished after limit_s says WHICH rank is stuck in WHICH phase and exits 124 -- also under
+    torch.distributed.run, where no parent of ours watches (a rank stuck inside a collective has released the GIL)"""
+    import threading
+    t_start = time.time()
+
+    def run():
+        while not _PHASE["done"]:
+            if time.time() - t_start > limit_s:
+                print(f"bench.py: rank {_PHASE['rank']} did not finish within {limit_s:.0f} s: stuck in phase '{_PHASE['name']}' for "
+                      f"{time.time() - _PHASE['t']:.0f} s", file=sys.stderr, flush=True)
+                os._exit(124)
+            time.sleep(0.5)
+    threading.Thread(target=run, daemon=True).start()
+
+
 def launch_ranks(args):
     """--gpus N > 1 without a launcher environment: start the N ranks as child processes of THIS process (which never
-    initialises HIP), relay rank 0's stdout, fail if any rank fails or the realised world size is not N.
-    Replaces the role of WorkerManager fan-out in the reference (workers.py:168-184,298-303)."""
-    import socket
+    initialises HIP), relay rank 0's stdout, fail if any rank fails or the realised world size is not N; on a failure or a
+    timeout say which rank, and the phase every unfinished rank was in.  The rendezvous is a FILE store in a private temporary
+    directory (no TCP port to lose a race for).  Replaces the role of WorkerManager fan-out in the reference (workers.py:168-184,298-303)."""
     import tempfile
     n = args.gpus
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    tmp = tempfile.mkdtemp(prefix="oz_bench_")
     procs = []
     out_file = tempfile.TemporaryFile(mode="w+")               # rank 0's stdout (a file, so a long line can never block the rank)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OZ_BENCH_CHILD="1")
+                   OZ_BENCH_INIT_FILE=os.path.join(tmp, "rendezvous"), OZ_BENCH_PHASE_DIR=tmp, OZ_BENCH_CHILD="1")
+        env.pop("MASTER_PORT", None)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out_file if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+
+    def phases(ranks):
+        out = []
+        for r in ranks:
+            try:
+                name, t = open(os.path.join(tmp, f"rank{r}")).read().split()
+                out.append(f"rank {r}: phase '{name}' for {time.time() - float(t):.0f} s")
+            except (OSError, ValueError):
+                out.append(f"rank {r}: no phase reported (died or hung before the first one)")
+        return "; ".join(out)
     rc = 0
     try:
         pending = set(range(n))
-        deadline = time.time() + float(os.environ.get("OZ_BENCH_TIMEOUT", "1500"))
+        deadline = time.time() + BENCH_TIMEOUT_S + 10         # the ranks' own watchdogs fire first and name their phase
         while pending:
             for r in list(pending):
                 code = procs[r].poll()
@@ -314,11 +410,12 @@ def launch_ranks(args):
                     pending.discard(r)
                     if code != 0 and rc == 0:
                         rc = code
-                        print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+                        print(f"bench.py: rank {r} exited with code {code}" + (f"; still running: {phases(sorted(pending))}" if pending else ""),
+                              file=sys.stderr)
             if rc != 0 or time.time() > deadline:
                 if rc == 0:
                     rc = 124
-                    print("bench.py: ranks did not finish in time", file=sys.stderr)
+                    print(f"bench.py: ranks did not finish within {BENCH_TIMEOUT_S + 10:.0f} s: {phases(sorted(pending))}", file=sys.stderr)
                 break
             time.sleep(0.2)
     finally:
@@ -330,6 +427,8 @@ def launch_ranks(args):
                 p.wait(timeout=20)
             except subprocess.TimeoutExpired:
                 p.kill()
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
     out_file.seek(0)
     out0 = out_file.read()
     lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
@@ -377,6 +476,7 @@ def main():
     ap.add_argument("--driver", default="free", choices=["free", "lockstep"],
                     help="free: oz_selfplay_run_steps (every game runs on by itself, full leaf batches; identical records); "
                          "lockstep: oz_selfplay_run (one simulation per game per step, moves aligned)")
+    ap.add_argument("--arena-plies", type=int, default=6, help="config5 leg: plies per arena game (512 games x 800 sims per move and agent)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -394,6 +494,25 @@ def main():
               file=sys.stderr)
         sys.exit(2)
 
+    _PHASE["rank"] = rank
+    if world > 1 or "OZ_BENCH_TIMEOUT" in os.environ:          # (a one-rank run cannot hang in a collective; long profiling runs stay possible)
+        start_watchdog(BENCH_TIMEOUT_S)
+    phase("init")
+    try:
+        run_rank(args, rank, world, local_rank, t_proc)
+    except SystemExit:
+        raise
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        print(f"bench.py: rank {rank} failed in phase '{_PHASE['name']}'", file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        os._exit(1)                                            # (a rank blocked in a collective elsewhere is ended by its own watchdog / the launcher)
+    _PHASE["done"] = True
+
+
+def run_rank(args, rank, world, local_rank, t_proc):
+    import datetime
     import torch
     import torch.distributed as dist
     from othellozero_amd import _lib
@@ -410,14 +529,21 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a collective (or the rendezvous) that does not complete in COLLECTIVE_TIMEOUT_S fails instead of hanging: torch's watchdog
+        # aborts the communicator and the rank exits non-zero -- the launcher / this rank's watchdog then names the phase
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
+        if os.environ.get("OZ_BENCH_INIT_FILE"):               # ranks started by launch_ranks: a file store, no TCP port
+            kw["init_method"] = "file://" + os.environ["OZ_BENCH_INIT_FILE"]
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, **kw)
         if dist.get_world_size() != args.gpus:
             print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
             sys.exit(2)
 
+    phase("build")
     n, G = args.board, args.games
     stagger_sims = args.sims if args.stagger_sims < 0 else args.stagger_sims
     period = n * n - 4
@@ -431,12 +557,11 @@ def main():
         return preferred_batch_cap(board, games, args.channels) if args.batch_cap < 0 else args.batch_cap
 
     def make_engine(dedup, the_net=net, board=n, games=G, steps=args.steps):
-        os.environ["OZ_DEDUP"] = "1" if dedup else "0"          # read when the engine's search object is created
-        e = SelfPlayEngine(the_net, board, games, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * games,
-                           game_id_stride=world * games, q_mode=_lib.QMODE_F64, refill=True,
-                           record_cap=int(games * (steps + args.warmup + board * board + 2) * 1.25))
-        e.set_batch_cap(batch_cap(board, games))                # used by the free-running driver only
-        return e
+        # (oz_selfplay_config.dedup / .batch_cap; the cap is used by the free-running driver only)
+        return SelfPlayEngine(the_net, board, games, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * games,
+                              game_id_stride=world * games, q_mode=_lib.QMODE_F64, refill=True,
+                              record_cap=int(games * (steps + args.warmup + board * board + 2) * 1.25),
+                              dedup=dedup, batch_cap=batch_cap(board, games))
     eng = make_engine(args.dedup == "on")
     cap_main = batch_cap(n, G) if args.driver == "free" else 0
 
@@ -476,24 +601,35 @@ def main():
 
     t_setup = time.perf_counter() - t_proc                      # imports, network + table build, engine allocation
     t_sec = time.perf_counter()
+    phase("stagger")
     if stagger_sims >= 2:
         eng.stagger(stagger_sims)                               # untimed: slot g is (g * 60) / G plies into its first game
     t_stagger = time.perf_counter() - t_sec
+    phase("warmup")
     advance(eng, args.warmup, True)
     eng.sync()
     if world > 1:           # warm-up of the exchange step too (communicator channels for both collectives), like the W untimed steps
+        phase("gather-warmup")
         gather_records(torch.zeros((8, 48), dtype=torch.uint8, device=dev))
     dom0_ms, dom0_launches = net.profile_read()
     s0 = eng.stats()
     ev0 = eng.eval_time()
+    phase("barrier")
     barrier()
+    phase("timed")
     t0 = time.perf_counter()
     advance(eng, args.steps, False)
     eng.sync()
     # the path's only exchange step: the move records of the games that ended inside the timed region, pooled over the ranks
-    pooled = gather_records(engine_records_tensor(eng, dev)[s0["records"]:])
+    phase("gather")
+    t_g = time.perf_counter()
+    local_records = engine_records_tensor(eng, dev)[s0["records"]:]
+    pooled = gather_records(local_records)
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t_g) * 1e3
     barrier()
     dt = time.perf_counter() - t0
+    phase("reduce")
     s1 = eng.stats()
     ev1 = eng.eval_time()
     dom_all_ms, dom_all_launches = net.profile_read()           # the dominant launch: conv3 (conv2 is a gather-sum), or conv2
@@ -504,11 +640,20 @@ def main():
     d = {k: s1[k] - s0[k] for k in ("simulations", "expansions", "terminal_hits", "node_visits", "moves", "games_completed", "leaves_evaluated")}
     vec = torch.tensor([d["expansions"], d["simulations"], d["games_completed"], d["moves"], d["node_visits"]],
                        dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, gather_ms], dtype=torch.float64, device=dev)
+    per_rank = torch.zeros(world, dtype=torch.float64, device=dev)           # records every rank contributed to the pool
+    per_rank[rank] = float(local_records.shape[0])
     if world > 1:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+    dt, gather_ms = (float(x) for x in tmax.tolist())
+    per_rank_records = [int(x) for x in per_rank.tolist()]
+    if sum(per_rank_records) != int(pooled.shape[0]):                        # the all-gather lost or duplicated records: not a result
+        print(f"bench.py: rank {rank}: pooled {int(pooled.shape[0])} records, the ranks contributed {per_rank_records} (sum {sum(per_rank_records)})",
+              file=sys.stderr, flush=True)
+        sys.exit(4)
+    phase("report")
     exp_all, sims_all, games_all, moves_all, visits_all = (float(x) for x in vec.tolist())
 
     if rank == 0:
@@ -547,7 +692,9 @@ def main():
             "games_per_s": games_all / dt, "sims_per_s": sims_all / dt, "moves_per_s": moves_all / dt,
             "games_completed": int(games_all), "expansions": int(exp_all), "simulations": int(sims_all),
             "expansions_per_sim": exp_all / max(sims_all, 1), "node_visits_per_sim": visits_all / max(sims_all, 1),
-            "pooled_records": int(pooled.shape[0]),
+            "pooled_records": int(pooled.shape[0]), "per_rank_records": per_rank_records, "gather_ms": gather_ms,
+            "gather_note": "the path's one exchange step, inside the timed region: counts all-gather + one padded all-gather of 48-byte move "
+                           "records copied device to device out of each engine's HBM buffer (max over ranks; pooled == sum of per_rank checked)",
             "slot_ply_spread_rank0": [int(ply_now.min()), int(ply_now.max())],
             "nn_forward_ms_total_rank0": nn_ms, "nn_fraction_of_wall_rank0": nn_ms * 1e-3 / dt,
             "leaves_evaluated_rank0": int(d["leaves_evaluated"]),
@@ -589,7 +736,7 @@ def main():
             wall["kernels_s"] = round(time.perf_counter() - t_sec, 2)
         if secondary and not args.no_cpu_baseline:
             t_sec = time.perf_counter()
-            ps = parity_sample(net, eng, n, args.channels)
+            ps = parity_sample(net, eng, n, args.channels, cap_main or G)
             out["parity_sample_max_err"] = max(ps["max_abs_err_pi"], ps["max_abs_err_v"])
             out["parity_sample"] = ps
             wall["parity_sample_s"] = round(time.perf_counter() - t_sec, 2)
@@ -674,6 +821,11 @@ def main():
             del e6, net6
             wall["config4_s"] = round(time.perf_counter() - t_sec, 2)
         if secondary and n == 8 and not args.no_cpu_baseline:
+            # ---- BASELINE configs[4]: arena evaluation with two real networks (bounded plies), sampled games replayed by the oracle
+            t_sec = time.perf_counter()
+            out["config5"] = config5_arena(args.channels, args.precision, args.arena_plies)
+            wall["config5_s"] = round(time.perf_counter() - t_sec, 2)
+        if secondary and n == 8 and not args.no_cpu_baseline:
             t_sec = time.perf_counter()
             out["dropin_config0"] = dropin_config0(args.channels, args.precision)
             wall["dropin_config0_s"] = round(time.perf_counter() - t_sec, 2)
@@ -685,6 +837,7 @@ def main():
             wall["cpu_baseline_s"] = round(time.perf_counter() - t_sec, 2)
         print(json.dumps(out), flush=True)
     if world > 1:
+        phase("teardown")
         dist.barrier()
         dist.destroy_process_group()
 

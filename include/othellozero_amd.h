@@ -103,6 +103,15 @@ int oz_net_profiled_layer(oz_net* net, int* layer);
  * inside conv2's operand gather, conv2 an MFMA GEMM (bit-identical to 0); 0: conv1 kernel + conv2 MFMA GEMM; -1: back to the
  * default.  Takes effect at the next forward. */
 int oz_net_set_tables(oz_net* net, int mode);
+/* diagnostics switch, per network (default 0): the 3x3 convolutions of precision f16x2 on the one-barrier-per-k-tile main loop instead of
+ * the 4-phase ping-pong loop.  Same tiles' accumulation order, bit-identical results: the reference form the LDS-DMA race screen
+ * (tools/pp_race_check.py, test_pingpong_conv_loop_bit_identical_to_simple_loop) compares the ping-pong schedule against. */
+#define OZ_NET_OPT_SIMPLE_LOOP 1
+int oz_net_set_option(oz_net* net, int option, int value);
+/* launch facts of the last forward: OZ_NET_INFO_CONV3_TILE_ROWS = the row-tile height conv3 ran on (f16x2: 256 / 192, chosen per call from
+ * the capacity the caller launches with -- 256 at bench.py's batch cap of 3640 leaves; 128 for the latency path and precision f32) */
+#define OZ_NET_INFO_CONV3_TILE_ROWS 1
+int oz_net_get_info(oz_net* net, int what, int* value);
 
 /* ------------------------------------------------------------------ search
  * OthelloMCTS / MCTS (othelo_mcts.py:9-88, MCTS/__init__.py:19-187): num_games independent
@@ -113,6 +122,8 @@ typedef struct oz_mcts oz_mcts;
 int oz_mcts_create(oz_mcts** out, int n, int num_games, int node_cap, int edge_cap, double c, int q_mode);
 int oz_mcts_destroy(oz_mcts* m);
 int oz_mcts_reset(oz_mcts* m, int game /* -1 = all */);                 /* fresh OthelloMCTS() */
+/* cross-game leaf de-duplication of oz_mcts_simulate's batches (default on; results are identical either way) */
+int oz_mcts_set_dedup(oz_mcts* m, int enable);
 /* roots of the next simulations: canonical boards (othelo_mcts.py:22-26); active[i]=0 leaves slot i idle */
 int oz_mcts_set_roots(oz_mcts* m, const uint64_t* own, const uint64_t* opp, const uint8_t* active);
 /* OthelloMCTS.simulate x nsims for every active slot, leaves evaluated in one batch per step by `net` */
@@ -152,7 +163,13 @@ typedef struct {
     int32_t node_cap;       /* per-game node table capacity (0 = sims*61+64) */
     int32_t edge_cap;       /* unused (edges live inside the node records); kept for ABI stability */
     int32_t record_cap;     /* move records kept for export (0 = num_games*64*4) */
+    int32_t dedup;          /* OZ_DEDUP_*: cross-game leaf de-duplication -- a board that several games reach in the same batch is evaluated
+                             * once and every one of them reads the same (pi, v) row; changes no record, count or statistic, only leaves_evaluated */
+    int32_t batch_cap;      /* free-running driver: leaves per network batch (0 = none), see oz_selfplay_set_batch_cap */
 } oz_selfplay_config;
+#define OZ_DEDUP_DEFAULT 0  /* = on */
+#define OZ_DEDUP_ON 1
+#define OZ_DEDUP_OFF 2
 
 /* one move of one game; 8-fold symmetry expansion (training.py:13-23) happens in oz_examples_expand */
 typedef struct {
@@ -172,7 +189,7 @@ typedef struct {
     int64_t moves, games_completed, records;
     int32_t live_games, overflow;
     int64_t leaves_evaluated;   /* positions handed to the network: <= expansions, because a board that several games reach in
-                                 * the same step is evaluated once (results are identical either way; OZ_DEDUP=0 disables) */
+                                 * the same step is evaluated once (results are identical either way; oz_selfplay_config.dedup = OZ_DEDUP_OFF disables) */
 } oz_selfplay_stats;
 
 int oz_selfplay_create(oz_selfplay** out, const oz_selfplay_config* cfg, oz_net* net);
@@ -191,6 +208,8 @@ int oz_selfplay_run_steps(oz_selfplay* sp, int steps);
  * launches: the convolution grids are a whole number of rounds of the chip at the right cap (4096 8x8 games on the 512-filter network:
  * cap 3640 = 1024 conv3 tiles of 256 x 256 = 4.0 rounds of 256 CUs, against 5.5 rounds paid as 6 without it). */
 int oz_selfplay_set_batch_cap(oz_selfplay* sp, int cap);
+/* cross-game leaf de-duplication on / off from the next batch on (oz_selfplay_config.dedup sets the initial state) */
+int oz_selfplay_set_dedup(oz_selfplay* sp, int enable);
 int oz_selfplay_sync(oz_selfplay* sp);
 /* continuous self-play (cfg.refill): bring a fresh engine to the steady state of a long-running one before measuring it --
  * slot g is advanced (g * P) / num_games plies into its first game, P = n*n - 4, by searched self-play moves at `sims_pre`
@@ -225,6 +244,11 @@ int oz_arena_create(oz_arena** out, int n, int num_games, int sims, double c, in
                     uint64_t first_game_id, oz_net* net_a, oz_net* net_b, int node_cap, int edge_cap);
 int oz_arena_destroy(oz_arena* a);
 int oz_arena_run(oz_arena* a);       /* plays all games to the end (synchronous) */
+/* the same, stopping after `max_rounds` further rounds (0 = to the end): a round = one searched ply in every live game.  Synchronous; may
+ * be called again to play on.  bench.py's config-5 leg times a bounded number of plies at 800 sims with two real networks. */
+int oz_arena_run_rounds(oz_arena* a, int max_rounds);
+/* search counters of the BLACK / WHITE agent since creation, layout of oz_mcts_stats */
+int oz_arena_stats(oz_arena* a, int64_t* black5, int64_t* white5);
 int oz_arena_results(oz_arena* a, int8_t* winner /* +1 net_a */, int32_t* points, int32_t* n_moves,
                      uint8_t* actions /* [num_games][128] */, int8_t* players /* [num_games][128] */,
                      uint64_t* final_black, uint64_t* final_white);

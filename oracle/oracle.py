@@ -87,6 +87,7 @@ def lib():
     L.orc_episode.restype = i32; L.orc_episode.argtypes = [vp, i32, dbl, dbl, u64, u64, i32, P(EpisodeOut)]
     L.orc_episode_sched.restype = i32; L.orc_episode_sched.argtypes = [vp, i32, i32, i32, dbl, dbl, u64, u64, i32, P(EpisodeOut)]
     L.orc_arena.restype = i32; L.orc_arena.argtypes = [vp, vp, i32, u64, u64, P(ArenaOut)]
+    L.orc_arena_plies.restype = i32; L.orc_arena_plies.argtypes = [vp, vp, i32, u64, u64, i32, P(ArenaOut)]
     L.orc_symmetry_perms.restype = None; L.orc_symmetry_perms.argtypes = [i32, P(C.c_int32)]
     L.orc_nn_num_weights.restype = i32
     L.orc_nn_forward_f32.restype = None
@@ -237,14 +238,15 @@ class Mcts:
         )
 
 
-def arena(ma, mb, sims, seed, game_id):
-    """ma / mb = Mcts of the BLACK / WHITE agent; None = RandomOthelloAgent on that colour"""
+def arena(ma, mb, sims, seed, game_id, max_plies=-1):
+    """ma / mb = Mcts of the BLACK / WHITE agent; None = RandomOthelloAgent on that colour; max_plies >= 0 stops the duel
+    after that many plies (finished=False if the game is not over: winner / points then describe the unfinished board)"""
     out = ArenaOut()
-    rc = lib().orc_arena(ma.h if ma is not None else None, mb.h if mb is not None else None, sims, seed, game_id, C.byref(out))
+    rc = lib().orc_arena_plies(ma.h if ma is not None else None, mb.h if mb is not None else None, sims, seed, game_id, max_plies, C.byref(out))
     if rc < 0:
         raise KeyError("orc_arena: KeyError path")
     k = out.n_moves
-    return dict(n_moves=k, action=np.array(out.action[:k], dtype=np.uint8), player=np.array(out.player[:k], dtype=np.int8),
+    return dict(n_moves=k, finished=(rc == 0), action=np.array(out.action[:k], dtype=np.uint8), player=np.array(out.player[:k], dtype=np.int8),
                 final_black=out.final_black, final_white=out.final_white, winner=out.winner, points=out.points)
 
 

@@ -589,12 +589,14 @@ typedef struct {
 /* duel_between_agents with two NeuralNetworkOthelloAgent, agents.py:44-84.
  * ma plays BLACK, mb plays WHITE; temperature forced to 0 (agents.py:46).
  * Either may be NULL: that colour is played by RandomOthelloAgent (agents.py:20-24; main.py:163-233 evaluation games). */
-ORC_API int orc_arena(omcts* ma, omcts* mb, int sims, uint64_t seed, uint64_t game_id, orc_arena_out* out) {
+/* max_plies < 0: to the end of the game; else stop after max_plies plies (returns 1 if the game is then unfinished: the
+ * bounded form bench.py's config-5 leg replays -- winner / points are then those of the unfinished board) */
+ORC_API int orc_arena_plies(omcts* ma, omcts* mb, int sims, uint64_t seed, uint64_t game_id, int max_plies, orc_arena_out* out) {
     const int n = ma ? ma->n : mb->n;            /* a NULL search = RandomOthelloAgent on that colour */
     ogame g; game_init(&g, n);
     memset(out, 0, sizeof *out);
     int ply = 0;
-    while (!g.finished) {
+    while (!g.finished && (max_plies < 0 || ply < max_plies)) {
         omcts* m = g.player == 1 ? ma : mb;
         uint64_t bl, wh; pack(&g.b, &bl, &wh);
         if (!m) {   /* RandomOthelloAgent.play, agents.py:20-24: random.choice over the valid actions (ascending row-major) */
@@ -626,7 +628,10 @@ ORC_API int orc_arena(omcts* ma, omcts* mb, int sims, uint64_t seed, uint64_t ga
     out->n_moves = ply;
     pack(&g.b, &out->final_black, &out->final_white);
     out->winner = board_winner(&g.b, n, &out->points);
-    return 0;
+    return g.finished ? 0 : 1;
+}
+ORC_API int orc_arena(omcts* ma, omcts* mb, int sims, uint64_t seed, uint64_t game_id, orc_arena_out* out) {
+    return orc_arena_plies(ma, mb, sims, seed, game_id, -1, out);
 }
 
 /* training_example_symmetries, training.py:13-23: source index of every output

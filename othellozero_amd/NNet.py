@@ -201,6 +201,16 @@ class NNetWrapper(_NetHandle):
         """f16x2: 2 = conv1 + conv2 from pattern tables (default), 1 = conv1 table + conv2 GEMM, 0 = conv1 kernel + conv2 GEMM"""
         _lib.check(_lib.load().oz_net_set_tables(self._h, int(mode)))
 
+    def set_option(self, option, value):
+        """diagnostics switches (_lib.NET_OPT_*): NET_OPT_SIMPLE_LOOP = the one-barrier conv loop the race screen compares against"""
+        _lib.check(_lib.load().oz_net_set_option(self._h, int(option), int(value)))
+
+    def conv3_tile_rows(self):
+        """row-tile height the LAST forward ran conv3 on (f16x2: 256 at bench.py's batch cap, 192 for full 4096-leaf launches)"""
+        v = C.c_int()
+        _lib.check(_lib.load().oz_net_get_info(self._h, _lib.NET_INFO_CONV3_TILE_ROWS, C.byref(v)))
+        return v.value
+
     def profiled_layer(self):
         """which launch profile_read() timed: 2 = the conv2 GEMM, 3 = the conv3 GEMM (f16x2: conv1 + conv2 are a table gather-sum)"""
         layer = C.c_int()

@@ -14,6 +14,9 @@ LIB_PATH = os.environ.get("OZ_LIB_PATH") or os.path.join(_HERE, "lib", "libothel
 
 OZ_OK, OZ_ERR_HIP, OZ_ERR_ARG, OZ_ERR_CAPACITY, OZ_ERR_KEY, OZ_ERR_STATE = range(6)
 QMODE_NEP50, QMODE_F64 = 0, 1
+DEDUP_DEFAULT, DEDUP_ON, DEDUP_OFF = 0, 1, 2                                          # oz_selfplay_config.dedup
+NET_OPT_SIMPLE_LOOP = 1                                                               # oz_net_set_option
+NET_INFO_CONV3_TILE_ROWS = 1                                                          # oz_net_get_info
 LEAF_IDLE, LEAF_TERMINAL, LEAF_EVAL = 0, 1, 2
 VT_INT, VT_F32, VT_F64 = 0, 1, 2
 NET_KERNELS = ("input", "conv2", "conv3", "conv4", "fc1", "fc2", "heads")           # OZ_NET_KERNELS slots
@@ -36,6 +39,7 @@ class SelfplayConfig(C.Structure):
         ("c", C.c_double), ("temperature", C.c_double), ("e_greedy", C.c_double),
         ("seed", C.c_uint64), ("first_game_id", C.c_uint64), ("game_id_stride", C.c_uint64),
         ("refill", C.c_int32), ("node_cap", C.c_int32), ("edge_cap", C.c_int32), ("record_cap", C.c_int32),
+        ("dedup", C.c_int32), ("batch_cap", C.c_int32),
     ]
 
 
@@ -80,8 +84,9 @@ SIGNATURES = {
     "oz_net_profile": [_vp, C.c_int], "oz_net_profile_read": [_vp, _f64p, _i64p],
     "oz_net_profiled_layer": [_vp, C.POINTER(C.c_int)], "oz_net_set_tables": [_vp, C.c_int],
     "oz_net_profile_kernels": [_vp, _f64p, _i64p, C.c_int],
+    "oz_net_set_option": [_vp, C.c_int, C.c_int], "oz_net_get_info": [_vp, C.c_int, C.POINTER(C.c_int)],
     "oz_mcts_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int],
-    "oz_mcts_destroy": [_vp], "oz_mcts_reset": [_vp, C.c_int],
+    "oz_mcts_destroy": [_vp], "oz_mcts_reset": [_vp, C.c_int], "oz_mcts_set_dedup": [_vp, C.c_int],
     "oz_mcts_set_roots": [_vp, _u64p, _u64p, _u8p],
     "oz_mcts_simulate": [_vp, _vp, C.c_int], "oz_mcts_select": [_vp],
     "oz_mcts_leaves": [_vp, _i32p, _u64p, _u64p],
@@ -93,7 +98,7 @@ SIGNATURES = {
     "oz_mcts_stats": [_vp, _i64p],
     "oz_selfplay_create": [C.POINTER(_vp), C.POINTER(SelfplayConfig), _vp],
     "oz_selfplay_destroy": [_vp], "oz_selfplay_run": [_vp, C.c_int], "oz_selfplay_run_steps": [_vp, C.c_int], "oz_selfplay_sync": [_vp],
-    "oz_selfplay_stagger": [_vp, C.c_int], "oz_selfplay_profile": [_vp, C.c_int], "oz_selfplay_set_batch_cap": [_vp, C.c_int],
+    "oz_selfplay_stagger": [_vp, C.c_int], "oz_selfplay_profile": [_vp, C.c_int], "oz_selfplay_set_batch_cap": [_vp, C.c_int], "oz_selfplay_set_dedup": [_vp, C.c_int],
     "oz_selfplay_profile_read": [_vp, _f64p, _i64p, C.c_int],
     "oz_selfplay_get_stats": [_vp, C.POINTER(SelfplayStats)],
     "oz_selfplay_state": [_vp, _u64p, _u64p, _i8p, _u8p, _i32p, _u64p],
@@ -102,7 +107,7 @@ SIGNATURES = {
     "oz_selfplay_last_counts": [_vp, _i32p],
     "oz_selfplay_eval_time": [_vp, _f64p, _i64p, _i64p],
     "oz_arena_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_uint64, _vp, _vp, C.c_int, C.c_int],
-    "oz_arena_destroy": [_vp], "oz_arena_run": [_vp],
+    "oz_arena_destroy": [_vp], "oz_arena_run": [_vp], "oz_arena_run_rounds": [_vp, C.c_int], "oz_arena_stats": [_vp, _i64p, _i64p],
     "oz_arena_results": [_vp, _i8p, _i32p, _i32p, _u8p, _i8p, _u64p, _u64p],
     "oz_examples_expand": [_vp, C.c_int64, C.c_int, C.c_int, _u8p, _i32p, _i8p],
     "oz_symmetry_table": [C.c_int, _i32p],

@@ -74,18 +74,22 @@ def duel_between_agents(game, agent_1, agent_2):
 
 
 def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, degree_exploration=1.0, seed=0,
-                first_game_id=0, q_mode=_lib.QMODE_F64, node_cap=0, edge_cap=0):
+                first_game_id=0, q_mode=_lib.QMODE_F64, node_cap=0, edge_cap=0, max_rounds=0):
     """num_games games of net_a (BLACK) vs net_b (WHITE), temperature 0, max-visit ties broken by the RNG_TIE
     stream keyed (seed, game id, ply).  One of the two may be None: RandomOthelloAgent plays that colour.
-    Returns dict(winner (+1 = BLACK's agent), points, n_moves, actions, players, final)."""
+    max_rounds > 0 stops after that many plies per game (unfinished boards: winner / points then describe the position reached).
+    Returns dict(winner (+1 = BLACK's agent), points, n_moves, actions, players, final boards, stats_black / stats_white =
+    the two agents' search counters [simulations, node visits, expansions, terminal hits, fallbacks])."""
     lib = _lib.require_gpu()
     h = C.c_void_p()
     _lib.check(lib.oz_arena_create(C.byref(h), board_size, num_games, num_simulations, float(degree_exploration), q_mode,
                                    seed, first_game_id, net_a._h if net_a is not None else None,
                                    net_b._h if net_b is not None else None, node_cap, edge_cap))
     try:
-        _lib.check(lib.oz_arena_run(h))
+        _lib.check(lib.oz_arena_run_rounds(h, int(max_rounds)))
         G = num_games
+        sa, sb = np.zeros(5, np.int64), np.zeros(5, np.int64)
+        _lib.check(lib.oz_arena_stats(h, _lib.p_i64(sa), _lib.p_i64(sb)))
         winner, points, nm = np.zeros(G, np.int8), np.zeros(G, np.int32), np.zeros(G, np.int32)
         acts, pls = np.zeros((G, 128), np.uint8), np.zeros((G, 128), np.int8)
         fb, fw = np.zeros(G, np.uint64), np.zeros(G, np.uint64)
@@ -93,4 +97,5 @@ def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, 
                                         _lib.p_i8(pls), _lib.p_u64(fb), _lib.p_u64(fw)))
     finally:
         lib.oz_arena_destroy(h)
-    return dict(winner=winner, points=points, n_moves=nm, actions=acts, players=pls, final_black=fb, final_white=fw)
+    return dict(winner=winner, points=points, n_moves=nm, actions=acts, players=pls, final_black=fb, final_white=fw,
+                stats_black=sa, stats_white=sb)

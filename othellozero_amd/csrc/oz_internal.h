@@ -1,5 +1,6 @@
 // oz_internal.h -- host-side object layouts shared by the translation units of libothellozero_amd.
 #pragma once
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -11,13 +12,17 @@
 int oz_current_device();
 
 // HIP-event stopwatch with named slots, for timing launches on the stream they are launched on without a host sync:
-// begin / end record a pooled event pair around a launch sequence, collect() folds finished pairs into per-slot totals
-// and returns the events to the pool (no event is created or destroyed per launch once the pool is warm; a pair whose
-// end() never came -- an error return between the two -- is recycled by cancel()).
+// begin / end record a pooled event pair around a launch sequence; collect() waits for every finished pair and folds it into
+// the per-slot totals, drain() folds only the pairs whose end event has ALREADY completed (hipEventQuery: no host stall --
+// what the drivers call inside their enqueue loops).  begin() returns a stable handle (a running pair number), so a
+// collect() / drain() between a begin and its end cannot redirect the end; a pair that is still open is kept.  No event is
+// created or destroyed per launch once the pool is warm; a pair whose end() never came is recycled by cancel().
 struct OzTimer {
-    struct Pend { hipEvent_t a, b; int slot; bool ended; };
+    enum { OPEN = 0, ENDED = 1, CANCELLED = 2, FAILED = 3 };
+    struct Pend { hipEvent_t a, b; int slot; int state; };
     std::vector<hipEvent_t> pool;
-    std::vector<Pend> pending;
+    std::deque<Pend> pending;           // pairs [base, base + size), in begin order (= stream order on one stream)
+    long long base = 0;
     std::vector<double> ms;
     std::vector<long long> count;
     explicit OzTimer(int slots = 1) : ms(slots, 0.0), count(slots, 0) {}
@@ -27,32 +32,40 @@ struct OzTimer {
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
     }
-    // returns the index to hand to end() / cancel(), or -1 (events unavailable: the launch simply goes untimed)
-    int begin(int slot, hipStream_t s) {
+    // returns the handle to give to end() / cancel(), or -1 (events unavailable: the launch simply goes untimed)
+    long long begin(int slot, hipStream_t s) {
         hipEvent_t a = get(), b = get();
         if (!a || !b) { if (a) pool.push_back(a); if (b) pool.push_back(b); return -1; }
         if (hipEventRecord(a, s) != hipSuccess) { pool.push_back(a); pool.push_back(b); return -1; }
-        pending.push_back({a, b, slot, false});
-        return (int)pending.size() - 1;
+        pending.push_back({a, b, slot, OPEN});
+        return base + (long long)pending.size() - 1;
     }
-    void end(int idx, hipStream_t s) {
-        if (idx < 0) return;
-        pending[idx].ended = hipEventRecord(pending[idx].b, s) == hipSuccess;
+    Pend* find(long long h) { return (h < base || h >= base + (long long)pending.size()) ? nullptr : &pending[(size_t)(h - base)]; }
+    void end(long long h, hipStream_t s) {
+        if (Pend* p = find(h)) p->state = hipEventRecord(p->b, s) == hipSuccess ? ENDED : FAILED;
     }
-    void cancel(int idx) { if (idx >= 0) pending[idx].ended = false; }
+    void cancel(long long h) { if (Pend* p = find(h)) p->state = CANCELLED; }
     size_t backlog() const { return pending.size(); }
-    int collect() {
+    // folds finished pairs from the front; wait = true blocks on every ended pair, false stops at the first one still running
+    int fold(bool wait) {
         int rc = OZ_OK;
-        for (auto& p : pending) {
-            float t = 0;
-            if (p.ended && hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
-                ms[p.slot] += t; count[p.slot] += 1;
-            } else if (p.ended) rc = OZ_ERR_HIP;
+        while (!pending.empty()) {
+            Pend& p = pending.front();
+            if (p.state == OPEN) break;                                  // begin() without its end() yet: keep it and what follows
+            if (p.state == ENDED) {
+                if (!wait && hipEventQuery(p.b) != hipSuccess) break;
+                float t = 0;
+                if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { ms[p.slot] += t; count[p.slot] += 1; }
+                else rc = OZ_ERR_HIP;
+            } else if (p.state == FAILED) rc = OZ_ERR_HIP;
             pool.push_back(p.a); pool.push_back(p.b);
+            pending.pop_front();
+            ++base;
         }
-        pending.clear();
         return rc;
     }
+    int collect() { return fold(true); }
+    int drain() { return fold(false); }
     void reset() { for (auto& x : ms) x = 0; for (auto& x : count) x = 0; }
     void destroy() {
         for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }

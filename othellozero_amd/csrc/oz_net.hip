@@ -323,19 +323,17 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
     const long long Mmax = (long long)max_count * Hout * Hout;
     // pixel-major tiles skip the k-tiles of taps that only read zeros; they pay when the boards fill the 128-row tiles
     // (keyed on the call's capacity `max_count` / `sizing_count`, like the split-K choice: per-network constants)
-    static const bool pm_env = !(getenv("OZ_GEMM_PIXMAJOR") && atoi(getenv("OZ_GEMM_PIXMAJOR")) == 0);
     const int cap = sizing_count > 0 ? sizing_count : max_count;
     // ... and only where there IS a tap to skip ('same' padding, or a zero-bordered input): on 'valid' layers over dense inputs the
     // pixel-major order has nothing to skip and costs L2 reuse of the overlapping 3x3 windows (HBM-side reads of conv3 at 4096
     // positions 3.5 -> 4.2 GB per launch, -4 % throughput -- measured, round 2)
     const bool has_zero_taps = pad > 0 || core_lo > 0 || (core_hi >= 0 && core_hi < Hin);
-    g.pixmajor = pm_env && taps == 9 && has_zero_taps && cap >= 2 * GM_BM && ((cap + GM_BM - 1) / GM_BM) * GM_BM <= cap + cap / 8;
+    g.pixmajor = taps == 9 && has_zero_taps && cap >= 2 * GM_BM && ((cap + GM_BM - 1) / GM_BM) * GM_BM <= cap + cap / 8;
     const int num_mt = g.pixmajor ? ((max_count + GM_BM - 1) / GM_BM) * Hout * Hout : (int)((Mmax + GM_BM - 1) / GM_BM);
     const int grid = ((num_mt + 7) / 8) * 8 * (N / GM_BN);
     // dense layers on at most 64 rows: the weight-stream kernel (the capacity decides, a per-network constant)
-    static const bool skinny_env = !(getenv("OZ_GEMM_SKINNY") && atoi(getenv("OZ_GEMM_SKINNY")) == 0);
     const int Pout = Hout * Hout;
-    if (skinny_env && partial && (long long)cap * Pout <= 64 && (long long)max_count * Pout <= 64 && Cin % 64 == 0 && N % SK_COLS == 0) {
+    if (partial && (long long)cap * Pout <= 64 && (long long)max_count * Pout <= 64 && Cin % 64 == 0 && N % SK_COLS == 0) {
         int kb = SK_KB_MAX;
         while (kb > 64 && (Cin % kb != 0 || (long long)(N / SK_COLS) * (g.K / kb) < 192)) kb /= 2;
         const int ks = g.K / kb;
@@ -358,7 +356,7 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
         const long long Ms = (long long)(sizing_count > 0 ? sizing_count : max_count) * Hout * Hout;
         // blocks that have rows to work on (the grid is padded to a multiple of 8 row tiles for the XCD mapping; padding blocks exit at once)
         const int grid_s = (int)((Ms + GM_BM - 1) / GM_BM) * (N / GM_BN);
-        static const int split_blocks = getenv("OZ_GEMM_SPLIT_BLOCKS") ? atoi(getenv("OZ_GEMM_SPLIT_BLOCKS")) : 256;     // A/B runs
+        const int split_blocks = 256;                       // one block per CU
         while (ksplit < 16 && grid_s * ksplit < split_blocks && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * (Ms > Mmax ? Ms : Mmax) * N <= partial_floats) ksplit *= 2;
     }
     g.ksplit = ksplit; g.slab = Mmax * N;
@@ -412,13 +410,13 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
     void* dst = ksplit > 1 ? (void*)partial : (void*)out;
     if (big)
         hipLaunchKernelGGL(k_gemm_h2<H2BigPP>, dim3(grid), dim3(H2BigPP::NT), H2BigPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
-                           d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned short*)nullptr);
+                           d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
     else if (ksplit <= 4)
         hipLaunchKernelGGL(k_gemm_h2<H2Small>, dim3(grid), dim3(H2Small::NT), H2Small::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
-                           d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned short*)nullptr);
+                           d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
     else
         hipLaunchKernelGGL(k_gemm_h2<H2Small2>, dim3(grid), dim3(H2Small2::NT), H2Small2::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
-                           d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned short*)nullptr);
+                           d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
     if (ksplit > 1) {
         const long long quads = (Mmax * N + 3) / 4;
         hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float*)partial, g.slab, ksplit, N,
@@ -545,9 +543,9 @@ struct OnnNet : oz_net {
     uint4* d_zero = nullptr;
     // conv1 as a lookup (H2BigPPLut): the OZ_LUT_ROWS possible conv1 output rows and the per-pixel pattern ids of a batch
     uint4* d_lut = nullptr;
-    unsigned short* d_lut_ids = nullptr;
+    unsigned* d_lut_ids = nullptr;    // per-pixel pattern ids of a batch, padded boards [max_batch][(n + 2)^2] (k_lut_ids)
     bool lut_ok = false;
-    float* d_t2 = nullptr;           // conv2 as a gather-sum (k_conv2_lut): [9][OZ_LUT_PATTERNS][C]
+    float* d_t2 = nullptr;           // conv2 as a gather-sum (k_conv2_lut): [9][OZ_LUT_ROWS][C], the last row of every tap = zeros
     uint4* d_wtap = nullptr;         // build_t2 staging: conv2's kernel as nine [C][C] matrices in the h2 layout
     float* d_raw = nullptr;          // oz_net_commit staging: one Keras kernel as stored
     float* d_lut32 = nullptr;        // precision f32: conv1 pattern table [OZ_LUT_PATTERNS][C] fp32
@@ -562,7 +560,10 @@ struct OnnNet : oz_net {
     // mode 2 = every kernel of the forward (slot order: OZ_NET_KERNELS in the header)
     int profile = 0;
     OzTimer timer{OZ_NET_KERNELS};
-    int tables_mode = -1;            // oz_net_set_tables: -1 = environment default, 0 / 1 / 2 see forward_h2
+    int tables_mode = -1;            // oz_net_set_tables: -1 = default (2), 0 / 1 / 2 see forward_h2
+    bool simple_loop = false;        // oz_net_set_option(OZ_NET_OPT_SIMPLE_LOOP): one-barrier-per-k-tile loop for the 3x3 layers (race screen)
+    float* d_t2rows = nullptr;       // commit staging: one tap's T2 rows [OZ_LUT_PATTERNS][C] before the slice-major re-layout
+    int last_conv3_rows = 0;         // row-tile height the last forward ran conv3 on (oz_net_get_info)
     int profiled_layer = 2;          // 2 = conv2 GEMM, 3 = conv3 GEMM (when conv2 runs as the table gather-sum)
 
     template <typename T> int alloc(T** p, size_t count) {
@@ -623,7 +624,7 @@ struct OnnNet : oz_net {
     template <typename CF>
     int launch_gemm_h2(const void* in, int layer, void* out, int out_h2, const int* d_count, int max_count, int Hin,
                        int Hout, int pad, int Cin, int taps, int N, hipStream_t s, int ksplit = 1,
-                       const unsigned short* lut_ids = nullptr, const uint4* w_alt = nullptr, const float* scale_alt = nullptr,
+                       const unsigned* lut_ids = nullptr, const uint4* w_alt = nullptr, const float* scale_alt = nullptr,
                        const float* shift_alt = nullptr, int relu = 1) {
         H2Geom g;
         g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.out_h2 = out_h2; g.relu = relu;
@@ -637,7 +638,6 @@ struct OnnNet : oz_net {
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Big>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Big::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2BigPP::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2MidPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2MidPP::LDS));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2MidPP3>, hipFuncAttributeMaxDynamicSharedMemorySize, H2MidPP3::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPPLut>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        H2BigPPLut::LDS + 9 * H2BigPPLut::BM * 2));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Mid>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Mid::LDS));
@@ -666,11 +666,23 @@ struct OnnNet : oz_net {
 
     // small tiles (dense layers, latency path): three LDS stages for medium and large networks (-4 .. -6 % per forward at 128 .. 512
     // positions, +-0 at 4096), the two-stage loop for the 16-way split-K launches of small networks, where the deeper pipeline
-    // measured SLOWER (one position: 0.152 -> 0.186 ms).  Bit-identical either way; OZ_H2_STAGES=2 / 3 forces one (A/B runs).
+    // measured SLOWER (one position: 0.152 -> 0.186 ms).  Bit-identical either way (tools/pp_race_check.py compares networks of both kinds).
     template <typename CF3, typename CF2, typename... Args> int launch_small(Args... args) {
-        static const int forced = getenv("OZ_H2_STAGES") ? atoi(getenv("OZ_H2_STAGES")) : 0;
-        const bool two = forced == 2 || (forced != 3 && max_batch <= 32);
-        return two ? launch_gemm_h2<CF2>(args...) : launch_gemm_h2<CF3>(args...);
+        return max_batch <= 32 ? launch_gemm_h2<CF2>(args...) : launch_gemm_h2<CF3>(args...);
+    }
+
+    // conv1 + conv2 as the table gather-sum: one table slice per XCD at 512 filters, the thread-per-(pixel, 8 channels) kernel otherwise
+    template <bool OUT_H2> void launch_conv2_lut(int max_count, const int* d_count, const float* scale, const float* shift, void* out, hipStream_t s) {
+        const long long pixels = (long long)max_count * n * n;
+        if (C == 512) {
+            const unsigned blocks = 8u * (unsigned)((pixels + 32 * OZ_C2L_PPT - 1) / (32 * OZ_C2L_PPT));
+            if (n == 8) hipLaunchKernelGGL((k_conv2_lut_xcd<8, OUT_H2>), dim3(blocks), dim3(256), 0, s, d_lut_ids, d_count, d_t2, scale, shift, out, d_flag);
+            else hipLaunchKernelGGL((k_conv2_lut_xcd<6, OUT_H2>), dim3(blocks), dim3(256), 0, s, d_lut_ids, d_count, d_t2, scale, shift, out, d_flag);
+        } else {
+            const long long threads = pixels * (C / 8);
+            hipLaunchKernelGGL(k_conv2_lut<OUT_H2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_lut_ids, d_count, n, C, d_t2, scale, shift,
+                               out, d_flag);
+        }
     }
 
     // T2[t] = table . W_t^T (raw k-sums, scaled 2^kexp like the convolution's): nine GEMMs M = OZ_LUT_PATTERNS, K = N = C
@@ -686,11 +698,15 @@ struct OnnNet : oz_net {
             OZ_HIP(hipMemset(d_nul, 0, sizeof(float) * C));
             OZ_HIP(hipMemcpy(d_rows, &rows, sizeof(int), hipMemcpyHostToDevice));
         }
-        if (!d_t2) { if (int rc = alloc(&d_t2, (size_t)9 * OZ_LUT_PATTERNS * C)) return rc; }
+        if (!d_t2) { if (int rc = alloc(&d_t2, (size_t)9 * OZ_LUT_ROWS * C)) return rc; }
         int rc = OZ_OK;
-        for (int t = 0; t < 9 && rc == OZ_OK; ++t)
-            rc = launch_gemm_h2<H2BigPP>(d_lut, 1, d_t2 + (size_t)t * OZ_LUT_PATTERNS * C, 0, d_rows, OZ_LUT_PATTERNS, 1, 1, 0, C, 1, C, 0, 1, nullptr,
+        if (!d_t2rows) { if (int rc2 = alloc(&d_t2rows, (size_t)OZ_LUT_PATTERNS * C)) return rc2; }
+        for (int t = 0; t < 9 && rc == OZ_OK; ++t) {        // one tap at a time: GEMM rows -> staging -> slice-major records (same stream: ordered)
+            rc = launch_gemm_h2<H2BigPP>(d_lut, 1, d_t2rows, 0, d_rows, OZ_LUT_PATTERNS, 1, 1, 0, C, 1, C, 0, 1, nullptr,
                                          d_wtap + (size_t)t * C * (C / 4), d_one, d_nul, 0);
+            const long long quads = (long long)OZ_LUT_ROWS * C / 4;
+            hipLaunchKernelGGL(k_t2_to_slices, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, 0, d_t2rows, C, t, d_t2);
+        }
         OZ_HIP(hipDeviceSynchronize());
         if (rc == OZ_OK) t2_ok = true;
         return rc;
@@ -699,7 +715,7 @@ struct OnnNet : oz_net {
     // precision f32: the same tables in exact fp32 arithmetic (rows by k_lut_build_f32, T2 by nine fp32 MFMA GEMMs)
     int build_t2_f32() {
         if (!d_lut32) { if (int rc = alloc(&d_lut32, (size_t)OZ_LUT_PATTERNS * C)) return rc; }
-        if (!d_lut_ids) { if (int rc = alloc(&d_lut_ids, (size_t)max_batch * n * n)) return rc; }
+        if (!d_lut_ids) { if (int rc = alloc(&d_lut_ids, (size_t)max_batch * (n + 2) * (n + 2))) return rc; }
         if (!d_wtap32) { if (int rc = alloc(&d_wtap32, (size_t)9 * C * C)) return rc; }
         if (!d_one) {
             if (int rc = alloc(&d_one, (size_t)C)) return rc;
@@ -711,13 +727,17 @@ struct OnnNet : oz_net {
             OZ_HIP(hipMemset(d_nul, 0, sizeof(float) * C));
             OZ_HIP(hipMemcpy(d_rows, &rows, sizeof(int), hipMemcpyHostToDevice));
         }
-        if (!d_t2) { if (int rc = alloc(&d_t2, (size_t)9 * OZ_LUT_PATTERNS * C)) return rc; }
+        if (!d_t2) { if (int rc = alloc(&d_t2, (size_t)9 * OZ_LUT_ROWS * C)) return rc; }
+        if (!d_t2rows) { if (int rc2 = alloc(&d_t2rows, (size_t)OZ_LUT_PATTERNS * C)) return rc2; }
         const long long threads = (long long)OZ_LUT_PATTERNS * C;
         hipLaunchKernelGGL(k_lut_build_f32, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, C, d_w1, d_scale[0], d_shift[0], d_lut32);
         OZ_HIP(hipGetLastError());
-        for (int t = 0; t < 9; ++t)
-            if (int rc = oz_gemm_f32_launch(d_lut32, d_wtap32 + (size_t)t * C * C, d_one, d_nul, d_t2 + (size_t)t * OZ_LUT_PATTERNS * C, d_rows,
+        for (int t = 0; t < 9; ++t) {
+            if (int rc = oz_gemm_f32_launch(d_lut32, d_wtap32 + (size_t)t * C * C, d_one, d_nul, d_t2rows, d_rows,
                                             OZ_LUT_PATTERNS, 1, 1, 0, C, 1, C, 0, 0, nullptr, 0, 0)) return rc;
+            const long long quads = (long long)OZ_LUT_ROWS * C / 4;
+            hipLaunchKernelGGL(k_t2_to_slices, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, 0, d_t2rows, C, t, d_t2);
+        }
         OZ_HIP(hipDeviceSynchronize());
         t2f_ok = true;
         return OZ_OK;
@@ -738,22 +758,20 @@ struct OnnNet : oz_net {
 
     int forward_h2(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi, float* d_v,
                    hipStream_t s) {
-        static const bool pp = !(getenv("OZ_H2_PP") && atoi(getenv("OZ_H2_PP")) == 0);    // ping-pong main loop (default); OZ_H2_PP=0 selects the one-barrier-per-tile loop for A/B runs
-        // The input planes are discrete, so conv1 (and conv2 behind it) are functions of small neighbourhood patterns:
-        //   OZ_H2_T2  (default on): conv1 + conv2 as a gather-sum over the per-tap tables T2 (k_conv2_lut) -- no GEMM for conv2
-        //   OZ_H2_LUT (default on): when T2 is off, conv1 as a table lookup inside conv2's operand gather (H2BigPPLut; bit-identical
-        //                           to the conv1 kernel); OZ_H2_LUT=0 also implies no T2: conv1 kernel + conv2 GEMM
-        static const bool lut_env = !(getenv("OZ_H2_LUT") && atoi(getenv("OZ_H2_LUT")) == 0);
-        static const bool t2_env = !(getenv("OZ_H2_T2") && atoi(getenv("OZ_H2_T2")) == 0);
-        // tables_mode (oz_net_set_tables): -1 = the environment switches above, 0 = none, 1 = conv1 table only, 2 = both
-        const bool want_lut = tables_mode < 0 ? lut_env : tables_mode >= 1;
-        const bool want_t2 = tables_mode < 0 ? (lut_env && t2_env) : tables_mode >= 2;
+        // main loop of the 3x3 convolutions: the 4-phase ping-pong loop, or (oz_net_set_option OZ_NET_OPT_SIMPLE_LOOP: the reference
+        // form the race screen compares against, tools/pp_race_check.py) one barrier per k-tile; same accumulation order, bit-identical
+        const bool pp = !simple_loop;
+        // The input planes are discrete, so conv1 (and conv2 behind it) are functions of small neighbourhood patterns
+        // (oz_net_set_tables): 2 (default) = conv1 + conv2 as a gather-sum over the per-tap tables T2 (k_conv2_lut) -- no GEMM for conv2;
+        // 1 = conv1 as a table lookup inside conv2's operand gather (H2BigPPLut; bit-identical to the conv1 kernel); 0 = conv1 kernel + conv2 GEMM
+        const bool want_lut = tables_mode < 0 || tables_mode >= 1;
+        const bool want_t2 = tables_mode < 0 || tables_mode >= 2;
         const bool use_t2 = want_t2 && t2_ok;
         const bool use_lut = !use_t2 && pp && want_lut && lut_ok && max_batch > 32;
         // HIP events around the dominant launch (the conv2 GEMM, or conv3 when conv2 is the gather-sum), or around every kernel
         profiled_layer = use_t2 ? 3 : 2;
-        if (profile && timer.backlog() > 8192) { if (int rc = collect_profile()) return rc; }
-        int tidx = -1;
+        if (profile && timer.backlog() > 4096) timer.drain();          // no host stall inside an enqueue loop: only pairs that have completed
+        long long tidx = -1;
         auto mark = [&](int slot, bool begin) {
             if (!(profile == 2 || (profile == 1 && slot == profiled_layer - 1))) return;
             if (begin) tidx = timer.begin(slot, s);
@@ -761,7 +779,7 @@ struct OnnNet : oz_net {
         };
         mark(0, true);
         if (use_t2 || use_lut) {
-            const long long threads = (long long)max_count * n * n;
+            const long long threads = (long long)max_count * (n + 2) * (n + 2);
             hipLaunchKernelGGL(k_lut_ids, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, d_lut_ids);
         } else {
             const long long threads = (long long)max_count * n * (C / 8);       // one thread per (board row, 8 channels)
@@ -776,8 +794,7 @@ struct OnnNet : oz_net {
         // medium networks (arenas, evaluation batches, the loop's 100 episodes): a convolution whose grid would leave most
         // CUs idle splits its k loop (conv_ksplit: from max_batch, a per-network constant; 1 at the bench's 4096 games)
         // conv3 tile: 192 rows on 8x8 (36 output pixels per board: 6.0 grid rounds at 4096 boards instead of 4.5); on 6x6 (16 pixels per board) the
-        // 256-row tile = 16 whole boards, 2.0 rounds instead of 2.7 (OZ_H2_CONV3_BIG=0 / 1 forces one: A/B runs)
-        static const int conv3_big_env = getenv("OZ_H2_CONV3_BIG") ? atoi(getenv("OZ_H2_CONV3_BIG")) : -1;
+        // 256-row tile = 16 whole boards, 2.0 rounds instead of 2.7
         // ... and on either board the tile whose grid pays fewer tile-rows for the batch this call may hold: rounds of 256 CUs x tile height
         // (4096 boards of 8x8: 192 rows -> 6 rounds x 192; a caller that caps its batches at 3640 gets 256 rows -> 4.0 rounds x 256, -13 % per launch).
         // Both tiles add every output element's products in the same order: bit-identical results.
@@ -785,27 +802,24 @@ struct OnnNet : oz_net {
             const long long blocks = (((long long)max_count * (n - 2) * (n - 2) + BM - 1) / BM) * (C / 256);
             return ((blocks + 255) / 256) * BM;
         };
-        const bool conv3_big = conv3_big_env >= 0 ? conv3_big_env != 0 : (n == 6 || tile_cost(256) < tile_cost(192));
+        const bool conv3_big = n == 6 || tile_cost(256) < tile_cost(192);
+        last_conv3_rows = small ? 128 : (pp && conv3_big) ? 256 : 192;
         // (the k-split stays a constant of the network -- max_batch and the board decide it, not the tile this call picked -- so a position's
         //  result does not depend on the size of the call it sits in)
-        const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), (conv3_big_env >= 0 ? conv3_big_env != 0 : n == 6) ? 256 : 192),
+        const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), n == 6 ? 256 : 192),
                   k4 = conv_ksplit((n - 4) * (n - 4), 256);
         mark(1, true);
         if (use_t2) {
-            const long long threads = (long long)max_count * n * n * (C / 8);
-            hipLaunchKernelGGL(k_conv2_lut, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_lut_ids, d_count, n, C, d_t2,
-                               d_scale_h2[0], d_shift[1], (uint4*)act2, d_flag);
+            launch_conv2_lut<true>(max_count, d_count, d_scale_h2[0], d_shift[1], act2, s);
         } else if (int rc = small     ? launch_small<H2Small, H2Small2>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, 16)
                             : use_lut ? launch_gemm_h2<H2BigPPLut>(d_lut, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2, d_lut_ids)
                             : pp      ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)
                                       : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)) return rc;
         mark(1, false);
         mark(2, true);
-        // 3-phase loop on the 192-row tile (24-MFMA clusters): bit-identical, measured 0 .. +2 % on conv3 -- the layer is clock / power
-        // bound, not load-section bound -- so the 4-phase loop stays the default; OZ_H2_PP3=1 selects it
-        static const bool pp3 = getenv("OZ_H2_PP3") && atoi(getenv("OZ_H2_PP3")) != 0;
+        // (a 3-phase loop on the 192-row tile -- 24-MFMA clusters -- measured 0 .. +2 % in round 2: the layer is clock / power bound,
+        //  not load-section bound; deleted in round 3)
         if (int rc = small ? launch_small<H2Small, H2Small2>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, 16)
-                     : pp && pp3 ? launch_gemm_h2<H2MidPP3>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                      : pp && conv3_big ? launch_gemm_h2<H2BigPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                      : pp  ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                            : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
@@ -819,9 +833,8 @@ struct OnnNet : oz_net {
         // fc1: K = 8192 but only batch x 1024 outputs -> split-K (fixed-order reduce) to fill the chip
         // (large batches: on the 256 x 256 ping-pong tile, 16 x 4 tiles x 4 k-slices = one block per CU; bit-identical to
         //  the 128 x 128 tile because the k-slices and the order inside them are the same -- tools/pp_race_check.py)
-        static const bool fc1pp = !(getenv("OZ_H2_FC1PP") && atoi(getenv("OZ_H2_FC1PP")) == 0);
         if (int rc = small ? launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)
-                     : (fc1pp && pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
+                     : (pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
                                                           : launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
         mark(4, false);
         mark(5, true);
@@ -842,24 +855,23 @@ struct OnnNet : oz_net {
         if (precision == 1) return forward_h2(d_own, d_opp, d_count, max_count, d_pi, d_v, s);
         const int P = n * n;
         // precision f32: conv1 + conv2 from the fp32 pattern tables (default), or conv1 kernel + conv2 GEMM (oz_net_set_tables 0 / 1, OZ_H2_T2=0)
-        static const bool t2f_env = !(getenv("OZ_H2_T2") && atoi(getenv("OZ_H2_T2")) == 0) && !(getenv("OZ_H2_LUT") && atoi(getenv("OZ_H2_LUT")) == 0);
-        const bool use_t2f = (tables_mode < 0 ? t2f_env : tables_mode >= 2) && t2f_ok;
+        const bool use_t2f = (tables_mode < 0 || tables_mode >= 2) && t2f_ok;
+        last_conv3_rows = GM_BM;
         profiled_layer = use_t2f ? 3 : 2;
-        if (profile && timer.backlog() > 8192) { if (int rc = collect_profile()) return rc; }
-        int tidx = -1;
+        if (profile && timer.backlog() > 4096) timer.drain();          // no host stall inside an enqueue loop: only pairs that have completed
+        long long tidx = -1;
         auto mark = [&](int slot, bool begin) {
             if (!(profile == 2 || (profile == 1 && slot == profiled_layer - 1))) return;
             if (begin) tidx = timer.begin(slot, s);
             else { timer.end(tidx, s); tidx = -1; }
         };
         if (use_t2f) {
-            const long long pixels = (long long)max_count * P, threads = pixels * (C / 8);
+            const long long cells = (long long)max_count * (n + 2) * (n + 2);
             mark(0, true);
-            hipLaunchKernelGGL(k_lut_ids, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, d_lut_ids);
+            hipLaunchKernelGGL(k_lut_ids, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, d_lut_ids);
             mark(0, false);
             mark(1, true);
-            hipLaunchKernelGGL(k_conv2_lut_f32, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_lut_ids, d_count, n, C, d_t2,
-                               d_scale[1], d_shift[1], act2);
+            launch_conv2_lut<false>(max_count, d_count, d_scale[1], d_shift[1], act2, s);
             mark(1, false);
         } else {
             const long long threads = (long long)max_count * P * (C / 4);
@@ -1064,7 +1076,7 @@ OZ_API int oz_net_commit(oz_net* net) {
             // fp16 range disables the table for this network (the conv1 kernel then raises the flag on real positions)
             const size_t row_q = (size_t)C / 4;                                  // uint4 per row
             if (!o->d_lut) { if (int rc = o->alloc(&o->d_lut, (size_t)OZ_LUT_ROWS * row_q)) return rc; }
-            if (!o->d_lut_ids) { if (int rc = o->alloc(&o->d_lut_ids, (size_t)o->max_batch * n * n)) return rc; }
+            if (!o->d_lut_ids) { if (int rc = o->alloc(&o->d_lut_ids, (size_t)o->max_batch * (n + 2) * (n + 2))) return rc; }
             OZ_HIP(hipMemset(o->d_lut + (size_t)OZ_LUT_PATTERNS * row_q, 0, row_q * sizeof(uint4)));
             const long long threads = (long long)OZ_LUT_PATTERNS * (C / 8);
             hipLaunchKernelGGL(k_lut_build, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, C, o->d_w1, o->d_scale[0], o->d_shift[0],
@@ -1202,14 +1214,6 @@ OZ_API int oz_net_profile(oz_net* net, int enable) {
     o->profile = enable;
     return OZ_OK;
 }
-#ifdef H2PP_STAMPS
-OZ_API int oz_debug_h2_stamps(unsigned long long* out48) {
-    OZ_HIP(hipDeviceSynchronize());
-    OZ_HIP(hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_h2_stamps), sizeof(unsigned long long) * 48));
-    OZ_HIP(hipMemcpyFromSymbol(out48 + 48, HIP_SYMBOL(g_h2_clk), sizeof(unsigned long long) * 16));
-    return OZ_OK;
-}
-#endif
 
 OZ_API int oz_net_set_tables(oz_net* net, int mode) {
     OnnNet* o = as_onn(net);
@@ -1217,6 +1221,24 @@ OZ_API int oz_net_set_tables(oz_net* net, int mode) {
     OZ_REQUIRE(mode >= -1 && mode <= 2, "tables mode must be -1 (default), 0 (none), 1 (conv1) or 2 (conv1 + conv2)");
     std::lock_guard<std::mutex> lk(o->mu);
     o->tables_mode = mode;
+    return OZ_OK;
+}
+
+OZ_API int oz_net_set_option(oz_net* net, int option, int value) {
+    OnnNet* o = as_onn(net);
+    OZ_REQUIRE(o, "not an OthelloNN network");
+    OZ_REQUIRE(option == OZ_NET_OPT_SIMPLE_LOOP, "unknown network option %d", option);
+    std::lock_guard<std::mutex> lk(o->mu);
+    o->simple_loop = value != 0;
+    return OZ_OK;
+}
+
+OZ_API int oz_net_get_info(oz_net* net, int what, int* value) {
+    OnnNet* o = as_onn(net);
+    OZ_REQUIRE(o && value, "not an OthelloNN network / null argument");
+    OZ_REQUIRE(what == OZ_NET_INFO_CONV3_TILE_ROWS, "unknown network info %d", what);
+    std::lock_guard<std::mutex> lk(o->mu);
+    *value = o->last_conv3_rows;
     return OZ_OK;
 }
 

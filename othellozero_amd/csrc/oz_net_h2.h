@@ -37,17 +37,17 @@
 //   all three: 1.77-1.89 GHz, 66-70 % matrix-pipe busy -> clock/power bound, not issue bound
 //   16x16x32 shape (this kernel) ..................... 2.53 ms   (higher sustained clock on this shape)
 //   + swizzle key for the 16x16x32 operand map ....... 2.40 ms   (LDS conflict cycles 50 % -> 3 %)
-//   ablation of THIS kernel (tools/build_variant.sh -DH2_EXP_NODMA [-DH2_EXP_NOBARRIER]): 2.47 ms full, 2.06 ms with
+//   ablation of THIS kernel (round-1 experiment builds, since deleted): 2.47 ms full, 2.06 ms with
 //   no DMA in the loop, 2.00 ms with no DMA and no barrier; A staged for 1 tap of 9 only: 2.36 ms.  So the floor of
 //   this structure is LDS reads + MFMA at the power-limited clock (~620 TFLOP/s fp32-equivalent); LDS-DMA issue/wait
 //   costs 16 %, barriers 3 %, and tap reuse for A alone would buy <= 4.5 %.
 //   4-phase ping-pong loop (H2BigPP): conv2 2.41 -> 2.15 ms on the same device (-10 %), bench 842 k -> 915 k expansions/s.
-//     In-kernel stamps (tools/pp_stamps.py, -DH2PP_STAMPS): clock 2.20-2.28 GHz; per interval (one wave row in its 24-MFMA
+//     In-kernel s_memtime stamps (round-1 diagnostic build, since deleted): clock 2.20-2.28 GHz; per interval (one wave row in its 24-MFMA
 //     cluster, the other in its L section) ~531 cycles against 395 of MFMA issue (16.4 cycles per MFMA, measured alone in
 //     tools/ubench/mfma_bank.hip, independent of the operands' VGPR banks); without any DMA 469.  Variants on that loop:
 //     s_setprio around the cluster -2 %; DMA before the reads of an L section +-0; chained vs product-major MFMA order
 //     +-0; accumulators in AGPRs (inline asm) slower; no vmcnt wait at all +-0 (the waits are free); 2 phases per tile
-//     (half the barriers, -DH2PP_2PHASE) +-0 on conv2 and slower on conv3/conv4; the last 4 / 8 MFMAs of a cluster
+//     (half the barriers) +-0 on conv2 and slower on conv3/conv4; the last 4 / 8 MFMAs of a cluster
 //     issued after its closing barrier (hand-over overlap) 5 / 7 % slower; a second copy of the loop without the zero-line
 //     select for the pad-0 layers pushed spills into the loop (2.19 -> 2.53 ms); s_setprio 1 for wave row 1 over the whole loop
 //     -1 %; the nt cache policy on the A pieces -5 %.  What is left is the issue cost of the 8
@@ -81,14 +81,12 @@ template <int NWM, int NWN, int NTI, int NTJ, int NST = 2> struct H2Cfg {
     static_assert(NW * SLICE <= LDS, "epilogue slices must fit in the staging buffers");
     static constexpr bool PP = false;     // main loop: false = one barrier per k-tile; true = 4-phase ping-pong (H2BigPP)
     static constexpr bool LUT = false;    // A rows gathered from the conv1 pattern table (H2BigPPLut), see k_lut_build
-    static constexpr bool PP3 = false;    // 192-row tile: 3-phase ping-pong (thirds of the A rows x all four B blocks, 24-MFMA clusters)
 };
 typedef H2Cfg<2, 4, 4, 2> H2Big;      // conv2, conv4: 256 x 256
 // the same tile with the ping-pong main loop: the two wave rows (= the two waves of every SIMD) run half a phase
 // apart, so one of them is in its MFMA cluster while the other issues LDS reads and LDS-DMA (see k_gemm_h2)
 struct H2BigPP : H2Cfg<2, 4, 4, 2> { static constexpr bool PP = true; };
 struct H2MidPP : H2Cfg<2, 4, 3, 2> { static constexpr bool PP = true; };
-struct H2MidPP3 : H2Cfg<2, 4, 3, 2> { static constexpr bool PP3 = true; };
 // conv2 with conv1 folded into a lookup: the conv1 + BN + ReLU output of a pixel depends only on the 3 x 3 neighbourhood
 // of the position (9 cells, each empty / own / opponent: 3^9 = 19683 patterns), so conv2's A rows are LDS-DMA'd straight
 // from a table of the 19683 possible rows (+ one zero row for taps outside the board) instead of from a conv1 output
@@ -97,7 +95,7 @@ struct H2BigPPLut : H2BigPP { static constexpr bool LUT = true; };
 #define OZ_LUT_PATTERNS 19683
 #define OZ_LUT_ROWS (OZ_LUT_PATTERNS + 1)  // row OZ_LUT_PATTERNS = zeros
 typedef H2Cfg<2, 4, 3, 2> H2Mid;      // conv3 (M = B*36): 192 x 256 -> 1536 blocks = 6.0 rounds of 256 CUs (256 x 256: 4.5)
-typedef H2Cfg<2, 2, 2, 2> H2Small2;   // 128 x 128, two LDS stages (kept for A/B runs: OZ_H2_STAGES=2)
+typedef H2Cfg<2, 2, 2, 2> H2Small2;   // 128 x 128, two LDS stages (the 16-way split-K launches of one-position networks)
 typedef H2Cfg<1, 2, 2, 2> H2Thin2;    // 64 x 128, 2 waves, two stages
 // The small tiles serve launches with few k-tiles of MFMA work per wave: with two stages every k-tile exposes an LDS-DMA
 // round trip; three stages keep two k-tiles in flight (counted vmcnt, one barrier per k-tile).  Same accumulation order,
@@ -165,13 +163,6 @@ __device__ __forceinline__ void h2_split(float x, _Float16& h1, _Float16& h2) {
 // (the natural (row>>1)&7 key is conflict-free only for the 32x32x16 map: measured 50 % conflict cycles here)
 __device__ __forceinline__ int h2_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) * 6); }
 
-#ifdef H2PP_STAMPS                        // diagnostic build only (tools/pp_stamps.py): cycle budget of the ping-pong loop
-__device__ unsigned long long g_h2_stamps[8][6];
-__device__ unsigned long long g_h2_clk[8][2];
-#define H2_ST(k) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); st_acc[k] += t__ - st_prev; st_prev = t__; } while (0)
-#else
-#define H2_ST(k) do { } while (0)
-#endif
 typedef const __attribute__((address_space(1))) void* h2_gptr;
 typedef __attribute__((address_space(3))) void* h2_lptr;
 
@@ -279,13 +270,17 @@ __global__ __launch_bounds__(256) void k_w_to_h2(const float* __restrict__ src, 
     dst[1] = *reinterpret_cast<uint4*>(&h2);
 }
 
-// pattern id of every pixel: sum over the 3 x 3 neighbourhood (ky, kx) of 3^(ky*3+kx) * {0 empty or off the board, 1 own, 2 opponent}
+// pattern id of every pixel: sum over the 3 x 3 neighbourhood (ky, kx) of 3^(ky*3+kx) * {0 empty or off the board, 1 own, 2 opponent}.
+// Layout: PADDED boards [batch][(n+2)][(n+2)] of 32-bit ids, the one-cell border holding OZ_LUT_PATTERNS -- the index of the all-zero
+// row every table ends with -- so that the consumers (k_conv2_lut*, the H2BigPPLut gather) read the 3 x 3 window of a pixel with no
+// bounds test and an off-board tap adds an exact +0.0 (wave-uniform 32-bit ids are also what the scalar unit can load).
 __global__ __launch_bounds__(256) void k_lut_ids(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
-                                                 const int* __restrict__ d_count, int n, unsigned short* __restrict__ ids) {
-    const int P = n * n;
+                                                 const int* __restrict__ d_count, int n, unsigned* __restrict__ ids) {
+    const int W = n + 2, PW = W * W;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)(*d_count) * P) return;
-    const int b = (int)(idx / P), pix = (int)(idx % P), y = pix / n, x = pix % n;
+    if (idx >= (long long)(*d_count) * PW) return;
+    const int b = (int)(idx / PW), cell = (int)(idx % PW), y = cell / W - 1, x = cell % W - 1;
+    if (y < 0 || y >= n || x < 0 || x >= n) { ids[idx] = OZ_LUT_PATTERNS; return; }
     const uint64_t o = own[b], p = opp[b];
     unsigned id = 0, pw = 1;
 #pragma unroll
@@ -299,7 +294,7 @@ __global__ __launch_bounds__(256) void k_lut_ids(const uint64_t* __restrict__ ow
             }
             pw *= 3;
         }
-    ids[idx] = (unsigned short)id;
+    ids[idx] = id;
 }
 
 // table[id] = the h2 row k_conv1_h2 writes for a pixel whose neighbourhood is pattern id: the same fmaf sequence (taps in
@@ -344,62 +339,177 @@ __global__ __launch_bounds__(256) void k_lut_build(int C, const float* __restric
 
 // conv2 as a gather-sum (conv1 AND conv2 folded into tables).  With act1[q] = table[id(q)], conv2's pre-activation at
 // pixel p is sum over taps t of W_t . table[id(p + t)] = sum_t T2[t][id(p + t)], where T2[t][id] = W_t . table[id] is a
-// C-vector that depends on the weights only: 9 x 19683 rows of C floats (363 MB at C = 512), built at commit by nine
-// [19683 x C] x [C x C] GEMMs on k_gemm_h2 (same arithmetic as the convolution: fp32 as 2 x fp16, fp32 accumulate).
-// The layer is then 9 row reads + 8 fp32 adds per pixel -- 18 KB of (mostly L2 / MALL resident) table per pixel instead
-// of 4.7 MFLOP: HBM/L2-bound byte work.  One thread per (pixel, 8 channels): a wavefront reads one whole 2 KB row.
-// Taps are added in order t = 0..8 (taps off the board skipped): a fixed order, independent of batch size and position.
-__global__ __launch_bounds__(256) void k_conv2_lut(const unsigned short* __restrict__ ids, const int* __restrict__ d_count, int n, int C,
-                                                   const float* __restrict__ T2 /*[9][OZ_LUT_PATTERNS][C]*/,
-                                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                                   uint4* __restrict__ out, int* __restrict__ flag) {
-    const int cg = C >> 3, P = n * n;
+// C-vector that depends on the weights only: 9 x OZ_LUT_ROWS rows of C floats (363 MB at C = 512; row OZ_LUT_PATTERNS of every
+// tap = zeros), built at commit by nine [19683 x C] x [C x C] GEMMs on k_gemm_h2 (same arithmetic as the convolution: fp32 as
+// 2 x fp16, fp32 accumulate).  The layer is then 9 row reads + 9 fp32 adds per pixel -- 18 KB of (mostly L2 / MALL resident)
+// table per pixel instead of 4.7 MFLOP: byte work.  Taps are added in order t = 0..8 from +0.0: a fixed order, independent of batch
+// size and position; an off-board tap reads the zero row (the accumulator is never -0.0, so adding +0.0 changes no bit).
+// Table layout (round 3): SLICE-major, T2[slice = c / 64][tap][id][64 channels] -- a (tap, id) row of C channels is C / 64 records of
+// 256 B, and all records of one 64-channel slice are contiguous (45 MB at 19684 rows).  At C = 512 there are 8 slices = the 8 XCDs:
+// k_conv2_lut_xcd gives every XCD ONE slice of ALL pixels (workgroup ids go round-robin over the XCDs: slice = blockIdx.x & 7), so
+// the eight private 4 MiB L2s hold eight DIFFERENT eighths of the table instead of eight copies of the same hot rows -- the L2
+// capacity the gather sees is 32 MiB, not 4.  Measured on one device, 3640 mid-game leaves per launch (rocprofv3 --pmc, round 3,
+// profiles/r3_conv2_gather_pmc.csv): whole rows per XCD (the round-2 mapping) 11.7 M L2->fabric read requests (1.5 GB) + 0.50 GB
+// written in 0.39 ms; one slice per XCD 7.1 M requests (0.91 GB) + 0.48 GB written in 0.30 ms -- both ~4.5-5 TB/s of HBM-side
+// traffic, i.e. the launch is bound by the bytes that miss L2 (the 363 MB table cannot live in the 256 MB Infinity Cache), not by
+// instruction issue: a wave-per-pixel variant with 4x fewer VALU instructions (130 against the round-2 kernel's 462) measured the
+// same 0.39 ms as the round-2 kernel, and half-line stores (16 B per lane at a 32-byte stride) inflated the written bytes to
+// 0.83 GB and cancelled the gain until the stores became whole lines.
+#define OZ_C2L_SLICE 64       // channels per slice record (256 B)
+__device__ __forceinline__ size_t t2_record(int slice, int t, unsigned id) {          // float index of record (slice, tap, id)
+    return (((size_t)slice * 9 + t) * OZ_LUT_ROWS + id) * OZ_C2L_SLICE;
+}
+// one output row piece: BN + ReLU of 8 channel sums, then the h2 split (two 16-byte streaming stores) or fp32 (two 16-byte stores)
+template <bool OUT_H2>
+__device__ __forceinline__ bool c2l_finish(const f32x4& lo, const f32x4& hi, const float* __restrict__ scale, const float* __restrict__ shift, int c8,
+                                           void* __restrict__ out, size_t pixel, int C) {
+    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(scale + c8), sc1 = *reinterpret_cast<const f32x4*>(scale + c8 + 4);
+    const f32x4 sh0 = *reinterpret_cast<const f32x4*>(shift + c8), sh1 = *reinterpret_cast<const f32x4*>(shift + c8 + 4);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = fmaxf(fmaf(lo[j], sc0[j], sh0[j]), 0.f);
+        v[j + 4] = fmaxf(fmaf(hi[j], sc1[j], sh1[j]), 0.f);
+    }
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    bool over = false;
+    if constexpr (OUT_H2) {
+        f16x8 h1, h2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            over |= v[j] > H2_F16_MAX;
+            _Float16 a, bb;
+            h2_split(v[j], a, bb);
+            h1[j] = a; h2[j] = bb;
+        }
+        // streaming stores: the 0.5 GB of output would otherwise evict table records from L2 / Infinity Cache
+        v4u* dst = reinterpret_cast<v4u*>(reinterpret_cast<uint4*>(out) + (pixel * (size_t)(C >> 3) + (c8 >> 3)) * 2);
+        __builtin_nontemporal_store(*reinterpret_cast<v4u*>(&h1), dst);
+        __builtin_nontemporal_store(*reinterpret_cast<v4u*>(&h2), dst + 1);
+    } else {
+        float* dst = reinterpret_cast<float*>(out) + pixel * (size_t)C + c8;
+        const f32x4 r0 = {v[0], v[1], v[2], v[3]}, r1 = {v[4], v[5], v[6], v[7]};
+        __builtin_nontemporal_store(r0, reinterpret_cast<f32x4*>(dst));
+        __builtin_nontemporal_store(r1, reinterpret_cast<f32x4*>(dst + 4));
+    }
+    return over;
+}
+
+// C = 512: block b works on slice b & 7 (its XCD's eighth of the table) for pixels [(b >> 3) * 32 * PPT, ...): a wave = 8 pixels x 8 lanes
+// (lane j of a pixel: channels 64 * slice + 8 j .. + 7, two 16-byte loads per tap), OZ_C2L_PPT pixel groups per thread.
+#define OZ_C2L_PPT 2
+template <int N, bool OUT_H2>
+__global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restrict__ ids, const int* __restrict__ d_count,
+                                                       const float* __restrict__ T2, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       void* __restrict__ out, int* __restrict__ flag) {
+    constexpr int P = N * N, W = N + 2, PW = W * W, C = 512;
+    const int slice = blockIdx.x & 7, j = threadIdx.x & 7;
+    const long long total = (long long)(*d_count) * P;
+    // whole 128-byte lines per wave instruction: the 8 lanes of a pixel read 16 B each of line 0 of the record (channels 4 j .. 4 j + 3 of the
+    // slice) and of line 1 (channels 32 + 4 j ..); the stores are whole lines too (h2 output: lane pairs swap halves, below)
+    const int ca = slice * OZ_C2L_SLICE + j * 4, cb = ca + 32;
+    const f32x4 sca = *reinterpret_cast<const f32x4*>(scale + ca), scb = *reinterpret_cast<const f32x4*>(scale + cb);
+    const f32x4 sha = *reinterpret_cast<const f32x4*>(shift + ca), shb = *reinterpret_cast<const f32x4*>(shift + cb);
+    bool over = false;
+#pragma unroll 1
+    for (int k = 0; k < OZ_C2L_PPT; ++k) {
+        const long long pixel = ((long long)(blockIdx.x >> 3) * OZ_C2L_PPT + k) * 32 + (threadIdx.x >> 3);
+        if (pixel >= total) break;
+        const int b = (int)(pixel / P), pix = (int)(pixel - (long long)b * P), y = pix / N, x = pix - y * N;
+        const unsigned* idp = ids + (size_t)b * PW + y * W + x;
+        unsigned id[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) id[t] = idp[(t / 3) * W + t % 3];
+        f32x4 ra[9], rb[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float* rec = T2 + t2_record(slice, t, id[t]) + j * 4;
+            ra[t] = *reinterpret_cast<const f32x4*>(rec);
+            rb[t] = *reinterpret_cast<const f32x4*>(rec + 32);
+        }
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { lo += ra[t]; hi += rb[t]; }
+        f32x4 va, vb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            va[q] = fmaxf(fmaf(lo[q], sca[q], sha[q]), 0.f);
+            vb[q] = fmaxf(fmaf(hi[q], scb[q], shb[q]), 0.f);
+        }
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        if constexpr (OUT_H2) {
+            // group g = j >> 1 of line 0 (and of line 1): lane 2 g holds channels 8 g .. 8 g + 3, lane 2 g + 1 channels 8 g + 4 .. + 7.  The h2
+            // layout wants [h1 x 8][h2 x 8] per group: the even lane sends its h2 halves and receives the partner's h1 halves, so that the even lane
+            // owns the 16-byte h1 chunk and the odd lane the h2 chunk -- 8 lanes x 16 B = one whole 128-byte line per store instruction
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            union Pk { f16x4 h; unsigned u[2]; };
+            Pk h1a, h2a, h1b, h2b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                over |= va[q] > H2_F16_MAX || vb[q] > H2_F16_MAX;
+                _Float16 x1, x2;
+                h2_split(va[q], x1, x2); h1a.h[q] = x1; h2a.h[q] = x2;
+                h2_split(vb[q], x1, x2); h1b.h[q] = x1; h2b.h[q] = x2;
+            }
+            const bool even = (j & 1) == 0;
+            unsigned give[4] = {even ? h2a.u[0] : h1a.u[0], even ? h2a.u[1] : h1a.u[1], even ? h2b.u[0] : h1b.u[0], even ? h2b.u[1] : h1b.u[1]};
+            unsigned got[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) got[q] = (unsigned)__shfl_xor((int)give[q], 1, 64);
+            v4u c0, c1;       // even lane: [own h1 | partner's h1];  odd lane: [partner's h2 | own h2]
+            c0[0] = even ? h1a.u[0] : got[0]; c0[1] = even ? h1a.u[1] : got[1]; c0[2] = even ? got[0] : h2a.u[0]; c0[3] = even ? got[1] : h2a.u[1];
+            c1[0] = even ? h1b.u[0] : got[2]; c1[1] = even ? h1b.u[1] : got[3]; c1[2] = even ? got[2] : h2b.u[0]; c1[3] = even ? got[3] : h2b.u[1];
+            // streaming stores: the 0.5 GB of output would otherwise evict table records from L2 / Infinity Cache
+            v4u* dst = reinterpret_cast<v4u*>(reinterpret_cast<unsigned char*>(out) + (size_t)pixel * (C * 4) + slice * 256 + j * 16);
+            __builtin_nontemporal_store(c0, dst);
+            __builtin_nontemporal_store(c1, dst + 8);
+        } else {
+            float* dst = reinterpret_cast<float*>(out) + (size_t)pixel * C + ca;
+            __builtin_nontemporal_store(va, reinterpret_cast<f32x4*>(dst));
+            __builtin_nontemporal_store(vb, reinterpret_cast<f32x4*>(dst + 32));
+        }
+    }
+    if (OUT_H2 && over) atomicOr(flag, 1);
+}
+
+// any channel count: one thread per (pixel, 8 channels); same sums in the same order
+template <bool OUT_H2>
+__global__ __launch_bounds__(256) void k_conv2_lut(const unsigned* __restrict__ ids, const int* __restrict__ d_count, int n, int C,
+                                                   const float* __restrict__ T2, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   void* __restrict__ out, int* __restrict__ flag) {
+    const int cg = C >> 3, P = n * n, W = n + 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long pixel = idx / cg;
     if (pixel >= (long long)(*d_count) * P) return;
     const int c8 = (int)(idx % cg) * 8;
-    const int pix = (int)(pixel % P), y = pix / n, x = pix % n;
-    const unsigned short* idp = ids + (pixel - pix);
-    // memory-level parallelism: all 9 pattern ids first, then all 18 row loads in flight together, then the sum in tap order
-    // (the straightforward loop compiled to 18 dependent round trips per thread: id, wait, row, wait, add, ...)
+    const int b = (int)(pixel / P), pix = (int)(pixel % P), y = pix / n, x = pix % n;
+    const unsigned* idp = ids + (size_t)b * W * W + y * W + x;
+    // memory-level parallelism: all 9 pattern ids first, then all 18 record loads in flight together, then the sum in tap order
     unsigned id[9];
-    bool ok[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-        ok[t] = iy >= 0 && iy < n && ix >= 0 && ix < n;
-        id[t] = idp[ok[t] ? iy * n + ix : pix];              // off-board taps: the centre's id (a valid address)
-    }
+    for (int t = 0; t < 9; ++t) id[t] = idp[(t / 3) * W + t % 3];
     f32x4 ra[9], rb[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {                            // branch-free: an off-board tap re-reads the centre tap's row (an L1 hit) and is not added
-        const float* row = T2 + ((size_t)(ok[t] ? t : 4) * OZ_LUT_PATTERNS + id[t]) * C + c8;
-        ra[t] = *reinterpret_cast<const f32x4*>(row);
-        rb[t] = *reinterpret_cast<const f32x4*>(row + 4);
+    for (int t = 0; t < 9; ++t) {
+        const float* rec = T2 + t2_record(c8 / OZ_C2L_SLICE, t, id[t]) + (c8 % OZ_C2L_SLICE);
+        ra[t] = *reinterpret_cast<const f32x4*>(rec);
+        rb[t] = *reinterpret_cast<const f32x4*>(rec + 4);
     }
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        lo += ok[t] ? ra[t] : z;
-        hi += ok[t] ? rb[t] : z;
-    }
-    f16x8 h1, h2;
-    bool over = false;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float v = fmaxf(fmaf(j < 4 ? lo[j] : hi[j - 4], scale[c8 + j], shift[c8 + j]), 0.f);
-        over |= v > H2_F16_MAX;
-        _Float16 a, bb;
-        h2_split(v, a, bb);
-        h1[j] = a; h2[j] = bb;
-    }
-    uint4* dst = out + ((size_t)pixel * cg + (c8 >> 3)) * 2;
-    // streaming stores: the 0.5 GB of output would otherwise evict table rows from L2 / Infinity Cache (+1.4 % whole-bench)
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    __builtin_nontemporal_store(*reinterpret_cast<v4u*>(&h1), reinterpret_cast<v4u*>(dst));
-    __builtin_nontemporal_store(*reinterpret_cast<v4u*>(&h2), reinterpret_cast<v4u*>(dst) + 1);
-    if (over) atomicOr(flag, 1);
+    for (int t = 0; t < 9; ++t) { lo += ra[t]; hi += rb[t]; }
+    if (c2l_finish<OUT_H2>(lo, hi, scale, shift, c8, out, (size_t)pixel, C)) atomicOr(flag, 1);
+}
+
+// commit-time re-layout: one tap's GEMM output rows [OZ_LUT_PATTERNS][C] -> the slice-major records of that tap (row OZ_LUT_PATTERNS = zeros)
+__global__ __launch_bounds__(256) void k_t2_to_slices(const float* __restrict__ rows, int C, int t, float* __restrict__ T2) {
+    const long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;          // 4 channels per thread
+    if (idx >= (long long)OZ_LUT_ROWS * C) return;
+    const unsigned id = (unsigned)(idx / C);
+    const int c = (int)(idx % C);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (id < OZ_LUT_PATTERNS) v = *reinterpret_cast<const f32x4*>(rows + idx);
+    *reinterpret_cast<f32x4*>(T2 + t2_record(c / OZ_C2L_SLICE, t, id) + (c % OZ_C2L_SLICE)) = v;
 }
 
 // ---- the same two tables for precision f32 (exact fp32 arithmetic: rows and sums in fp32, T2 built by the fp32 MFMA GEMM)
@@ -420,50 +530,6 @@ __global__ __launch_bounds__(256) void k_lut_build_f32(int C, const float* __res
     }
     table[(size_t)id * C + c] = fmaxf(fmaf(acc, scale[c], shift[c]), 0.f);
 }
-// conv2 = gather-sum over T2 (fp32), BN + ReLU, fp32 rows [pixel][C]
-__global__ __launch_bounds__(256) void k_conv2_lut_f32(const unsigned short* __restrict__ ids, const int* __restrict__ d_count, int n, int C,
-                                                       const float* __restrict__ T2, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, float* __restrict__ out) {
-    const int cg = C >> 3, P = n * n;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long pixel = idx / cg;
-    if (pixel >= (long long)(*d_count) * P) return;
-    const int c8 = (int)(idx % cg) * 8;
-    const int pix = (int)(pixel % P), y = pix / n, x = pix % n;
-    const unsigned short* idp = ids + (pixel - pix);
-    unsigned id[9];
-    bool ok[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-        ok[t] = iy >= 0 && iy < n && ix >= 0 && ix < n;
-        id[t] = idp[ok[t] ? iy * n + ix : pix];
-    }
-    f32x4 ra[9], rb[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float* row = T2 + ((size_t)(ok[t] ? t : 4) * OZ_LUT_PATTERNS + id[t]) * C + c8;
-        ra[t] = *reinterpret_cast<const f32x4*>(row);
-        rb[t] = *reinterpret_cast<const f32x4*>(row + 4);
-    }
-    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        lo += ok[t] ? ra[t] : z;
-        hi += ok[t] ? rb[t] : z;
-    }
-    f32x4 r0, r1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r0[j] = fmaxf(fmaf(lo[j], scale[c8 + j], shift[c8 + j]), 0.f);
-        r1[j] = fmaxf(fmaf(hi[j], scale[c8 + 4 + j], shift[c8 + 4 + j]), 0.f);
-    }
-    float* dst = out + (size_t)pixel * C + c8;
-    __builtin_nontemporal_store(r0, reinterpret_cast<f32x4*>(dst));
-    __builtin_nontemporal_store(r1, reinterpret_cast<f32x4*>(dst + 4));
-}
-
 // out[M][N] = act((A[M][K] . W[N][K]^T) * scale + shift); A and W in the h2 layout; M = *d_count * Hout^2.
 // CF::LUT: `in` is the pattern table, lut_ids the per-pixel pattern ids [batch][Hin^2] (k_lut_ids).
 // zero_line: >= 128 B of zeros in global memory (source of out-of-image taps and of rows beyond M).
@@ -472,7 +538,7 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        void* __restrict__ out, const int* __restrict__ d_count, H2Geom g,
                                                        int num_mt, const uint4* __restrict__ zero_line, int* __restrict__ flag,
-                                                       const unsigned short* __restrict__ lut_ids) {
+                                                       const unsigned* __restrict__ lut_ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = CF::BM, BN = CF::BN, IA = CF::IA, IB = CF::IB;
     constexpr int RI = CF::TI * 2, RJ = CF::TJ * 2;           // 16-row / 16-column MFMA tiles per wave
@@ -499,8 +565,7 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     // (192-row tile: 3 A pieces per wave -- piece 0 early, piece 2 late, piece 1 early for waves 0-3 and late for waves 4-7)
     auto a_late = [&](int i) -> int { return IA == 4 ? (i >> 1) : (i == 0 ? 0 : i == 2 ? 1 : (wave >= 4 ? 1 : 0)); };
     auto a_row0 = [&](int i) -> int {
-        if constexpr (CF::PP3) return (wave >> 2) * (BM / 2) + i * (BM / 6) + (wave & 3) * 8;    // piece i = third i of both wave rows
-        else if constexpr (!CF::PP) return (wave * IA + i) * 8;
+        if constexpr (!CF::PP) return (wave * IA + i) * 8;
         else {
             constexpr int HR = BM / 4, HBLK = HR / 8;            // rows / 8-row blocks in one half of a wave row
             const int hb = IA == 4 ? 2 * wave + (i & 1) : (i == 1 ? 8 + (wave & 3) : wave);
@@ -522,9 +587,9 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
             const int tap = e / BM, row = e - tap * BM;
             const long long m = (long long)mt * BM + row;
             unsigned id = OZ_LUT_PATTERNS;
-            if (m < M) {
-                const int b = (int)(m / P), pix = (int)(m % P), iy = pix / g.Hout - g.pad + tap / 3, ix = pix % g.Hout - g.pad + tap % 3;
-                if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Hin) id = lut_ids[(size_t)b * g.Hin * g.Hin + iy * g.Hin + ix];
+            if (m < M) {         // padded id boards (k_lut_ids): cell (iy + 1, ix + 1), the border = the zero row
+                const int b = (int)(m / P), pix = (int)(m % P), iy = pix / g.Hout - g.pad + tap / 3, ix = pix % g.Hout - g.pad + tap % 3, Wp = g.Hin + 2;
+                id = lut_ids[(size_t)b * Wp * Wp + (iy + 1) * Wp + ix + 1];
             }
             lut[e] = (unsigned short)id;
         }
@@ -567,9 +632,6 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         const long long toff = ((long long)(tap / 3) * g.Hin + (tap % 3)) * rowq + slice * 8;    // 32 ch = 8 uint4
         unsigned char* la = smem + (size_t)buf * CF::BUF;
         unsigned char* lb = smem + (size_t)buf * CF::BUF + CF::TILEA;
-#ifdef H2_EXP_TAP0                        // timing experiment only (wrong results): A staged for tap 0 only = upper bound of tap reuse
-        if (tap == 0)
-#endif
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             const uint4* ga;
@@ -596,106 +658,6 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     const int swz = h2_swz(r16);                             // tile bases are multiples of 16 rows
     const int oh1 = ((2 * kg) ^ swz) * 16, oh2 = ((2 * kg + 1) ^ swz) * 16;
 
-    if constexpr (CF::PP3) {
-        // ---- 3-phase ping-pong main loop for the 192 x 256 tile (8 waves = 2 wave rows x 4 wave columns, wave tile 96 x 64).
-        // MEASURED: bit-identical to the other loops, conv3 1.320 -> 1.305 / 1.319 ms at 4096 leaves (0 .. +1 %): the layer is
-        // clock / power bound, not load-section bound.  Kept as an option (OZ_H2_PP3=1), the 4-phase loop stays the default.
-        // The 4-phase loop gives this tile 18-MFMA clusters, shorter than the load section they are meant to cover; here
-        // a k-tile is three thirds of the A rows (2 x 16 rows each) times ALL four B blocks = 24 MFMAs per phase:
-        //   phase q: L section: ds_read A third q (4 reads; phase 1 also the tile's 8 B reads), LDS-DMA pieces, counted
-        //            s_waitcnt vmcnt, s_barrier;  M section: lgkmcnt(0), 24 MFMAs, s_barrier.
-        // Wave row 1 runs one barrier behind wave row 0 (as in the 4-phase loop).  Phases are numbered Q = 3 * tile + q.
-        //   visibility: a piece read in L_Q is retired (vmcnt) by every issuing wave in L_{Q-1} or earlier;
-        //   reuse:      a region read in L_Q is DMA-overwritten from L_{Q+2} on (row 1's reads of L_Q finish before the
-        //               barrier that opens row 0's L_{Q+2}).
-        // Per wave and tile k: L1 issues A third 1 of tile k+1, B pieces 2,3 of tile k+1; L2: A third 2 of k+1;
-        // L3: A third 3 of k+1 and B pieces 0,1 of tile k+2 (into the buffer whose B was read in L1 of tile k).
-        // Every piece is issued two phases before the vmcnt that retires it; in-order retirement gives vmcnt(6), (6), (4).
-        static_assert(IA == 3 && IB == 4 && RI == 6 && RJ == 4, "3-phase loop: 192 x 256 tile, 8 waves");
-        stage(kbeg, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        f16x8 fa1[2], fa2[2], fb1[4], fb2[4];
-        int kt1 = kbeg + 1 < nk ? kbeg + 1 : nk - 1;         // tile k+1 (past the end: the last tile again)
-        int kt2 = kt1 + 1 < nk ? kt1 + 1 : nk - 1;           // tile k+2
-        int slice1 = kt1 / g.taps, tap1 = kt1 - slice1 * g.taps;
-        auto dma_b_to = [&](int i, int ktile, int bufi) {
-            unsigned char* lb = smem + (size_t)bufi * CF::BUF + CF::TILEA;
-            __builtin_amdgcn_global_load_lds((h2_gptr)(Wh + bidx[i] + ktile * 8), (h2_lptr)(lb + b_row0(i) * 128), 16, 0, 0);
-        };
-        dma_b_to(0, kt1, 1); dma_b_to(1, kt1, 1);            // what L3 of the tile before the first would have issued
-        if (wm == 1) __builtin_amdgcn_s_barrier();           // stagger: wave row 1 is one barrier behind
-        for (int kt = kbeg; kt < nk; ++kt) {
-            const int buf = (kt - kbeg) & 1;
-            const int dy = (tap1 * 11) >> 5, dx = tap1 - 3 * dy;
-            const long long toff = ((long long)dy * g.Hin + dx) * rowq + slice1 * 8;
-            const int tapn = tap1, k1 = kt1, k2 = kt2;
-            unsigned char* la = smem + (size_t)(buf ^ 1) * CF::BUF;
-            const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * RI * 16 + r16) * 128;
-            const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
-            auto dma_a = [&](int i) {
-                const uint4* ga = ((amask[i] >> tapn) & 1) ? in + (aidx[i] + toff) : zsrc;
-                __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la + a_row0(i) * 128), 16, 0, 0);
-            };
-            auto lda = [&](int third) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    fa1[i] = *reinterpret_cast<const f16x8*>(At + (third * 2 + i) * 16 * 128 + oh1);
-                    fa2[i] = *reinterpret_cast<const f16x8*>(At + (third * 2 + i) * 16 * 128 + oh2);
-                }
-            };
-            auto l_end = [&](auto keep) {
-                constexpr int K = decltype(keep)::value;
-                if constexpr (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            auto mma = [&](int third) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f32x4v& c = acc[third * 2 + i][j];
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? fa2[i] : fa1[i], p == 1 ? fb2[j] : fb1[j], c, 0, 0, 0);
-                        }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            auto m_end = [&]() {
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            using std::integral_constant;
-            // phase 1
-            lda(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                fb1[j] = *reinterpret_cast<const f16x8*>(Bt + j * 16 * 128 + oh1);
-                fb2[j] = *reinterpret_cast<const f16x8*>(Bt + j * 16 * 128 + oh2);
-            }
-            dma_a(0); dma_b_to(2, k1, buf ^ 1); dma_b_to(3, k1, buf ^ 1);
-            l_end(integral_constant<int, 6>{}); mma(0); m_end();
-            // phase 2
-            lda(1); dma_a(1);
-            l_end(integral_constant<int, 6>{}); mma(1); m_end();
-            // phase 3
-            lda(2); dma_a(2); dma_b_to(0, k2, buf); dma_b_to(1, k2, buf);
-            l_end(integral_constant<int, 4>{}); mma(2); m_end();
-            // advance (k+1, k+2) incrementally: no integer division in the loop
-            if (kt1 + 1 < nk) { ++kt1; if (++tap1 == g.taps) { tap1 = 0; ++slice1; } }
-            kt2 = kt1 + 1 < nk ? kt1 + 1 : nk - 1;
-        }
-        if (wm == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave rows
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every piece has landed before the epilogue reuses the LDS
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    } else
     if constexpr (CF::PP) {
         // ---- 4-phase ping-pong main loop (block 256 x 256, 8 waves = 2 wave rows x 4 wave columns).
         // A k-tile is processed as four quadrants of the 128 x 64 wave tile, (m0,n0) (m0,n1) (m1,n0) (m1,n1); phase q =
@@ -735,10 +697,6 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         // (slice, tap) of the tile being staged, advanced incrementally: no integer division in the loop
         int ktn = kbeg + 1 < nk ? kbeg + 1 : nk - 1;
         int slice_n = ktn / g.taps, tap_n = ktn - slice_n * g.taps;
-#ifdef H2PP_STAMPS
-        unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
-        const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_t0 = st_prev;
-#endif
         for (int kt = kbeg; kt < nk; ++kt) {
             const int buf = (kt - kbeg) & 1;
             const int slice = slice_n, tap = tap_n, dy = (tap * 11) >> 5, dx = tap - 3 * dy;            // tap / 3, tap % 3 for tap < 9
@@ -781,7 +739,6 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
             const unsigned char* Btn = smem + (size_t)(buf ^ 1) * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
             // end of an L section: all but the `keep` youngest DMA pieces of this wave have landed, then the barrier
             auto l_end = [&](auto keep) {
-                H2_ST(0);                                    // L work: address arithmetic, ds_read issue, DMA issue
                 constexpr int K = decltype(keep)::value;
                 if constexpr (K == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 else if constexpr (K == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -789,11 +746,8 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                 else if constexpr (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else if constexpr (K == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                H2_ST(1);                                    // DMA wait
                 __builtin_amdgcn_s_barrier();
-                H2_ST(2);                                    // mid barrier
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                H2_ST(3);                                    // LDS read latency left
                 __builtin_amdgcn_sched_barrier(0);
             };
             // quadrant (m half, n half): 3 * 2 * HA MFMAs, product-major (2 * HA independent accumulators between two
@@ -812,42 +766,20 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
             };
             auto m_end = [&]() {                             // end of an M section: the closing barrier
                 asm volatile("" ::: "memory");
-                H2_ST(4);                                    // MFMA cluster (issue)
                 __builtin_amdgcn_s_barrier();
-                H2_ST(5);                                    // closing barrier
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             };
             using std::integral_constant;
             auto dma_a_early = [&]() { dma_a(0); if (IA == 4 || wave < 4) dma_a(1); };
             auto dma_a_late = [&]() { dma_a(IA - 1); if (IA == 4) dma_a(2); else if (wave >= 4) dma_a(1); };
-#if defined(H2PP_NODMA)                   // timing experiment only (wrong results): the loop without any DMA
-            lda(0); l_end(integral_constant<int, 4>{}); mma(0, 0); m_end(); ldb(1, Bt); l_end(integral_constant<int, 4>{}); mma(0, 1); m_end();
-            lda(1); l_end(integral_constant<int, 4>{}); mma(1, 0); m_end(); ldb(0, Btn); l_end(integral_constant<int, 4>{}); mma(1, 1); m_end();
-#elif defined(H2PP_2PHASE)
-            // two phases per k-tile (half the barriers): L_A reads A m0, B n1 (B n0 came in L_B of the tile before) and issues
-            // the 6 (5) pieces of the next tile that its L_A / L_B read first; L_B reads A m1 and the next tile's B n0 ...
-            lda(0); ldb(1, Bt); dma_b(0); dma_b(1); dma_a_early(); dma_b(2); dma_b(3);
-            l_end(integral_constant<int, IA == 4 ? 6 : 5>{}); mma(0, 0); mma(0, 1); m_end();
-            lda(1); dma_a_late();
-            l_end(integral_constant<int, IA == 4 ? 2 : 1>{}); mma(1, 0); mma(1, 1); m_end();
-            ldb(0, Btn);                                     // after M_B: quadrant (m1, n0) is done; retired by the vmcnt of L_B
-#else
             constexpr int KEEP = IA == 4 ? 4 : 3;
             lda(0); ld_ids(); dma_b(0); dma_b(1); l_end(integral_constant<int, KEEP>{}); mma(0, 0); m_end();     // phase 1
             ldb(1, Bt); dma_a_early(); l_end(integral_constant<int, KEEP>{}); mma(0, 1); m_end();                // phase 2
             lda(1); dma_b(2); dma_b(3); l_end(integral_constant<int, KEEP>{}); mma(1, 0); m_end();               // phase 3
             ldb(0, Btn); dma_a_late(); l_end(integral_constant<int, KEEP>{}); mma(1, 1); m_end();                // phase 4 (B n0 of the next tile)
-#endif
             if (ktn + 1 < nk) { ++ktn; if (++tap_n == g.taps) { tap_n = 0; ++slice_n; } }    // past the end: re-stage the last tile
         }
-#ifdef H2PP_STAMPS
-        if (blockIdx.x == 0 && lane == 0) {
-            for (int q = 0; q < 6; ++q) g_h2_stamps[wave][q] = st_acc[q];
-            g_h2_clk[wave][0] = __builtin_amdgcn_s_memtime() - st_t0;
-            g_h2_clk[wave][1] = __builtin_amdgcn_s_memrealtime() - st_rt0;      // 100 MHz ticks
-        }
-#endif
         if (wm == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave rows
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every piece has landed before the epilogue reuses the LDS
         __builtin_amdgcn_s_barrier();
@@ -871,9 +803,7 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
             asm volatile("" ::: "memory");
             stage(kt + S - 1, (kt - kbeg + S - 1) % S);
         } else {
-#ifndef H2_EXP_NODMA                      // H2_EXP_* : timing experiments only (wrong results), see tools/build_variant.sh
         stage(kt + 1, buf ^ 1);
-#endif
         }
         const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * RI * 16 + r16) * 128;
         const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
@@ -903,9 +833,7 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
             }
         }
         if constexpr (S == 2) {
-#ifndef H2_EXP_NOBARRIER
         __syncthreads();
-#endif
         }
     }
     if constexpr (S > 2) {                                   // the re-staged tail tiles have landed before the epilogue reuses the LDS

@@ -547,7 +547,7 @@ static int mcts_create(oz_mcts** out, int n, int G, int node_cap, int edge_cap, 
     if (!rc) rc = m->alloc(&m->rc_legal, (size_t)G);
     if (!rc) rc = m->alloc(&m->rc_rc, (size_t)G);
     d.batch_cap = 0; d.batch_rot = 0;
-    { const char* e = getenv("OZ_DEDUP"); d.dedup = !(e && atoi(e) == 0); }      // OZ_DEDUP=0: one evaluation per game and step (A/B runs, tests)
+    d.dedup = 1;               // cross-game leaf de-duplication (oz_mcts_set_dedup / oz_selfplay_config.dedup switch it off)
     if (!rc && hipStreamCreate(&m->stream) != hipSuccess) { oz_set_error("hipStreamCreate failed"); rc = OZ_ERR_HIP; }
     if (!rc) {
         hipMemsetAsync(d.stat, 0, sizeof(unsigned long long) * (size_t)G * OZ_NSTAT, m->stream);
@@ -605,7 +605,7 @@ static int mcts_step_async(oz_mcts* m, oz_net* net, bool time_eval) {
     MctsDev& d = m->d;
     hipStream_t s = m->stream;
     const bool all = m->profile;
-    int i = all ? m->timer.begin(TS_SELECT, s) : -1;
+    long long i = all ? m->timer.begin(TS_SELECT, s) : -1;
     hipLaunchKernelGGL(k_select, dim3(d.G), dim3(64), 0, s, d);
     m->timer.end(i, s);
     i = all ? m->timer.begin(TS_COMPACT, s) : -1;
@@ -627,11 +627,10 @@ static int mcts_collect_eval_time(oz_mcts* m) {
 }
 
 // `nsims` lock-step simulations: descent | compaction | evaluator, then per further simulation the previous one's expand + backup
-// fused with the next descent (k_backup_select), and one closing expand + backup: nsims + 1 tree launches instead of 2 nsims.
-// OZ_FUSE_STEP=0 launches the two kernels separately (A/B runs); results are identical either way.
+// fused with the next descent (k_backup_select), and one closing expand + backup: nsims + 1 tree launches instead of 2 nsims
+// (results are identical to the unfused sequence, which a single step still uses).
 static int mcts_steps_async(oz_mcts* m, oz_net* net, int nsims, bool time_eval) {
-    static const bool fuse = !(getenv("OZ_FUSE_STEP") && atoi(getenv("OZ_FUSE_STEP")) == 0);
-    if (!fuse || nsims < 2) {
+    if (nsims < 2) {
         for (int i = 0; i < nsims; ++i)
             if (int rc = mcts_step_async(m, net, time_eval)) return rc;
         return OZ_OK;
@@ -640,7 +639,7 @@ static int mcts_steps_async(oz_mcts* m, oz_net* net, int nsims, bool time_eval) 
     hipStream_t s = m->stream;
     const bool all = m->profile;
     for (int k = 0; k < nsims; ++k) {
-        int i = all ? m->timer.begin(TS_SELECT, s) : -1;
+        long long i = all ? m->timer.begin(TS_SELECT, s) : -1;
         if (k == 0) hipLaunchKernelGGL(k_select, dim3(d.G), dim3(64), 0, s, d);
         else hipLaunchKernelGGL(k_backup_select, dim3(d.G), dim3(64), 0, s, d);
         m->timer.end(i, s);
@@ -651,7 +650,7 @@ static int mcts_steps_async(oz_mcts* m, oz_net* net, int nsims, bool time_eval) 
         if (int rc = oz_net_forward_device(net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, s)) { m->timer.cancel(i); return rc; }
         m->timer.end(i, s);
     }
-    const int i = all ? m->timer.begin(TS_BACKUP, s) : -1;
+    const long long i = all ? m->timer.begin(TS_BACKUP, s) : -1;
     hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, s, d, 0);
     m->timer.end(i, s);
     OZ_HIP(hipGetLastError());
@@ -663,6 +662,13 @@ OZ_API int oz_mcts_create(oz_mcts** out, int n, int num_games, int node_cap, int
     return mcts_create(out, n, num_games, node_cap, edge_cap, c, q_mode);
 }
 OZ_API int oz_mcts_destroy(oz_mcts* m) { mcts_destroy(m); return OZ_OK; }
+
+OZ_API int oz_mcts_set_dedup(oz_mcts* m, int enable) {
+    OZ_REQUIRE(m, "null mcts");
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->d.dedup = enable ? 1 : 0;                          // takes effect at the next leaf compaction (kernels get the struct by value)
+    return OZ_OK;
+}
 
 OZ_API int oz_mcts_reset(oz_mcts* m, int game) {
     OZ_REQUIRE(m, "null mcts");
@@ -988,7 +994,7 @@ __global__ __launch_bounds__(64) void k_sp_move(GamesDev gm, MctsDev t, int aren
 // can run many network-free simulations); a game that hits the cap simply contributes no leaf to this batch.  The launch lasts
 // as long as its slowest wave, so the cap trades batch fill for launch time -- measured at 4096 games x 100 simulations
 // (bench.py --driver free): cap 24 -> 4081 leaves per batch but 367 us per launch, 1.40 M expansions/s; cap 8 -> 1.56 M;
-// cap 4 -> 1.585 M; cap 2 -> 3908 leaves per batch, 1.59 M (1.60 M with k_backup_advance; the lock-step driver: 1.56-1.58 M).  env OZ_ADVANCE_CAP overrides.
+// cap 4 -> 1.585 M; cap 2 -> 3908 leaves per batch, 1.59 M (1.60 M with k_backup_advance; the lock-step driver: 1.56-1.58 M).
 #define OZ_ADVANCE_CAP 2
 __device__ __forceinline__ void advance_body(const GamesDev& gm, const MctsDev& t, TreeLds& L, int g, int lane, int sims, int* __restrict__ sims_done, int cap) {
     if (unii(t.leaf_status[g]) == OZ_LEAF_WAIT) {          // batch cap: the leaf of the simulation in progress found no slot -- offer it again, unchanged
@@ -1128,6 +1134,8 @@ OZ_API int oz_selfplay_create(oz_selfplay** out, const oz_selfplay_config* cfg, 
     OZ_REQUIRE(cfg->num_games > 0, "num_games must be positive");
     OZ_REQUIRE(net->n == cfg->n, "network board size %d != %d", net->n, cfg->n);
     OZ_REQUIRE(net->max_batch >= cfg->num_games, "network max_batch %d < num_games %d", net->max_batch, cfg->num_games);
+    OZ_REQUIRE(cfg->dedup == OZ_DEDUP_DEFAULT || cfg->dedup == OZ_DEDUP_ON || cfg->dedup == OZ_DEDUP_OFF, "oz_selfplay_config.dedup = %d", cfg->dedup);
+    OZ_REQUIRE(cfg->batch_cap == 0 || cfg->batch_cap >= 8, "oz_selfplay_config.batch_cap = %d (0 = none, else >= 8 leaves)", cfg->batch_cap);
     oz_selfplay* sp = new oz_selfplay();
     sp->cfg = *cfg; sp->net = net;
     const int max_plies = cfg->n * cfg->n - 4;
@@ -1136,6 +1144,8 @@ OZ_API int oz_selfplay_create(oz_selfplay** out, const oz_selfplay_config* cfg, 
     const long long rcap = cfg->record_cap > 0 ? cfg->record_cap : (long long)cfg->num_games * 64 * 4;
     int rc = mcts_create(&sp->m, cfg->n, cfg->num_games, node_cap, edge_cap, cfg->c, cfg->q_mode);
     if (!rc) rc = games_alloc(sp, cfg->num_games, cfg->n, rcap);
+    if (!rc) sp->m->d.dedup = cfg->dedup == OZ_DEDUP_OFF ? 0 : 1;
+    if (!rc) sp->batch_cap = cfg->batch_cap;
     if (!rc) rc = sp->alloc(&sp->d_sims_done, cfg->num_games);
     if (!rc && hipMemset(sp->d_sims_done, 0, sizeof(int) * cfg->num_games) != hipSuccess) rc = OZ_ERR_HIP;
     if (!rc) {
@@ -1169,7 +1179,7 @@ static int selfplay_round_async(oz_selfplay* sp, int sims, int stagger_round) {
     oz_mcts* m = sp->m;
     const int G = sp->gm.G;
     hipStream_t s = m->stream;
-    int ti = m->profile ? m->timer.begin(TS_MOVE, s) : -1;
+    long long ti = m->profile ? m->timer.begin(TS_MOVE, s) : -1;
     if (stagger_round >= 0) hipLaunchKernelGGL(k_sp_roots_stagger, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, m->d, stagger_round, sp->stagger_period);
     else hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, m->d, 0);
     m->timer.end(ti, s);
@@ -1178,7 +1188,7 @@ static int selfplay_round_async(oz_selfplay* sp, int sims, int stagger_round) {
     hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, m->d, 0);
     m->timer.end(ti, s);
     OZ_HIP(hipGetLastError());
-    if (m->timer.backlog() > 8192) { if (int rc = mcts_collect_eval_time(m)) return rc; }
+    if (m->timer.backlog() > 4096) m->timer.drain();      // completed pairs only: never a host stall inside the enqueue loop
     return OZ_OK;
 }
 
@@ -1244,15 +1254,14 @@ OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
     MctsDev& d = m->d;
     if (sp->mode == 1) OZ_HIP(hipMemsetAsync(d.leaf_status, 0, sizeof(int) * d.G, m->stream));    // no simulation is pending after whole rounds
     sp->mode = 2;
-    static const bool fuse = !(getenv("OZ_FUSE_STEP") && atoi(getenv("OZ_FUSE_STEP")) == 0);
+    const bool fuse = true;
     for (int i = 0; i < steps; ++i) {
         const bool all = m->profile;
         hipStream_t s = m->stream;
-        int ti = all ? m->timer.begin(TS_SELECT, s) : -1;
-        static const int adv_env = getenv("OZ_ADVANCE_CAP") && atoi(getenv("OZ_ADVANCE_CAP")) > 0 ? atoi(getenv("OZ_ADVANCE_CAP")) : 0;     // A/B runs
+        long long ti = all ? m->timer.begin(TS_SELECT, s) : -1;
         // under a batch cap the leaves on offer exceed the slots anyway (waiting games re-offer theirs), so one descent per game and call is
         // enough to keep the batches full and the launch is as short as the lock-step one (measured: +1.2 % expansions/s, +3 % games/s over 2)
-        const int adv_cap = adv_env ? adv_env : (sp->batch_cap > 0 && sp->batch_cap < d.G ? 1 : OZ_ADVANCE_CAP);
+        const int adv_cap = (sp->batch_cap > 0 && sp->batch_cap < d.G ? 1 : OZ_ADVANCE_CAP);
         // (from the second batch of a call on, the previous batch's expand + backup rides in the same launch; one closing k_expand_backup per call)
         if (fuse && i > 0) hipLaunchKernelGGL(k_backup_advance, dim3(d.G), dim3(64), 0, s, sp->gm, d, sp->cfg.sims, sp->d_sims_done, adv_cap);
         else hipLaunchKernelGGL(k_advance, dim3(d.G), dim3(64), 0, s, sp->gm, d, sp->cfg.sims, sp->d_sims_done, adv_cap);
@@ -1275,7 +1284,7 @@ OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
             m->timer.end(ti, s);
         }
         OZ_HIP(hipGetLastError());
-        if (m->timer.backlog() > 8192) { if (int rc = mcts_collect_eval_time(m)) return rc; }
+        if (m->timer.backlog() > 4096) m->timer.drain();      // completed pairs only: never a host stall inside the enqueue loop
     }
     return OZ_OK;
 }
@@ -1286,6 +1295,13 @@ OZ_API int oz_selfplay_set_batch_cap(oz_selfplay* sp, int cap) {
     OZ_REQUIRE(cap >= 0, "oz_selfplay_set_batch_cap: cap %d", cap);
     OZ_REQUIRE(cap == 0 || cap >= 8, "oz_selfplay_set_batch_cap: a cap below 8 leaves (got %d)", cap);
     sp->batch_cap = cap;
+    return OZ_OK;
+}
+
+OZ_API int oz_selfplay_set_dedup(oz_selfplay* sp, int enable) {
+    OZ_REQUIRE(sp, "null selfplay");
+    std::lock_guard<std::mutex> lk(sp->mu);
+    sp->m->d.dedup = enable ? 1 : 0;
     return OZ_OK;
 }
 
@@ -1463,8 +1479,20 @@ OZ_API int oz_arena_destroy(oz_arena* a) {
     return OZ_OK;
 }
 
-OZ_API int oz_arena_run(oz_arena* a) {
+OZ_API int oz_arena_run(oz_arena* a) { return oz_arena_run_rounds(a, 0); }
+
+// counters of the two agents' searches since creation (layout of oz_mcts_stats); a RandomOthelloAgent side reads zeros
+OZ_API int oz_arena_stats(oz_arena* a, int64_t* black5, int64_t* white5) {
+    OZ_REQUIRE(a && black5 && white5, "null argument");
+    std::lock_guard<std::mutex> lk(a->mu);
+    hipSetDevice(a->games.m->device);
+    if (int rc = mcts_stats_locked(a->games.m, black5)) return rc;
+    return mcts_stats_locked(a->mb, white5);
+}
+
+OZ_API int oz_arena_run_rounds(oz_arena* a, int max_rounds_arg) {
     OZ_REQUIRE(a, "null arena");
+    OZ_REQUIRE(max_rounds_arg >= 0, "oz_arena_run_rounds: max_rounds %d", max_rounds_arg);
     std::lock_guard<std::mutex> lk(a->mu);
     oz_selfplay* sp = &a->games;
     oz_mcts *ma = sp->m, *mb = a->mb;
@@ -1474,7 +1502,8 @@ OZ_API int oz_arena_run(oz_arena* a) {
     hipStream_t sb_saved = mb->stream;
     mb->stream = s;
     int rc = OZ_OK;
-    const int max_rounds = sp->gm.n * sp->gm.n;      // every round plays one ply in every live game
+    // every round plays one ply in every live game (two where a RandomOthelloAgent side moves first); n*n rounds end every game
+    const int max_rounds = max_rounds_arg > 0 && max_rounds_arg < sp->gm.n * sp->gm.n ? max_rounds_arg : sp->gm.n * sp->gm.n;
     std::vector<uint8_t> fin(G);
     for (int round = 0; round < max_rounds && !rc; ++round) {
         // BLACK movers search in agent A's tables with net A, WHITE movers in agent B's with net B

@@ -573,13 +573,19 @@ __global__ __launch_bounds__(256) void k_t_absmax(AbsMaxArgs a, unsigned* __rest
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n[l]; i += (long long)gridDim.x * 1024) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
         m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        if (v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3]) m = INFINITY;         // fmaxf drops NaNs: a NaN weight must not pass as finite
     }
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(out + l, __float_as_uint(m));
 }
+// power-of-two exponent that brings a tensor whose |maximum| has bit pattern max_bits to ~target; a non-finite maximum (a diverged
+// step) gives exponent 0 and t_bad_max() -- the converting kernels raise the sticky flag (bit 2) so that the step fails loudly
+__device__ __forceinline__ bool t_bad_max(unsigned max_bits) { return !(__uint_as_float(max_bits) <= 3.402823466e38f); }      // Inf or NaN
 __device__ __forceinline__ int t_exp_for(unsigned max_bits, float target) {
     const float mx = __uint_as_float(max_bits);
-    return mx > 0.f ? (int)floorf(log2f(target / mx)) : 0;
+    if (!(mx > 0.f) || t_bad_max(max_bits)) return 0;
+    const int e = (int)floorf(log2f(target / mx));
+    return e < -120 ? -120 : e > 120 ? 120 : e;
 }
 __device__ __forceinline__ void t_store_h2(uint4* dst, const float* v) {
     t_f16x8 h1, h2;
@@ -596,7 +602,7 @@ __device__ __forceinline__ void t_store_h2(uint4* dst, const float* v) {
 // scale_out[n] = 2^-kexp (forward only).  One thread per (row, group of 8 k').
 template <int DGRAD>
 __global__ __launch_bounds__(256) void k_t_w_to_h2(const float* __restrict__ W, int Cin, int Cout, const unsigned* __restrict__ wmax,
-                                                   uint4* __restrict__ out, float* __restrict__ scale_out) {
+                                                   uint4* __restrict__ out, float* __restrict__ scale_out, int* __restrict__ flag) {
     const int N = DGRAD ? Cin : Cout, Cch = DGRAD ? Cout : Cin, ng = 9 * Cch / 8;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int nrow, grp;
@@ -604,6 +610,7 @@ __global__ __launch_bounds__(256) void k_t_w_to_h2(const float* __restrict__ W, 
     else { nrow = (int)(idx % N); grp = (int)(idx / N); }
     if (idx >= (long long)N * ng) return;
     const int kexp = t_exp_for(*wmax, 1000.0f);
+    if (idx == 0 && t_bad_max(*wmax)) atomicOr(flag, 2);
     const int kp = grp * 8, tile = kp >> 5, c32 = kp & 31, slice = tile / 9, tap = tile - slice * 9, ch = slice * 32 + c32;
     float v[8];
     if (DGRAD) {
@@ -636,10 +643,11 @@ __global__ __launch_bounds__(256) void k_t_act_to_h2(const float* __restrict__ a
 // from the tensor's maximum (dzmax, left by the BN backward); dscale[c] = 2^-(ez + kexp of the data-gradient weights)
 __global__ __launch_bounds__(256) void k_t_dz_to_h2(const float* __restrict__ dz, const int* __restrict__ d_count, int Hout, int Hz, int zoff, int C,
                                                     const unsigned* __restrict__ dzmax, const unsigned* __restrict__ wmax,
-                                                    uint4* __restrict__ out, float* __restrict__ dscale, int ncols) {
+                                                    uint4* __restrict__ out, float* __restrict__ dscale, int ncols, int* __restrict__ flag) {
     const int cg = C >> 3, P = Hout * Hout;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, m = idx / cg;
     const int ez = t_exp_for(*dzmax, 8192.0f);
+    if (idx == 0 && (t_bad_max(*dzmax) || t_bad_max(*wmax))) atomicOr(flag, 2);
     if (idx < ncols) dscale[idx] = ldexpf(1.0f, -(ez + t_exp_for(*wmax, 1000.0f)));
     if (m >= (long long)(*d_count) * P) return;
     const int g8 = (int)(idx % cg), b = (int)(m / P), pix = (int)(m % P);
@@ -696,7 +704,7 @@ struct oz_trainer {
     unsigned *wmax = nullptr, *dzmax = nullptr;          // [3] max |w| of conv2..4, [6] max |dz| per layer (bit patterns)
     int* h2flag = nullptr;
     float* bnb2[6] = {};                 // per-layer row-block partials of the bias gradient (mid-size BN backward)
-    bool overlap = true;                 // env OZ_TRAIN_OVERLAP=0: weight gradients on the main stream
+    bool overlap = true;                 // weight gradients on the second stream beside the data-gradient chain (false: all on the main stream)
     long long gpartial_floats = 40LL << 20;      // 160 MB each: 16 row-split slabs of a 3x3 x 512 x 512 weight gradient
     bool wconv_attr = false;
     // HBM-resident data set of a fit (oz_trainer_set_dataset / oz_trainer_fit_epoch)
@@ -705,7 +713,7 @@ struct oz_trainer {
     int* ds_order = nullptr;
     double* ds_acc = nullptr;
     int64_t ds_n = 0, ds_cap = 0;
-    int split_mask = 7;                  // diagnostic (env OZ_TRAIN_SPLIT_MASK): 1 forward, 2 dense dgrad, 4 conv dgrad GEMMs may split K
+    int split_mask = 7;                  // 1 forward, 2 dense dgrad, 4 conv dgrad GEMMs may split K
     int P_[6], Co[6], Hout[6], Hz[6], zoff[6];
     std::vector<void*> allocs;
     bool dirty = true;                   // derived operands need a refresh
@@ -765,7 +773,6 @@ OZ_API int oz_trainer_create(oz_trainer** out, int n, int channels, int in_chann
     oz_trainer* t = new oz_trainer();
     t->n = n; t->C = channels; t->cin = in_channels; t->Bmax = max_batch; t->lr = lr; t->clip = clipvalue; t->rate = dropout;
     t->mom = bn_momentum; t->seed = seed; t->device = oz_current_device();
-    if (const char* e = getenv("OZ_TRAIN_SPLIT_MASK")) t->split_mask = atoi(e);
     auto fail = [&](int rc) { delete t; return rc; };
     if (hipSetDevice(t->device) != hipSuccess || hipStreamCreate(&t->s) != hipSuccess) { oz_set_error("oz_trainer_create: no GPU stream"); return fail(OZ_ERR_HIP); }
     const int C = channels, A = n * n, F = (n - 4) * (n - 4) * C;
@@ -809,7 +816,6 @@ OZ_API int oz_trainer_create(oz_trainer** out, int n, int channels, int in_chann
         OZ_HIP(hipEventCreateWithFlags(&t->ev_w, hipEventDisableTiming));
         for (hipEvent_t* e : {&t->ev_pre, &t->ev_wt, &t->ev_wd}) OZ_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         for (int l = 0; l < 6; ++l) T_ALLOC(t->bnb2[l], (size_t)OZ_BNB_MAX_RB * t->Co[l]);
-        { const char* e = getenv("OZ_TRAIN_OVERLAP"); t->overlap = !(e && atoi(e) == 0); }
         OZ_HIP(hipStreamSynchronize(t->s));
         return OZ_OK;
     }();
@@ -827,7 +833,11 @@ static int t_check_range(oz_trainer* t) {
     OZ_HIP(hipMemcpyAsync(&f, t->h2flag, sizeof(int), hipMemcpyDeviceToHost, t->s));
     OZ_HIP(hipStreamSynchronize(t->s));
     if (f) {
-        oz_set_error("an activation exceeded the fp16 range (65504) in the trainer's f16x2 mode: the step is invalid; use precision 0 (f32)");
+        // reported once: the flag is cleared, so the trainer is usable again after set_weights reloads good weights (the step that raised it is invalid)
+        OZ_HIP(hipMemsetAsync(t->h2flag, 0, sizeof(int), t->s));
+        OZ_HIP(hipStreamSynchronize(t->s));
+        if (f & 2) oz_set_error("a weight or gradient tensor holds Inf / NaN in the trainer's f16x2 mode (the optimisation diverged): the step is invalid");
+        else oz_set_error("an activation exceeded the fp16 range (65504) in the trainer's f16x2 mode: the step is invalid; use precision 0 (f32)");
         return OZ_ERR_STATE;
     }
     return OZ_OK;
@@ -930,7 +940,7 @@ static int t_refresh(oz_trainer* t) {
         for (int l = 1; l < 4; ++l) { am.p[l - 1] = t->param(6 * l); am.n[l - 1] = 9LL * C * C; }
         hipLaunchKernelGGL(k_t_absmax, dim3(256, 3), dim3(256), 0, r, am, t->wmax);
         for (int l = 1; l < 4; ++l)
-            hipLaunchKernelGGL(k_t_w_to_h2<0>, dim3(h2_blocks), dim3(256), 0, r, t->param(6 * l), C, C, t->wmax + (l - 1), t->Wh[l], t->wscale[l]);
+            hipLaunchKernelGGL(k_t_w_to_h2<0>, dim3(h2_blocks), dim3(256), 0, r, t->param(6 * l), C, C, t->wmax + (l - 1), t->Wh[l], t->wscale[l], t->h2flag);
         OZ_HIP(hipGetLastError());
     }
     for (int l = t->h2 ? 4 : 1; l < 6; ++l) {      // fp32 forward operands (the dense layers; the 3x3 layers too in f32 mode)
@@ -940,7 +950,7 @@ static int t_refresh(oz_trainer* t) {
     if (t->overlap) OZ_HIP(hipEventRecord(t->ev_wt, r));
     for (int l = 1; l < 4; ++l) {
         if (t->h2)
-            hipLaunchKernelGGL(k_t_w_to_h2<1>, dim3(h2_blocks), dim3(256), 0, r, t->param(6 * l), C, C, t->wmax + (l - 1), t->Whd[l], (float*)nullptr);
+            hipLaunchKernelGGL(k_t_w_to_h2<1>, dim3(h2_blocks), dim3(256), 0, r, t->param(6 * l), C, C, t->wmax + (l - 1), t->Whd[l], (float*)nullptr, t->h2flag);
         else {
             const long long cnt = 9LL * C * C;
             hipLaunchKernelGGL(k_t_dgrad_operand, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, r, t->param(6 * l), C, C, t->Wd[l]);
@@ -1026,8 +1036,7 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
         bool have_dzmax = false;
         const int Cc = t->Co[l], P = t->P_[l];
         const float post = l >= 4 && t->rate > 0.f ? 1.0f / (1.0f - t->rate) : 1.0f;
-        static const bool bnb_split = !(getenv("OZ_BN_BWD_SPLIT") && atoi(getenv("OZ_BN_BWD_SPLIT")) == 0);
-        if ((bnb_split || t->h2) && (long long)B * P > OZ_BNB_MIN_ROWS && (long long)B * P <= OZ_BNB_MAX_ROWS) {
+        if ((long long)B * P > OZ_BNB_MIN_ROWS && (long long)B * P <= OZ_BNB_MAX_ROWS) {
             // partial sums over row splits, then one launch that finishes the sums and writes dz (oz_train_fused.h)
             const long long M = (long long)B * P;
             const int Q = Cc / 4, lpr = Q < 64 ? Q : 64, rpp = 256 / lpr;
@@ -1091,10 +1100,9 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
                 OZ_HIP(hipStreamWaitEvent(t->s2, t->ev_dz[l], 0));
                 sw = t->s2; wp = t->wpartial;
             }
-            static const bool conv_kernel = !(getenv("OZ_WGRAD_CONV") && atoi(getenv("OZ_WGRAD_CONV")) == 0);   // OZ_WGRAD_CONV=0: the tap-per-block kernel (A/B runs)
             // (measured on one MI355X, 8x8 / 512 filters: the board-resident kernel wins from batch 256 on -- 6.01 vs 6.36 ms per step, 17.0 vs
             //  19.9 at 1024 -- and loses 3-4 % at 32 .. 128, where the tap-per-block kernel's 144 x 4 short blocks finish sooner)
-            if (taps[l] == 9 && conv_kernel && B >= 192 && Cin[l] % WC_CI == 0 && Cc % WC_CO == 0) {
+            if (taps[l] == 9 && B >= 192 && Cin[l] % WC_CI == 0 && Cc % WC_CO == 0) {
                 // board-resident kernel: (Cin / 64) x (Cout / 128) tiles, boards split over blockIdx.y until every CU has a block
                 WconvGeom cg; cg.Hin = Hin[l]; cg.Hout = t->Hout[l]; cg.pad = pad[l]; cg.Cin = Cin[l]; cg.Cout = Cc; cg.Hz = t->Hz[l]; cg.zoff = t->zoff[l];
                 const int tiles = (Cin[l] / WC_CI) * (Cc / WC_CO);
@@ -1125,7 +1133,7 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
                     long long thr = (long long)B * P * (Cc / 8);
                     if (thr < Cin[l]) thr = Cin[l];
                     hipLaunchKernelGGL(k_t_dz_to_h2, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, s, t->dz[l], t->d_count, t->Hout[l], t->Hz[l], t->zoff[l], Cc,
-                                       t->dzmax + l, t->wmax + (l - 1), t->dz_h2[l], t->dscale[l], Cin[l]);
+                                       t->dzmax + l, t->wmax + (l - 1), t->dz_h2[l], t->dscale[l], Cin[l], t->h2flag);
                     if (int rc = oz_gemm_h2_launch(t->dz_h2[l], t->Whd[l], t->dscale[l], t->zeros, t->dA[cur ^ 1], t->d_count, B, t->Hz[l], Hin[l], same ? 1 : 0, Cc, 9,
                                                    Cin[l], s, t->gpartial, t->gpartial_floats, t->zeros, t->h2flag)) return rc;
                 } else if (t->h2) {

@@ -121,7 +121,9 @@ class SelfPlayEngine:
 
     def __init__(self, neural_network, board_size=8, num_games=4096, num_simulations=100, degree_exploration=1.0,
                  policy_temperature=1.0, e_greedy=0.9, seed=1234, first_game_id=0, game_id_stride=0,
-                 q_mode=_lib.QMODE_F64, refill=False, node_cap=0, edge_cap=0, record_cap=0):
+                 q_mode=_lib.QMODE_F64, refill=False, node_cap=0, edge_cap=0, record_cap=0, dedup=True, batch_cap=0):
+        """dedup: cross-game leaf de-duplication (a board several games reach in one batch is evaluated once; no record changes);
+        batch_cap: leaves per network batch of the free-running driver (0 = none; see preferred_batch_cap)"""
         lib = _lib.require_gpu()
         assert getattr(neural_network, "_h", None) is not None, "SelfPlayEngine needs a native NNetWrapper / StubNetWrapper"
         self.net = neural_network
@@ -129,7 +131,7 @@ class SelfPlayEngine:
             n=board_size, num_games=num_games, sims=num_simulations, q_mode=q_mode, c=float(degree_exploration),
             temperature=float(policy_temperature), e_greedy=float(e_greedy), seed=seed, first_game_id=first_game_id,
             game_id_stride=game_id_stride, refill=1 if refill else 0, node_cap=node_cap, edge_cap=edge_cap,
-            record_cap=record_cap)
+            record_cap=record_cap, dedup=_lib.DEDUP_ON if dedup else _lib.DEDUP_OFF, batch_cap=int(batch_cap))
         self._h = C.c_void_p()
         _lib.check(lib.oz_selfplay_create(C.byref(self._h), C.byref(self.cfg), neural_network._h))
         self.n, self.num_games = board_size, num_games
@@ -161,6 +163,10 @@ class SelfPlayEngine:
         the slot order rotates so that every game is served.  Records do not change; the launches become whole grid rounds at the right
         cap (see `preferred_batch_cap`)"""
         _lib.check(_lib.load().oz_selfplay_set_batch_cap(self._h, int(cap)))
+
+    def set_dedup(self, enable):
+        """cross-game leaf de-duplication on / off from the next batch on"""
+        _lib.check(_lib.load().oz_selfplay_set_dedup(self._h, 1 if enable else 0))
 
     def stagger(self, sims_pre=None, sync=True):
         """continuous self-play (refill=True), first call only: advance slot g (g * P) // num_games plies into its first game

@@ -117,6 +117,49 @@ def test_network_at_bench_batch_vs_float64_oracle(oz, n, precision):
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_network_at_the_timed_shape_vs_float64_oracle(oz, precision):
+    """the exact launch bench.py's timed region makes: NNetWrapper(max_batch=4096), ONE call with preferred_batch_cap(8, 4096, 512) =
+    3640 positions -- conv3 then runs on the 256-row tile (1024 tiles = 4.0 grid rounds), the kernel the roofline row is about.
+    <= 1e-5 against the float64 oracle, and bit-identical on the shared rows with the 4096-position call (192-row tile: same sums)"""
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.training import preferred_batch_cap
+    n = 8
+    cap = preferred_batch_cap(n, B, C)
+    assert cap == 3640
+    w, own, opp, pi64, v64 = _case(n)
+    net = NNetWrapper((n, n), num_channels_1=C, max_batch=B, weights=w, precision=precision)
+    pi, v = net.predict_batch(own[:cap], opp[:cap])
+    rows_cap = net.conv3_tile_rows()
+    pi = pi.reshape(cap, -1)
+    err_pi, err_v = np.abs(pi - pi64[:cap]).max(), np.abs(v - v64[:cap]).max()
+    assert err_pi <= TOL and err_v <= TOL, (err_pi, err_v)
+    p4, v4 = net.predict_batch(own, opp)
+    rows_full = net.conv3_tile_rows()
+    if precision == "f16x2":
+        assert (rows_cap, rows_full) == (256, 192)                       # the capped call IS the timed kernel; the full call is the other tile
+    assert np.array_equal(p4.reshape(B, -1)[:cap], pi) and np.array_equal(v4[:cap], v)
+    # the last rows of the call sit in the partly filled last row tile (3640 * 36 = 511.9 tiles of 256 rows)
+    tail = np.abs(pi[-8:] - pi64[cap - 8:cap]).max()
+    assert tail <= TOL
+
+
+def test_config5_real_networks_bounded_plies_vs_oracle(oz):
+    """bench.py's config5 leg (BASELINE configs[4] with REAL networks): 512 arena games x 800 sims per move and agent on two 512-filter
+    networks (seeds 0 / 1), bounded to 3 plies; two sampled games replayed by the oracle's arena (agents.py:44-84 restated) fed with
+    the GPU networks' own (pi, v): actions, movers and boards bit-exact"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("oz_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.config5_arena(C, "f16x2", plies=3)
+    assert out["sample_mismatches"] == 0 and out["sample_games_replayed_by_oracle"] == 2
+    assert out["moves"] == 512 * 3 and out["simulations"] == 512 * 3 * 800 and out["expansions"] > 0.8 * out["simulations"]
+    assert out["sims_per_s"] > 0 and out["value"] > 0
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
 def test_network_at_bench_batch_gemm_form_vs_float64_oracle(oz, precision):
     """the same 4096-position forward with conv1 as a kernel and conv2 as an MFMA implicit GEMM (oz_net_set_tables 0: the
     `all_layers_as_gemm` leg of bench.py) -- the 256 x 256 ping-pong tile on conv2 at one k-slice"""
@@ -135,7 +178,7 @@ def test_network_at_bench_batch_gemm_form_vs_float64_oracle(oz, precision):
 
 
 @pytest.mark.parametrize("precision,dedup", [("f16x2", False), ("f16x2", True), ("f32", False)])
-def test_config2_real_network_search_replay(oz, precision, dedup, monkeypatch):
+def test_config2_real_network_search_replay(oz, precision, dedup):
     """BASELINE configs[1] with the real network: 4096 concurrent 8x8 games x 100 sims/move x 2 move rounds on the
     512-filter OthelloNN (max_batch 4096: the kernels bench.py times); 16 sampled games are replayed by the oracle's search
     fed with the GPU network's own (pi, v) per position -- moves, boards and root visit counts must match bit for bit
@@ -143,9 +186,8 @@ def test_config2_real_network_search_replay(oz, precision, dedup, monkeypatch):
     from othellozero_amd.NNet import NNetWrapper
     from othellozero_amd.training import SelfPlayEngine
     n, G, sims, rounds = 8, B, 100, 2
-    monkeypatch.setenv("OZ_DEDUP", "1" if dedup else "0")
     net = NNetWrapper((n, n), num_channels_1=C, max_batch=G, seed=0, precision=precision)        # bench.py's network (seed 0)
-    eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=0, q_mode=1)
+    eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=0, q_mode=1, dedup=dedup)
     eng.run(1)
     counts1 = eng.last_counts().copy()
     eng.run(rounds - 1)
@@ -203,19 +245,18 @@ def test_stagger_spreads_games_and_keeps_records_exact(oz):
 
 
 @pytest.mark.parametrize("dedup,cap", [(False, 0), (True, 0), (False, 3640), (True, 3640)])
-def test_free_running_driver_at_config2_size_equals_lock_step(oz, monkeypatch, dedup, cap):
+def test_free_running_driver_at_config2_size_equals_lock_step(oz, dedup, cap):
     """bench.py's default driver (oz_selfplay_run_steps: a game runs on by itself, batches stay full) at the bench's own size -- 4096
     staggered 8x8 games x 100 simulations on the 512-filter network, f16x2, one evaluation per expansion: every game that completes
     under both drivers has the records of the lock-step driver (whose games the tests above replay with the oracle) bit for bit"""
     from othellozero_amd.NNet import NNetWrapper
     from othellozero_amd.training import SelfPlayEngine
     n, G, sims = 8, B, 100
-    monkeypatch.setenv("OZ_DEDUP", "1" if dedup else "0")       # bench headline (off) and the library default (on)
     net = NNetWrapper((n, n), num_channels_1=C, max_batch=G, seed=0, precision="f16x2")
 
     def make():
         return SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=0, game_id_stride=G, q_mode=1, refill=True,
-                              record_cap=G * 16)
+                              record_cap=G * 16, dedup=dedup)            # bench headline (off) and the library default (on)
     lock = make()
     lock.stagger(8)
     lock.run(3)

@@ -676,7 +676,7 @@ def test_basenn_network_vs_float64_oracle(oz, precision, channels):
 
 @pytest.mark.gpu
 def test_pingpong_conv_loop_bit_identical_to_simple_loop():
-    """the 4-phase ping-pong main loop (default) and the one-barrier-per-k-tile loop (OZ_H2_PP=0) accumulate every
+    """the 4-phase ping-pong main loop (default) and the one-barrier-per-k-tile loop (oz_net_set_option OZ_NET_OPT_SIMPLE_LOOP) accumulate every
     output in the same order: (pi, v) must be bit-identical over batch sizes / boards / repetitions -- a LDS-DMA
     visibility race in the ping-pong schedule would show up as a mismatch (tools/pp_race_check.py)"""
     import os
@@ -792,18 +792,17 @@ def test_free_running_selfplay_equals_lock_step(oz, n, sims, T, keep, cap):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["stub", "onn"])
-def test_cross_game_leaf_dedup_changes_nothing_but_the_work(oz, kind, monkeypatch):
+def test_cross_game_leaf_dedup_changes_nothing_but_the_work(oz, kind):
     """k_compact evaluates a board that several games reach in the same step once (default) -- records, visit counts and
-    per-game statistics are those of one evaluation per game (OZ_DEDUP=0), and the opening plies cost far fewer evaluations"""
+    per-game statistics are those of one evaluation per game (oz_selfplay_config.dedup = OZ_DEDUP_OFF), and the opening plies cost far fewer evaluations"""
     from othellozero_amd.NNet import NNetWrapper, StubNetWrapper
     from othellozero_amd.training import SelfPlayEngine
     n, G, sims = 6, 96, 12
     def run(dedup):
-        monkeypatch.setenv("OZ_DEDUP", "1" if dedup else "0")
         net = (StubNetWrapper((n, n), 5, 0, max_batch=G) if kind == "stub" else
                NNetWrapper((n, n), num_channels_1=256, max_batch=G, seed=4, precision="f16x2"))
         eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=77, first_game_id=0, game_id_stride=G, refill=False,
-                             record_cap=G * n * n)
+                             record_cap=G * n * n, dedup=dedup)
         eng.run(n * n)
         return eng.records(), eng.stats(), eng.last_counts()
     r1, s1, c1 = run(True)
@@ -875,6 +874,7 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 36 and out["scaling"] == "weak" and out["value"] > 0
+    assert len(out["per_rank_records"]) == 2 and sum(out["per_rank_records"]) == out["pooled_records"] and out["gather_ms"] > 0
     # records leave the engines when a game ends: both ranks' finished games (>= 28 moves each) are in the pooled tensor
     assert out["games_completed"] >= 2 * 48 and out["pooled_records"] >= 28 * out["games_completed"]
     assert "cpu_baseline" not in out and "cross_game_dedup" not in out
@@ -944,6 +944,25 @@ def test_bench_launches_its_own_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 0 and out["config"]["backend"] == "gloo"
     assert out["games_completed"] > 0 and out["pooled_records"] >= 28 * out["games_completed"] and out["value"] > 0
+    # the exchange step is diagnosable from the line: what every rank contributed, that nothing was lost, and what the gather cost
+    assert len(out["per_rank_records"]) == 2 and min(out["per_rank_records"]) > 0
+    assert sum(out["per_rank_records"]) == out["pooled_records"] and out["gather_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_rank_names_its_phase_when_a_peer_never_arrives(tmp_path):
+    """a rank of a 2-rank world whose peer never starts: the rendezvous times out (OZ_BENCH_COLLECTIVE_TIMEOUT), the rank prints WHICH
+    rank failed in WHICH phase and exits non-zero without a JSON line -- the first real multi-rank RCCL run must be diagnosable"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", OZ_BENCH_INIT_FILE=str(tmp_path / "rendezvous"),
+               OZ_BENCH_COLLECTIVE_TIMEOUT="5", OZ_BENCH_TIMEOUT="60")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--board", "6", "--games", "64", "--sims", "6",
+                        "--backend", "gloo", "--same-device"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "rank 0" in r.stderr and "phase 'init'" in r.stderr, r.stderr[-1500:]
 
 
 @pytest.mark.gpu

@@ -3,7 +3,6 @@ from K host threads: while one engine is in its small latency-bound kernels (sel
 bandwidth-bound table gather, the others' GEMMs fill the chip.   python tools/exp_two_engines.py [K] [rounds]"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("OZ_DEDUP", "0")
 from othellozero_amd import _lib
 from othellozero_amd.NNet import NNetWrapper
 from othellozero_amd.training import SelfPlayEngine
@@ -13,7 +12,7 @@ G, n = 4096, 8
 g = G // K
 nets = [NNetWrapper((n, n), num_channels_1=512, max_batch=g, seed=0, precision="f16x2") for _ in range(K)]
 engs = [SelfPlayEngine(nets[k], n, g, 100, 1.0, 1.0, 0.9, seed=1234, first_game_id=k * g, game_id_stride=G, q_mode=_lib.QMODE_F64,
-                       refill=True, record_cap=int(g * (rounds + 4) * 1.25)) for k in range(K)]
+                       refill=True, record_cap=int(g * (rounds + 4) * 1.25), dedup=False) for k in range(K)]
 def run(e, r):
     e.run(r, sync=False); e.sync()
 def all_run(r):

@@ -21,8 +21,8 @@ net = NNetWrapper((n, n), num_channels_1=512, max_batch=G, seed=0, precision=arg
 pre_plies = np.zeros(G, int)
 if args.driver == "free":
     from othellozero_amd.training import preferred_batch_cap
-    os.environ["OZ_DEDUP"] = "0"                             # the bench headline: one evaluation per expansion
-    eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=0, game_id_stride=G, q_mode=1, refill=True, record_cap=G * 140)
+    eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=0, game_id_stride=G, q_mode=1, refill=True, record_cap=G * 140,
+                         dedup=False)                                # the bench headline: one evaluation per expansion
     cap = preferred_batch_cap(n, G, 512) if args.batch_cap < 0 else args.batch_cap
     eng.set_batch_cap(cap)
     eng.stagger(8)
