@@ -479,6 +479,7 @@ def main():
     ap.add_argument("--arena-plies", type=int, default=6, help="config5 leg: plies per arena game (512 games x 800 sims per move and agent)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    ap.add_argument("--no-c-abi-gather", action="store_true", help="N > 1: skip the post-line check of the C ABI's own RCCL exchange step")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -556,12 +557,12 @@ def run_rank(args, rank, world, local_rank, t_proc):
         """leaves per network batch of the free-running driver (0: none)"""
         return preferred_batch_cap(board, games, args.channels) if args.batch_cap < 0 else args.batch_cap
 
-    def make_engine(dedup, the_net=net, board=n, games=G, steps=args.steps):
+    def make_engine(dedup, the_net=net, board=n, games=G, steps=args.steps, eval_cache=False):
         # (oz_selfplay_config.dedup / .batch_cap; the cap is used by the free-running driver only)
         return SelfPlayEngine(the_net, board, games, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * games,
                               game_id_stride=world * games, q_mode=_lib.QMODE_F64, refill=True,
                               record_cap=int(games * (steps + args.warmup + board * board + 2) * 1.25),
-                              dedup=dedup, batch_cap=batch_cap(board, games))
+                              dedup=dedup, batch_cap=batch_cap(board, games), eval_cache=eval_cache)
     eng = make_engine(args.dedup == "on")
     cap_main = batch_cap(n, G) if args.driver == "free" else 0
 
@@ -653,6 +654,7 @@ def run_rank(args, rank, world, local_rank, t_proc):
         print(f"bench.py: rank {rank}: pooled {int(pooled.shape[0])} records, the ranks contributed {per_rank_records} (sum {sum(per_rank_records)})",
               file=sys.stderr, flush=True)
         sys.exit(4)
+    eng_for_c_abi = eng if world > 1 else None
     phase("report")
     exp_all, sims_all, games_all, moves_all, visits_all = (float(x) for x in vec.tolist())
 
@@ -740,7 +742,8 @@ def run_rank(args, rank, world, local_rank, t_proc):
             out["parity_sample_max_err"] = max(ps["max_abs_err_pi"], ps["max_abs_err_v"])
             out["parity_sample"] = ps
             wall["parity_sample_s"] = round(time.perf_counter() - t_sec, 2)
-        del eng
+        if world == 1:
+            del eng                                               # (N > 1: kept for the C-ABI exchange check after the line)
         if secondary and args.dedup == "off":
             t_sec = time.perf_counter()
             # the same workload with the library default (cross-game de-duplication on): identical records, fewer evaluations
@@ -754,6 +757,28 @@ def run_rank(args, rank, world, local_rank, t_proc):
                         "network evaluation (k_compact). Not the headline: `value` above evaluates every expansion"}
             del eng2
             wall["dedup_compare_s"] = round(time.perf_counter() - t_sec, 2)
+        if secondary and args.dedup == "off":
+            # the same workload with every sharing the library offers: cross-game de-duplication AND the network's persistent exact-key
+            # evaluation cache (the reference's per-search _predict_cache, othelo_mcts.py:82-88, across batches / games / refilled slots)
+            t_sec = time.perf_counter()
+            net.set_eval_cache(1 << 23)
+            engc = make_engine(True, eval_cache=True)
+            engc.stagger(cheap_pre)
+            c0 = net.eval_cache_stats()
+            qc, dtc = measure(engc, args.steps)
+            c1 = net.eval_cache_stats()
+            out["eval_cache"] = {
+                "value": qc["expansions"] / dtc, "unit": "node-expansions/s", "ms_per_step": dtc / args.steps * 1e3,
+                "games_per_s": qc["games_completed"] / dtc, "sims_per_s": qc["simulations"] / dtc,
+                "expansions": int(qc["expansions"]), "leaves_evaluated": int(qc["leaves_evaluated"]),
+                "hit_rate": (c1["hits"] - c0["hits"]) / max(c1["lookups"] - c0["lookups"], 1), "cache_entries": c1["entries"],
+                "note": f"same workload (slots staggered at {cheap_pre} sims/move, which also warms the cache), de-duplication on, "
+                        "oz_selfplay_config.eval_cache = 1: a leaf whose board this network has evaluated before takes (pi, v) from the "
+                        "network's HBM cache and needs no batch slot; records identical (tests/test_gpu_bench_config.py). Not the headline: "
+                        "`value` above evaluates every expansion"}
+            del engc
+            net.set_eval_cache(0)
+            wall["eval_cache_s"] = round(time.perf_counter() - t_sec, 2)
         if secondary:
             # the same workload under the library's other driver (identical records per game: tests/test_gpu_bench_config.py)
             t_sec = time.perf_counter()
@@ -836,6 +861,33 @@ def run_rank(args, rank, world, local_rank, t_proc):
                 out["config4"]["cpu_baseline"] = cpu_baseline_config(6, args.channels, args.sims, 5.0, out["cpu_baseline"]["cores"])
             wall["cpu_baseline_s"] = round(time.perf_counter() - t_sec, 2)
         print(json.dumps(out), flush=True)
+    if world > 1 and args.backend == "nccl" and not args.no_c_abi_gather:
+        # AFTER the line is out (nothing here can cost the measurement): the same exchange step through the C ABI's own RCCL communicator
+        # (oz_comm_* / oz_selfplay_gather_records), checked against the torch.distributed pool; outcome on stderr.  Guarded by a
+        # timeout: a rank that cannot finish it in 60 s says so and the run still ends with exit code 0.
+        import threading
+        phase("c-abi-gather")
+        result = {}
+
+        def c_abi():
+            try:
+                from othellozero_amd.distributed import Comm, torch_share
+                comm = Comm(rank, world, torch_share(dev))
+                t_c = time.perf_counter()
+                rec, per = comm.gather_records(eng_for_c_abi, first_record=s0["records"])
+                result.update(ms=(time.perf_counter() - t_c) * 1e3, records=int(rec.size), per_rank=[int(x) for x in per],
+                              same=bool(rec.tobytes() == pooled.cpu().numpy().tobytes()))
+                comm.close()
+            except BaseException as e:                          # noqa: BLE001 -- report, never fail the run
+                result["error"] = repr(e)
+        th = threading.Thread(target=c_abi, daemon=True)
+        th.start()
+        th.join(60)
+        if th.is_alive():
+            print(f"bench.py: rank {rank}: c-abi gather over RCCL did not finish in 60 s (skipped; the line above stands)", file=sys.stderr, flush=True)
+            os._exit(0)
+        if rank == 0:
+            print(f"bench.py: c-abi gather over RCCL ({world} ranks, oz_selfplay_gather_records): {json.dumps(result)}", file=sys.stderr, flush=True)
     if world > 1:
         phase("teardown")
         dist.barrier()

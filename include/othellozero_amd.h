@@ -103,6 +103,13 @@ int oz_net_profiled_layer(oz_net* net, int* layer);
  * inside conv2's operand gather, conv2 an MFMA GEMM (bit-identical to 0); 0: conv1 kernel + conv2 MFMA GEMM; -1: back to the
  * default.  Takes effect at the next forward. */
 int oz_net_set_tables(oz_net* net, int mode);
+/* Persistent exact-key evaluation cache of this network: (own, opp) -> (pi, v) for up to ~`entries` positions in HBM (rounded up to a
+ * power of two of 4-way buckets; n*n + 6 words per entry; 0 frees it).  The generalisation of the reference's per-search
+ * `_predict_cache` (othelo_mcts.py:13,82-88: one dict per OthelloMCTS instance) to every self-play engine that is created with
+ * oz_selfplay_config.eval_cache = 1 on this network -- across batches, games and refilled slots.  A hit changes no bit of any result
+ * (a position's (pi, v) is independent of the batch it is evaluated in); the cache is emptied by oz_net_commit (new weights). */
+int oz_net_set_eval_cache(oz_net* net, int64_t entries);
+int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int64_t* hits, int64_t* inserts);
 /* diagnostics switch, per network (default 0): the 3x3 convolutions of precision f16x2 on the one-barrier-per-k-tile main loop instead of
  * the 4-phase ping-pong loop.  Same tiles' accumulation order, bit-identical results: the reference form the LDS-DMA race screen
  * (tools/pp_race_check.py, test_pingpong_conv_loop_bit_identical_to_simple_loop) compares the ping-pong schedule against. */
@@ -166,6 +173,9 @@ typedef struct {
     int32_t dedup;          /* OZ_DEDUP_*: cross-game leaf de-duplication -- a board that several games reach in the same batch is evaluated
                              * once and every one of them reads the same (pi, v) row; changes no record, count or statistic, only leaves_evaluated */
     int32_t batch_cap;      /* free-running driver: leaves per network batch (0 = none), see oz_selfplay_set_batch_cap */
+    int32_t eval_cache;     /* 1: leaves whose board is in the network's evaluation cache (oz_net_set_eval_cache) take their (pi, v) from it and
+                             * need no batch slot; evaluated leaves are inserted.  0 (default): every leaf is evaluated by the network */
+    int32_t reserved;
 } oz_selfplay_config;
 #define OZ_DEDUP_DEFAULT 0  /* = on */
 #define OZ_DEDUP_ON 1
@@ -233,6 +243,22 @@ int oz_selfplay_records_device(oz_selfplay* sp, void* dst_device, int64_t max_re
 int oz_selfplay_last_counts(oz_selfplay* sp, int32_t* counts);
 /* HIP-event time of the evaluator (NN) launches since creation, and their count */
 int oz_selfplay_eval_time(oz_selfplay* sp, double* ms_total, int64_t* launches, int64_t* leaves);
+
+/* ------------------------------------------------------------------ exchange step (multi-GPU; SURVEY.md 8(b) gather_examples(comm), 8(e))
+ * One process per GPU, games sharded by global id (first_game_id / game_id_stride), weights replicated; the path's ONE collective is
+ * the all-gather of the 48-byte move records of completed games -- RCCL over xGMI, bound at run time (librccl.so.1).  Replaces
+ * WorkerManager.get_results' list concatenation and the ssh / pickle return path (workers.py:147-159,180-184).
+ * Rank 0 makes an id (oz_comm_unique_id), the host hands its 128 bytes to every rank, every rank calls oz_comm_create on ITS device
+ * (oz_set_device first), then oz_selfplay_gather_records collectively. */
+typedef struct oz_comm oz_comm;
+#define OZ_COMM_ID_BYTES 128
+int oz_comm_unique_id(uint8_t* id /* [OZ_COMM_ID_BYTES] */);
+int oz_comm_create(oz_comm** out, const uint8_t* id, int rank, int world);
+int oz_comm_destroy(oz_comm* comm);
+/* COLLECTIVE over `comm`: the records [first_record, completed so far) of every rank's engine, concatenated in rank order, into `out`
+ * (host buffer of max_records); *written = their number, per_rank[world] (optional) = what each rank contributed. */
+int oz_selfplay_gather_records(oz_selfplay* sp, oz_comm* comm, int64_t first_record, oz_record* out, int64_t max_records, int64_t* written,
+                               int64_t* per_rank);
 
 /* ------------------------------------------------------------------ arena
  * duel_between_agents with two NeuralNetworkOthelloAgent (agents.py:44-84): net_a = BLACK, net_b = WHITE,

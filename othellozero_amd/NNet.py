@@ -201,6 +201,16 @@ class NNetWrapper(_NetHandle):
         """f16x2: 2 = conv1 + conv2 from pattern tables (default), 1 = conv1 table + conv2 GEMM, 0 = conv1 kernel + conv2 GEMM"""
         _lib.check(_lib.load().oz_net_set_tables(self._h, int(mode)))
 
+    def set_eval_cache(self, entries):
+        """persistent exact-key evaluation cache of this network for up to ~`entries` positions (0 frees it); used by engines created with
+        eval_cache=True, emptied whenever the weights change"""
+        _lib.check(_lib.load().oz_net_set_eval_cache(self._h, int(entries)))
+
+    def eval_cache_stats(self):
+        e, l, h, i = (C.c_int64() for _ in range(4))
+        _lib.check(_lib.load().oz_net_eval_cache_stats(self._h, C.byref(e), C.byref(l), C.byref(h), C.byref(i)))
+        return dict(entries=e.value, lookups=l.value, hits=h.value, inserts=i.value)
+
     def set_option(self, option, value):
         """diagnostics switches (_lib.NET_OPT_*): NET_OPT_SIMPLE_LOOP = the one-barrier conv loop the race screen compares against"""
         _lib.check(_lib.load().oz_net_set_option(self._h, int(option), int(value)))
@@ -234,3 +244,5 @@ class StubNetWrapper(_NetHandle):
 
     predict_batch = NNetWrapper.predict_batch
     predict = NNetWrapper.predict
+    set_eval_cache = NNetWrapper.set_eval_cache
+    eval_cache_stats = NNetWrapper.eval_cache_stats

@@ -39,7 +39,7 @@ class SelfplayConfig(C.Structure):
         ("c", C.c_double), ("temperature", C.c_double), ("e_greedy", C.c_double),
         ("seed", C.c_uint64), ("first_game_id", C.c_uint64), ("game_id_stride", C.c_uint64),
         ("refill", C.c_int32), ("node_cap", C.c_int32), ("edge_cap", C.c_int32), ("record_cap", C.c_int32),
-        ("dedup", C.c_int32), ("batch_cap", C.c_int32),
+        ("dedup", C.c_int32), ("batch_cap", C.c_int32), ("eval_cache", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -84,6 +84,7 @@ SIGNATURES = {
     "oz_net_profile": [_vp, C.c_int], "oz_net_profile_read": [_vp, _f64p, _i64p],
     "oz_net_profiled_layer": [_vp, C.POINTER(C.c_int)], "oz_net_set_tables": [_vp, C.c_int],
     "oz_net_profile_kernels": [_vp, _f64p, _i64p, C.c_int],
+    "oz_net_set_eval_cache": [_vp, C.c_int64], "oz_net_eval_cache_stats": [_vp, _i64p, _i64p, _i64p, _i64p],
     "oz_net_set_option": [_vp, C.c_int, C.c_int], "oz_net_get_info": [_vp, C.c_int, C.POINTER(C.c_int)],
     "oz_mcts_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int],
     "oz_mcts_destroy": [_vp], "oz_mcts_reset": [_vp, C.c_int], "oz_mcts_set_dedup": [_vp, C.c_int],
@@ -106,6 +107,8 @@ SIGNATURES = {
     "oz_selfplay_records_device": [_vp, _vp, C.c_int64, _i64p],
     "oz_selfplay_last_counts": [_vp, _i32p],
     "oz_selfplay_eval_time": [_vp, _f64p, _i64p, _i64p],
+    "oz_comm_unique_id": [_u8p], "oz_comm_create": [C.POINTER(_vp), _u8p, C.c_int, C.c_int], "oz_comm_destroy": [_vp],
+    "oz_selfplay_gather_records": [_vp, _vp, C.c_int64, _vp, C.c_int64, _i64p, _i64p],
     "oz_arena_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_uint64, _vp, _vp, C.c_int, C.c_int],
     "oz_arena_destroy": [_vp], "oz_arena_run": [_vp], "oz_arena_run_rounds": [_vp, C.c_int], "oz_arena_stats": [_vp, _i64p, _i64p],
     "oz_arena_results": [_vp, _i8p, _i32p, _i32p, _u8p, _i8p, _u64p, _u64p],

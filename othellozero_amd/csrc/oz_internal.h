@@ -74,6 +74,23 @@ struct OzTimer {
     }
 };
 
+// Persistent exact-key evaluation cache of a network (oz_net_set_eval_cache): (own, opp) -> (pi[n*n], v), the generalisation of the
+// reference's per-search `_predict_cache` (othelo_mcts.py:82-88) to every search that uses the network, across batches, games and
+// refilled slots.  4-way buckets (the four 16-byte keys of a bucket are one 64-byte line), empty key = (0, 0) (no Othello position is
+// empty), a full bucket replaces the way the hash picks.  Lookups (leaf compaction) and inserts (after the network) run in different
+// kernels of one stream, so a lookup never sees a half-written entry; `stamp` arbitrates two inserts into one entry within a batch.
+// A position's (pi, v) does not depend on the batch it is evaluated in (oz_net.hip), so serving it from the cache changes no bit.
+#define OZ_EC_WAYS 4
+struct EvalCacheDev {
+    unsigned long long* keys = nullptr;     // [entries][2]
+    float* pi = nullptr;                    // [entries][n2]
+    float* v = nullptr;                     // [entries]
+    unsigned* stamp = nullptr;              // [entries] batch number of the last insert
+    unsigned long long* counters = nullptr; // [0] lookups [1] hits [2] inserts
+    unsigned buckets = 0;                   // power of two; entries = buckets * OZ_EC_WAYS; 0 = no cache
+    int n2 = 0;
+};
+
 // Leaf evaluator: NNetWrapper.predict (Net/NNet.py:70-87) over a device-resident batch.
 // d_count lives on the device (filled by the compaction kernel); kernels are launched for
 // max_count leaves and exit early beyond *d_count, so no host round trip per step.
@@ -88,8 +105,16 @@ struct oz_net {
     float* p_out = nullptr;
     std::vector<uint64_t> h_in;
     std::vector<float> h_out;
+    EvalCacheDev ec;         // oz_net_set_eval_cache; cleared whenever the weights change (oz_net_commit)
+    void free_eval_cache() {
+        if (!ec.buckets) return;
+        hipSetDevice(device);
+        hipFree(ec.keys); hipFree(ec.pi); hipFree(ec.v); hipFree(ec.stamp); hipFree(ec.counters);
+        ec = EvalCacheDev();
+    }
     virtual ~oz_net() {
         if (p_in) { hipSetDevice(device); hipFree(p_in); hipFree(p_out); }
+        free_eval_cache();
     }
     virtual int check() { return 0; }      // sticky device-side validity flags (f16x2 range)
     virtual const int* flag_device() { return nullptr; }     // the device word check() reads (nullptr: nothing to check)

@@ -949,6 +949,56 @@ OZ_API int oz_net_create_stub(oz_net** out, int n, uint64_t salt, uint64_t keep_
 
 OZ_API int oz_net_destroy(oz_net* net) { delete net; return OZ_OK; }
 
+// ---------------------------------------------------------------- persistent evaluation cache (EvalCacheDev, oz_internal.h)
+static int eval_cache_clear(oz_net* net) {
+    EvalCacheDev& c = net->ec;
+    if (!c.buckets) return OZ_OK;
+    const size_t entries = (size_t)c.buckets * OZ_EC_WAYS;
+    OZ_HIP(hipMemset(c.keys, 0, entries * 16));
+    OZ_HIP(hipMemset(c.stamp, 0, entries * sizeof(unsigned)));
+    return OZ_OK;
+}
+OZ_API int oz_net_set_eval_cache(oz_net* net, int64_t entries) {
+    OZ_REQUIRE(net, "null net");
+    OZ_REQUIRE(entries >= 0 && entries <= (1ll << 30), "oz_net_set_eval_cache: entries %lld", (long long)entries);
+    std::lock_guard<std::mutex> lk(net->mu);
+    hipSetDevice(net->device);
+    OZ_HIP(hipDeviceSynchronize());                          // no search may be using the old table
+    net->free_eval_cache();
+    if (entries == 0) return OZ_OK;
+    unsigned buckets = 1024;
+    while ((long long)buckets * OZ_EC_WAYS < entries) buckets <<= 1;
+    const size_t e = (size_t)buckets * OZ_EC_WAYS;
+    EvalCacheDev c;
+    c.n2 = net->n * net->n;
+    hipError_t err = hipMalloc((void**)&c.keys, e * 16);
+    if (err == hipSuccess) err = hipMalloc((void**)&c.pi, e * c.n2 * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc((void**)&c.v, e * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc((void**)&c.stamp, e * sizeof(unsigned));
+    if (err == hipSuccess) err = hipMalloc((void**)&c.counters, 4 * sizeof(unsigned long long));
+    if (err != hipSuccess) {
+        hipFree(c.keys); hipFree(c.pi); hipFree(c.v); hipFree(c.stamp); hipFree(c.counters);
+        oz_set_error("oz_net_set_eval_cache: %s", hipGetErrorString(err));
+        return OZ_ERR_HIP;
+    }
+    c.buckets = buckets;
+    net->ec = c;
+    OZ_HIP(hipMemset(c.counters, 0, 4 * sizeof(unsigned long long)));
+    return eval_cache_clear(net);
+}
+OZ_API int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int64_t* hits, int64_t* inserts) {
+    OZ_REQUIRE(net, "null net");
+    std::lock_guard<std::mutex> lk(net->mu);
+    hipSetDevice(net->device);
+    unsigned long long c[4] = {0, 0, 0, 0};
+    if (net->ec.buckets) { OZ_HIP(hipDeviceSynchronize()); OZ_HIP(hipMemcpy(c, net->ec.counters, sizeof c, hipMemcpyDeviceToHost)); }
+    if (entries) *entries = (int64_t)net->ec.buckets * OZ_EC_WAYS;
+    if (lookups) *lookups = (int64_t)c[0];
+    if (hits) *hits = (int64_t)c[1];
+    if (inserts) *inserts = (int64_t)c[2];
+    return OZ_OK;
+}
+
 static OnnNet* as_onn(oz_net* net) { return net && net->kind == 0 ? static_cast<OnnNet*>(net) : nullptr; }
 
 OZ_API int oz_net_num_weights(const oz_net* net) { return net && net->kind == 0 ? 40 : 0; }
@@ -1104,6 +1154,7 @@ OZ_API int oz_net_commit(oz_net* net) {
         if (int rc = o->alloc(&o->f2, B * 512)) return rc;
     }
     OZ_HIP(hipDeviceSynchronize());
+    if (int rc = eval_cache_clear(o)) return rc;             // new weights: every cached (pi, v) is stale
     o->committed = true;
     return OZ_OK;
 }

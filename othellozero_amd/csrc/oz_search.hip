@@ -75,6 +75,10 @@ struct MctsDev {
     unsigned long long* eval_leaves;    // positions handed to the network so far (after cross-game de-duplication)
     int dedup;                 // k_compact: evaluate a board reached by several games in the same step once
     int batch_cap, batch_rot;  // k_compact (free-running driver): at most batch_cap slots (0: no cap), handed out in game order starting at game batch_rot
+    EvalCacheDev ec;           // the network's persistent evaluation cache (buckets == 0: none)
+    int* hit_count;            // leaves of this batch served from the cache: they take the pi / v rows G-1, G-2, ... (never the network's rows 0 ..)
+    int* hit_entry;            // [G] cache entry of hit h
+    unsigned batch_stamp;      // k_cache_insert: number of this batch (two inserts into one entry within a batch: the first wins)
 };
 
 __device__ __forceinline__ unsigned char* rec_ptr(const MctsDev& t, int g, int node) {
@@ -273,18 +277,78 @@ __global__ __launch_bounds__(64) void k_select(MctsDev t) {
 // not depend on its slot or on the batch (oz_net.hip), so results are bit-identical with or without this; it removes the
 // evaluations of the opening plies, where thousands of concurrent games still walk the same few positions.
 // The table (LDS, open addressing) holds the LOWEST game index with a given board: slots are the first occurrences in game order.
+// ---- the network's persistent evaluation cache (EvalCacheDev, oz_internal.h)
+__device__ __forceinline__ unsigned ec_bucket(const EvalCacheDev& c, uint64_t own, uint64_t opp, unsigned* way_pick) {
+    const uint64_t h = key_hash64(own ^ 0x6A09E667F3BCC909ULL, opp);
+    *way_pick = (unsigned)(h >> 40) & (OZ_EC_WAYS - 1);
+    return (unsigned)(h >> 8) & (c.buckets - 1);
+}
+// entry index of (own, opp), or -1 (one 64-byte line read)
+__device__ __forceinline__ int ec_find(const EvalCacheDev& c, uint64_t own, uint64_t opp) {
+    unsigned pick;
+    const unsigned b = ec_bucket(c, own, opp, &pick);
+    const ulonglong2* k = reinterpret_cast<const ulonglong2*>(c.keys) + (size_t)b * OZ_EC_WAYS;
+#pragma unroll
+    for (int w = 0; w < OZ_EC_WAYS; ++w) {
+        const ulonglong2 e = k[w];
+        if (e.x == own && e.y == opp) return (int)(b * OZ_EC_WAYS + w);
+    }
+    return -1;
+}
+// the (pi, v) rows of this batch's cache hits: hit h -> row G-1-h of the engine's pi / v arrays.  One thread per (hit, policy entry).
+__global__ __launch_bounds__(256) void k_cache_copy(MctsDev t) {
+    const int idx = blockIdx.x * 256 + threadIdx.x, h = idx >> 6, a = idx & 63;
+    if (h >= *t.hit_count) return;
+    const int e = t.hit_entry[h], row = t.G - 1 - h;
+    if (a < t.n2) t.pi[(size_t)row * t.n2 + a] = t.ec.pi[(size_t)e * t.n2 + a];
+    if (a == 0) t.v[row] = t.ec.v[e];
+}
+// after the network: every evaluated position (rows 0 .. batch_count-1) goes into the cache.  One wave per position.
+__global__ __launch_bounds__(256) void k_cache_insert(MctsDev t) {
+    const int lane = threadIdx.x & 63, slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= *t.batch_count) return;
+    const uint64_t own = t.batch_own[slot], opp = t.batch_opp[slot];
+    unsigned pick;
+    const unsigned b = ec_bucket(t.ec, own, opp, &pick);
+    const ulonglong2* k = reinterpret_cast<const ulonglong2*>(t.ec.keys) + (size_t)b * OZ_EC_WAYS;
+    ulonglong2 e = make_ulonglong2(1, 1);
+    if (lane < OZ_EC_WAYS) e = k[lane];
+    const uint64_t present = __ballot(lane < OZ_EC_WAYS && e.x == own && e.y == opp);
+    if (present) return;                                             // (two games evaluated the same board in one batch and the other one won)
+    const uint64_t empty = __ballot(lane < OZ_EC_WAYS && e.x == 0 && e.y == 0);
+    // candidate ways: the empty ones in order, else the way the hash picks; an entry takes ONE insert per batch (another position of this
+    // batch may be claiming the same way right now: the stamp arbitrates, the loser tries the next candidate or stays uncached)
+    uint64_t cand = empty ? empty : (1ULL << pick);
+    size_t entry = 0;
+    int mine = 0;
+    while (cand && !mine) {
+        entry = (size_t)b * OZ_EC_WAYS + (unsigned)oz_ctz(cand);
+        cand &= cand - 1;
+        if (lane == 0) mine = atomicExch(&t.ec.stamp[entry], t.batch_stamp) != t.batch_stamp;
+        mine = __shfl(mine, 0, 64);
+    }
+    if (!mine) return;
+    if (lane < t.n2) t.ec.pi[entry * t.n2 + lane] = t.pi[(size_t)slot * t.n2 + lane];
+    if (lane == 0) {
+        t.ec.v[entry] = t.v[slot];
+        t.ec.keys[entry * 2] = own; t.ec.keys[entry * 2 + 1] = opp;
+        atomicAdd(&t.ec.counters[2], 1ULL);
+    }
+}
+
 #define OZ_DEDUP_MAX_G 8192
 #define OZ_DEDUP_SLOTS 16384
 __device__ __forceinline__ unsigned dedup_hash(uint64_t own, uint64_t opp) {
     return (unsigned)(((own * 0x9E3779B97F4A7C15ull) ^ (opp * 0xC2B2AE3D27D4EB4Full)) >> 40) & (OZ_DEDUP_SLOTS - 1);
 }
 __global__ __launch_bounds__(1024) void k_compact(MctsDev t) {
-    __shared__ int wtot[16];
-    __shared__ int base_s;
+    __shared__ int wtot[16], whit[16];
+    __shared__ int base_s, hit_s;
     __shared__ int tab[OZ_DEDUP_SLOTS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool dedup = t.dedup && t.G <= OZ_DEDUP_MAX_G;
-    if (tid == 0) base_s = 0;
+    const bool cached = t.ec.buckets != 0;
+    if (tid == 0) { base_s = 0; hit_s = 0; }
     if (dedup) {
         for (int i = tid; i < OZ_DEDUP_SLOTS; i += 1024) tab[i] = -1;
         __syncthreads();
@@ -321,14 +385,23 @@ __global__ __launch_bounds__(1024) void k_compact(MctsDev t) {
                 h = (h + 1) & (OZ_DEDUP_SLOTS - 1);
             }
         }
-        const bool flag = leaf && first == g;                              // first occurrence: gets a slot
-        const uint64_t b = __ballot(flag);
-        const int pre = oz_popc(b & ((1ULL << lane) - 1ULL));
-        if (lane == 0) wtot[w] = oz_popc(b);
+        // first occurrence: gets a row -- a network slot, or (the board is in the network's evaluation cache) one of the hit rows G-1, G-2, ...
+        int entry = -1;
+        if (cached && leaf && first == g) entry = ec_find(t.ec, t.leaf_own[g], t.leaf_opp[g]);
+        const bool hit = entry >= 0;
+        const bool flag = leaf && first == g && !hit;
+        const uint64_t b = __ballot(flag), bh = __ballot(hit);
+        const int pre = oz_popc(b & ((1ULL << lane) - 1ULL)), preh = oz_popc(bh & ((1ULL << lane) - 1ULL));
+        if (lane == 0) { wtot[w] = oz_popc(b); whit[w] = oz_popc(bh); }
         __syncthreads();
-        int woff = 0, total = 0;
-        for (int i = 0; i < 16; ++i) { int x = wtot[i]; if (i < w) woff += x; total += x; }
-        const int base = base_s;
+        int woff = 0, total = 0, hoff = 0, htotal = 0;
+        for (int i = 0; i < 16; ++i) { int x = wtot[i], y = whit[i]; if (i < w) { woff += x; hoff += y; } total += x; htotal += y; }
+        const int base = base_s, hbase = hit_s;
+        if (hit) {
+            const int h = hbase + hoff + preh;
+            t.leaf_slot[g] = t.G - 1 - h;
+            t.hit_entry[h] = entry;
+        }
         if (flag) {
             const int slot = base + woff + pre;
             if (slot < cap) {
@@ -339,11 +412,11 @@ __global__ __launch_bounds__(1024) void k_compact(MctsDev t) {
                 t.leaf_slot[g] = 0;
                 t.leaf_status[g] = OZ_LEAF_WAIT;                            // no slot in this batch: the leaf is offered again in the next one
             }
-        } else if (leaf) {
+        } else if (leaf && !hit) {
             t.leaf_slot[g] = -1 - first;                                   // resolved below (the first occurrence may sit in a later chunk)
         }
         __syncthreads();
-        if (tid == 0) base_s = base + total;
+        if (tid == 0) { base_s = base + total; hit_s = hbase + htotal; }
         __syncthreads();
     }
     if (dedup) {
@@ -356,7 +429,12 @@ __global__ __launch_bounds__(1024) void k_compact(MctsDev t) {
                 else t.leaf_slot[g] = t.leaf_slot[first];
             }
     }
-    if (tid == 0) { const int used = base_s < cap ? base_s : cap; *t.batch_count = used; *t.eval_leaves += (unsigned long long)used; }
+    if (tid == 0) {
+        const int used = base_s < cap ? base_s : cap;
+        *t.batch_count = used; *t.eval_leaves += (unsigned long long)used;
+        *t.hit_count = hit_s;
+        if (cached) { atomicAdd(&t.ec.counters[0], (unsigned long long)(base_s + hit_s)); atomicAdd(&t.ec.counters[1], (unsigned long long)hit_s); }
+    }
 }
 
 // ---------------------------------------------------------------- K5 + K6: expand and backup
@@ -483,6 +561,7 @@ struct oz_mcts {
     // the tree kernels too when `profile` is on (oz_selfplay_profile)
     OzTimer timer{OZ_TREE_KERNELS};
     bool profile = false;
+    unsigned batch_no = 0;           // batches evaluated (stamp of the evaluation-cache inserts)
     // staging of oz_mcts_root_counts (called once per move by the drop-in agents): lives with the object
     int32_t* rc_counts = nullptr; uint64_t* rc_legal = nullptr; int32_t* rc_rc = nullptr;
 
@@ -542,6 +621,7 @@ static int mcts_create(oz_mcts** out, int n, int G, int node_cap, int edge_cap, 
     A(pi, (size_t)G * d.n2); A(v, G);
     A(last_value, G); A(last_vtype, G);
     A(stat, (size_t)G * OZ_NSTAT); A(error_flag, 1); A(eval_leaves, 1);
+    A(hit_count, 1); A(hit_entry, G);
 #undef A
     if (!rc) rc = m->alloc(&m->rc_counts, (size_t)G * 64);
     if (!rc) rc = m->alloc(&m->rc_legal, (size_t)G);
@@ -553,6 +633,7 @@ static int mcts_create(oz_mcts** out, int n, int G, int node_cap, int edge_cap, 
         hipMemsetAsync(d.stat, 0, sizeof(unsigned long long) * (size_t)G * OZ_NSTAT, m->stream);
         hipMemsetAsync(d.error_flag, 0, sizeof(int), m->stream);
         hipMemsetAsync(d.eval_leaves, 0, sizeof(unsigned long long), m->stream);
+        hipMemsetAsync(d.hit_count, 0, sizeof(int), m->stream);
         hipMemsetAsync(d.active, 0, G, m->stream);
         hipMemsetAsync(d.leaf_status, 0, sizeof(int) * G, m->stream);
         hipMemsetAsync(d.batch_count, 0, sizeof(int), m->stream);
@@ -599,8 +680,26 @@ static int check_error_flag(oz_mcts* m) {
     return OZ_OK;
 }
 
-// one lock-step simulation for every active game, leaves evaluated by `net` (all on m->stream)
 enum { TS_SELECT = 0, TS_COMPACT = 1, TS_NN = 2, TS_BACKUP = 3, TS_MOVE = 4 };
+// the evaluator's part of a batch: the rows of the leaves k_compact found in the network's evaluation cache (if the search uses one),
+// the network on the compacted batch (launched for up to max_count leaves), the evaluated positions into the cache
+static int eval_batch_async(oz_mcts* m, oz_net* net, int max_count, bool timed) {
+    MctsDev& d = m->d;
+    hipStream_t s = m->stream;
+    if (d.ec.buckets) hipLaunchKernelGGL(k_cache_copy, dim3((unsigned)(((long long)d.G * 64 + 255) / 256)), dim3(256), 0, s, d);
+    const long long ti = timed ? m->timer.begin(TS_NN, s) : -1;
+    if (int rc = oz_net_forward_device(net, d.batch_own, d.batch_opp, d.batch_count, max_count, d.pi, d.v, s)) { m->timer.cancel(ti); return rc; }
+    m->timer.end(ti, s);
+    if (d.ec.buckets) {
+        m->batch_no += 1;
+        if (m->batch_no == 0) m->batch_no = 1;               // 0 = "never written"
+        d.batch_stamp = m->batch_no;
+        hipLaunchKernelGGL(k_cache_insert, dim3((unsigned)((max_count + 3) / 4)), dim3(256), 0, s, d);
+    }
+    return OZ_OK;
+}
+
+// one lock-step simulation for every active game, leaves evaluated by `net` (all on m->stream)
 static int mcts_step_async(oz_mcts* m, oz_net* net, bool time_eval) {
     MctsDev& d = m->d;
     hipStream_t s = m->stream;
@@ -611,9 +710,7 @@ static int mcts_step_async(oz_mcts* m, oz_net* net, bool time_eval) {
     i = all ? m->timer.begin(TS_COMPACT, s) : -1;
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, d);
     m->timer.end(i, s);
-    i = (time_eval || all) ? m->timer.begin(TS_NN, s) : -1;
-    if (int rc = oz_net_forward_device(net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, s)) { m->timer.cancel(i); return rc; }
-    m->timer.end(i, s);
+    if (int rc = eval_batch_async(m, net, d.G, time_eval || all)) return rc;
     i = all ? m->timer.begin(TS_BACKUP, s) : -1;
     hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, s, d, 0);
     m->timer.end(i, s);
@@ -646,9 +743,7 @@ static int mcts_steps_async(oz_mcts* m, oz_net* net, int nsims, bool time_eval) 
         i = all ? m->timer.begin(TS_COMPACT, s) : -1;
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, d);
         m->timer.end(i, s);
-        i = (time_eval || all) ? m->timer.begin(TS_NN, s) : -1;
-        if (int rc = oz_net_forward_device(net, d.batch_own, d.batch_opp, d.batch_count, d.G, d.pi, d.v, s)) { m->timer.cancel(i); return rc; }
-        m->timer.end(i, s);
+        if (int rc = eval_batch_async(m, net, d.G, time_eval || all)) return rc;
     }
     const long long i = all ? m->timer.begin(TS_BACKUP, s) : -1;
     hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, s, d, 0);
@@ -1135,6 +1230,7 @@ OZ_API int oz_selfplay_create(oz_selfplay** out, const oz_selfplay_config* cfg, 
     OZ_REQUIRE(net->n == cfg->n, "network board size %d != %d", net->n, cfg->n);
     OZ_REQUIRE(net->max_batch >= cfg->num_games, "network max_batch %d < num_games %d", net->max_batch, cfg->num_games);
     OZ_REQUIRE(cfg->dedup == OZ_DEDUP_DEFAULT || cfg->dedup == OZ_DEDUP_ON || cfg->dedup == OZ_DEDUP_OFF, "oz_selfplay_config.dedup = %d", cfg->dedup);
+    OZ_REQUIRE(cfg->eval_cache == 0 || cfg->eval_cache == 1, "oz_selfplay_config.eval_cache = %d", cfg->eval_cache);
     OZ_REQUIRE(cfg->batch_cap == 0 || cfg->batch_cap >= 8, "oz_selfplay_config.batch_cap = %d (0 = none, else >= 8 leaves)", cfg->batch_cap);
     oz_selfplay* sp = new oz_selfplay();
     sp->cfg = *cfg; sp->net = net;
@@ -1173,6 +1269,12 @@ OZ_API int oz_selfplay_destroy(oz_selfplay* sp) {
     return OZ_OK;
 }
 
+// cfg.eval_cache: the engine's leaves go through the network's evaluation cache as it is NOW (oz_net_set_eval_cache may have been called,
+// or called again, since the engine was created)
+static void selfplay_attach_cache(oz_selfplay* sp) {
+    sp->m->d.ec = (sp->cfg.eval_cache && sp->net->ec.buckets && sp->net->ec.n2 == sp->m->d.n2) ? sp->net->ec : EvalCacheDev();
+}
+
 // one move round on m->stream: roots, `sims` lock-step simulations, move.  stagger_round >= 0: only slots whose start
 // offset (oz_selfplay_stagger) is still ahead of that round take part
 static int selfplay_round_async(oz_selfplay* sp, int sims, int stagger_round) {
@@ -1199,6 +1301,7 @@ OZ_API int oz_selfplay_run(oz_selfplay* sp, int rounds) {
     hipSetDevice(sp->m->device);
     OZ_REQUIRE(sp->mode != 2, "oz_selfplay_run after oz_selfplay_run_steps: moves are in progress (use one driver per engine)");
     sp->mode = 1;
+    selfplay_attach_cache(sp);
     for (int r = 0; r < rounds; ++r)
         if (int rc = selfplay_round_async(sp, sp->cfg.sims, -1)) return rc;
     return OZ_OK;
@@ -1219,6 +1322,7 @@ OZ_API int oz_selfplay_stagger(oz_selfplay* sp, int sims_pre) {
     OZ_REQUIRE(sp->mode == 0, "oz_selfplay_stagger must be the first driver call on an engine");
     OZ_REQUIRE(sp->cfg.refill, "oz_selfplay_stagger is for continuous self-play (cfg.refill = 1)");
     sp->mode = 1;
+    selfplay_attach_cache(sp);
     sp->stagger_period = sp->cfg.n * sp->cfg.n - 4;
     for (int r = 0; r + 1 < sp->stagger_period; ++r)
         if (int rc = selfplay_round_async(sp, sims_pre, r)) return rc;
@@ -1254,6 +1358,7 @@ OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
     MctsDev& d = m->d;
     if (sp->mode == 1) OZ_HIP(hipMemsetAsync(d.leaf_status, 0, sizeof(int) * d.G, m->stream));    // no simulation is pending after whole rounds
     sp->mode = 2;
+    selfplay_attach_cache(sp);
     const bool fuse = true;
     for (int i = 0; i < steps; ++i) {
         const bool all = m->profile;
@@ -1274,10 +1379,8 @@ OZ_API int oz_selfplay_run_steps(oz_selfplay* sp, int steps) {
         sp->batch_no += 1;
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, dc);
         m->timer.end(ti, s);
-        ti = m->timer.begin(TS_NN, s);
         // (the network's launches are sized for the cap: it picks its tile shapes from the batch it is asked to hold)
-        if (int rc = oz_net_forward_device(sp->net, d.batch_own, d.batch_opp, d.batch_count, cap ? cap : d.G, d.pi, d.v, s)) { m->timer.cancel(ti); return rc; }
-        m->timer.end(ti, s);
+        if (int rc = eval_batch_async(m, sp->net, cap ? cap : d.G, true)) return rc;
         if (!fuse || i == steps - 1) {
             ti = all ? m->timer.begin(TS_BACKUP, s) : -1;
             hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, s, d, 0);
@@ -1562,6 +1665,149 @@ OZ_API int oz_arena_results(oz_arena* a, int8_t* winner, int32_t* points, int32_
     if (n_moves) OZ_HIP(hipMemcpy(n_moves, a->d_nmoves, 4ull * G, hipMemcpyDeviceToHost));
     if (actions) OZ_HIP(hipMemcpy(actions, a->d_actions, (size_t)G * 128, hipMemcpyDeviceToHost));
     if (players) OZ_HIP(hipMemcpy(players, a->d_players, (size_t)G * 128, hipMemcpyDeviceToHost));
+    return OZ_OK;
+}
+
+// ================================================================ exchange step over RCCL (SURVEY.md 8(b) gather_examples(comm), 8(e))
+// The path's ONE collective -- the all-gather of the move records of the games a self-play batch completed -- behind the C ABI, for
+// hosts that are not Python (othellozero_amd/distributed.py does the same through torch.distributed).  RCCL is bound at run time
+// (dlopen of librccl.so.1: a process that already carries an RCCL -- PyTorch ships its own -- keeps using that one; no link-time
+// dependency for single-GPU users).  Replaces WorkerManager.get_results' list concatenation (workers.py:180-184) and the ssh / pickle
+// return path (workers.py:147-159).
+#include <dlfcn.h>
+namespace {
+struct Rccl {
+    struct Id { char b[OZ_COMM_ID_BYTES]; };                 // ncclUniqueId: 128 bytes, passed BY VALUE to ncclCommInitRank
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+int rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.h) return OZ_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names) if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) { oz_set_error("RCCL not available: %s", dlerror()); return OZ_ERR_STATE; }
+    Rccl r;
+    r.h = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
+        oz_set_error("the RCCL library lacks an expected symbol");
+        dlclose(h);
+        return OZ_ERR_STATE;
+    }
+    g_rccl = r;
+    return OZ_OK;
+}
+}  // namespace
+#define OZ_NCCL(call) do { int rc__ = (call); if (rc__ != 0) { oz_set_error("RCCL: %s (%s)", g_rccl.GetErrorString(rc__), #call); return OZ_ERR_HIP; } } while (0)
+enum { OZ_NCCL_UINT8 = 1, OZ_NCCL_INT64 = 4 };              // ncclDataType_t (rccl.h)
+
+struct oz_comm {
+    void* comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;
+    long long* d_counts = nullptr;        // [world + 1]: this rank's count, then every rank's
+    unsigned char *d_send = nullptr, *d_recv = nullptr;
+    long long cap = 0;                    // records per rank the two buffers hold
+    std::mutex mu;
+};
+
+OZ_API int oz_comm_unique_id(uint8_t* id) {
+    OZ_REQUIRE(id, "null id");
+    if (int rc = rccl_load()) return rc;
+    oz_current_device();
+    OZ_NCCL(g_rccl.GetUniqueId(id));
+    return OZ_OK;
+}
+
+OZ_API int oz_comm_create(oz_comm** out, const uint8_t* id, int rank, int world) {
+    OZ_REQUIRE(out && id, "null argument");
+    OZ_REQUIRE(world >= 1 && rank >= 0 && rank < world, "oz_comm_create: rank %d of %d", rank, world);
+    if (int rc = rccl_load()) return rc;
+    oz_comm* c = new oz_comm();
+    c->rank = rank; c->world = world; c->device = oz_current_device();
+    Rccl::Id uid;
+    memcpy(uid.b, id, OZ_COMM_ID_BYTES);
+    int nrc = g_rccl.CommInitRank(&c->comm, world, uid, rank);
+    if (nrc != 0) { oz_set_error("RCCL: %s (ncclCommInitRank, rank %d of %d)", g_rccl.GetErrorString(nrc), rank, world); delete c; return OZ_ERR_HIP; }
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipMalloc((void**)&c->d_counts, sizeof(long long) * (world + 1)) != hipSuccess) {
+        oz_set_error("oz_comm_create: stream / buffer allocation failed");
+        g_rccl.CommDestroy(c->comm);
+        delete c;
+        return OZ_ERR_HIP;
+    }
+    *out = c;
+    return OZ_OK;
+}
+
+OZ_API int oz_comm_destroy(oz_comm* c) {
+    if (!c) return OZ_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->comm) g_rccl.CommDestroy(c->comm);
+    hipFree(c->d_counts); hipFree(c->d_send); hipFree(c->d_recv);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return OZ_OK;
+}
+
+// COLLECTIVE: every rank of `comm` calls it with its own engine.  The records [first_record, records completed so far) of every rank's
+// engine, concatenated in rank order, into `out` (host, caller-owned, max_records long; per_rank[world] gets every rank's count).
+// Counts all-gather (8 bytes per rank) + ONE padded all-gather of 48-byte records, device to device out of the engines' HBM buffers.
+OZ_API int oz_selfplay_gather_records(oz_selfplay* sp, oz_comm* c, int64_t first_record, oz_record* out, int64_t max_records, int64_t* written,
+                                      int64_t* per_rank) {
+    OZ_REQUIRE(sp && c && written, "null argument");
+    OZ_REQUIRE(first_record >= 0, "first_record %lld", (long long)first_record);
+    std::lock_guard<std::mutex> lk(sp->mu);
+    std::lock_guard<std::mutex> lkc(c->mu);
+    hipSetDevice(sp->m->device);
+    OZ_REQUIRE(c->device == sp->m->device, "the communicator lives on device %d, the engine on device %d", c->device, sp->m->device);
+    OZ_HIP(hipStreamSynchronize(sp->m->stream));
+    unsigned long long total = 0;
+    OZ_HIP(hipMemcpy(&total, sp->gm.counters, 8, hipMemcpyDeviceToHost));
+    long long have = (long long)total < sp->gm.record_cap ? (long long)total : sp->gm.record_cap;
+    long long mine = have > first_record ? have - first_record : 0;
+    const int W = c->world;
+    OZ_HIP(hipMemcpyAsync(c->d_counts, &mine, sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    OZ_NCCL(g_rccl.AllGather(c->d_counts, c->d_counts + 1, 1, OZ_NCCL_INT64, c->comm, c->stream));
+    std::vector<long long> counts((size_t)W);
+    OZ_HIP(hipMemcpyAsync(counts.data(), c->d_counts + 1, sizeof(long long) * W, hipMemcpyDeviceToHost, c->stream));
+    OZ_HIP(hipStreamSynchronize(c->stream));
+    long long mx = 0, sum = 0;
+    for (int r = 0; r < W; ++r) { mx = counts[r] > mx ? counts[r] : mx; sum += counts[r]; if (per_rank) per_rank[r] = counts[r]; }
+    *written = 0;
+    if (mx == 0) return OZ_OK;
+    OZ_REQUIRE(out && sum <= max_records, "oz_selfplay_gather_records: %lld pooled records, room for %lld", sum, (long long)max_records);
+    if (mx > c->cap) {                                        // grow the padded send / receive buffers (kept with the communicator)
+        hipFree(c->d_send); hipFree(c->d_recv);
+        c->d_send = c->d_recv = nullptr; c->cap = 0;
+        const long long cap = mx + mx / 4 + 1024;
+        OZ_HIP(hipMalloc((void**)&c->d_send, (size_t)cap * sizeof(oz_record)));
+        OZ_HIP(hipMalloc((void**)&c->d_recv, (size_t)cap * sizeof(oz_record) * W));
+        c->cap = cap;
+    }
+    if (mine) OZ_HIP(hipMemcpyAsync(c->d_send, sp->gm.records + first_record, (size_t)mine * sizeof(oz_record), hipMemcpyDeviceToDevice, c->stream));
+    if (mine < mx) OZ_HIP(hipMemsetAsync(c->d_send + (size_t)mine * sizeof(oz_record), 0, (size_t)(mx - mine) * sizeof(oz_record), c->stream));
+    OZ_NCCL(g_rccl.AllGather(c->d_send, c->d_recv, (size_t)mx * sizeof(oz_record), OZ_NCCL_UINT8, c->comm, c->stream));
+    long long pos = 0;
+    for (int r = 0; r < W; ++r) {
+        if (counts[r]) OZ_HIP(hipMemcpyAsync(out + pos, c->d_recv + (size_t)r * mx * sizeof(oz_record), (size_t)counts[r] * sizeof(oz_record),
+                                             hipMemcpyDeviceToHost, c->stream));
+        pos += counts[r];
+    }
+    OZ_HIP(hipStreamSynchronize(c->stream));
+    *written = sum;
     return OZ_OK;
 }
 

@@ -85,6 +85,63 @@ def pooled_selfplay_records(engine, device, group=None):
     return allrec[np.lexsort((allrec["ply"], allrec["game_id"]))]
 
 
+# ---------------------------------------------------------------- the same exchange step behind the C ABI (no torch on the data path)
+class Comm:
+    """RCCL communicator owned by the library (oz_comm_*): what a non-Python host uses.  Rank 0 makes the 128-byte id, the host hands it
+    to every rank (here: any callable `share(id_bytes_or_None) -> id_bytes`, e.g. a torch.distributed broadcast), every rank creates
+    its communicator on its own device."""
+
+    def __init__(self, rank, world, share=None):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.require_gpu()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.check(lib.oz_comm_unique_id(ident))
+        raw = bytes(ident)
+        if world > 1:
+            assert share is not None, "a multi-rank communicator needs a way to hand rank 0's id to the other ranks"
+            raw = share(raw if rank == 0 else None)
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        _lib.check(lib.oz_comm_create(C.byref(self._h), ident, rank, world))
+
+    def gather_records(self, engine, first_record=0, max_records=None):
+        """COLLECTIVE: the records [first_record, ...) of every rank's engine in rank order -> (records, per-rank counts)"""
+        import ctypes as C
+        from . import _lib
+        cap = int(max_records if max_records is not None else self.world * max(engine.stats()["records"] - first_record, 0) * 2 + 65536)
+        out = np.zeros(cap, dtype=RECORD_DTYPE)
+        written, per = C.c_int64(), np.zeros(self.world, np.int64)
+        _lib.check(_lib.load().oz_selfplay_gather_records(engine._h, self._h, int(first_record), out.ctypes.data_as(C.c_void_p), cap,
+                                                          C.byref(written), _lib.p_i64(per)))
+        return out[:written.value], per
+
+    def close(self):
+        if self._h:
+            from . import _lib
+            _lib.load().oz_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def torch_share(device):
+    """`share` for Comm over an initialised torch.distributed group: broadcast of the 128 id bytes from rank 0"""
+    def share(raw):
+        t = torch.zeros(128, dtype=torch.uint8, device=device if dist.get_backend() != "gloo" else "cpu")
+        if raw is not None:
+            t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+    return share
+
+
 # ---------------------------------------------------------------- data-parallel training (SURVEY.md 8(f) item 2)
 class GradientAllReduce:
     """Averages a Trainer's gradient arena across ranks between backward and apply: ONE all-reduce per optimiser step
@@ -105,13 +162,19 @@ class GradientAllReduce:
         self.flat = torch.zeros(Trainer.arena_size(board_size, channels, in_channels), dtype=torch.float32, device=device)
         self.ptr = self.flat.data_ptr()
 
-    def __call__(self, trainer):
-        if not (dist.is_available() and dist.is_initialized()):
+    def __call__(self, trainer, failed=None):
+        """failed: the error this rank's forward / backward raised (None: the step is valid).  A failed rank poisons element 0 of its
+        arena with NaN and still takes part in the all-reduce; after it every rank sees the NaN and raises, so a step that is invalid
+        on one rank (the f16x2 range guard, a diverged tensor) ends the job on ALL ranks instead of leaving the others blocked."""
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(self.group) == 1 and not self.single_rank_collective):
+            if failed is not None:
+                raise failed
             return
         world = dist.get_world_size(self.group)
-        if world == 1 and not self.single_rank_collective:
-            return
-        trainer.sync()                                   # the library's stream wrote the arena
+        if failed is None:
+            trainer.sync()                               # the library's stream wrote the arena
+        else:
+            self.flat[0] = float("nan")
         if dist.get_backend(self.group) == "gloo" and self.flat.is_cuda:
             host = self.flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
@@ -121,6 +184,10 @@ class GradientAllReduce:
             self.flat.div_(world)
         if self.flat.is_cuda:
             torch.cuda.synchronize(self.flat.device)     # torch's stream -> before the library's Adam kernel reads it
+        if bool(torch.isnan(self.flat[0]).item()):
+            from ._lib import OZ_ERR_STATE, OzError
+            raise failed if failed is not None else OzError(OZ_ERR_STATE, "another rank's training step was invalid (its forward / backward raised): "
+                                                                          "the averaged gradients are poisoned, the step is not applied on any rank")
 
 
 def average_moving_statistics(weights, group=None):

@@ -177,9 +177,17 @@ def fit(trainer, own, opp, pi, z, batch_size=32, epochs=10, shuffle_seed=0, allr
             tot, seen = np.zeros(3), 0
             for s in range(0, N, batch_size):
                 idx = order[s:s + batch_size]
-                losses = trainer.forward_backward(own[idx], opp[idx], pi[idx], z[idx])
+                failed = None
+                try:
+                    losses = trainer.forward_backward(own[idx], opp[idx], pi[idx], z[idx])
+                except _lib.OzError as e:                        # e.g. the f16x2 range guard: this rank's step is invalid
+                    if allreduce is None:
+                        raise
+                    failed, losses = e, np.zeros(3)
                 if allreduce is not None:
-                    allreduce(trainer)
+                    # a rank that failed still joins the collective (with a poisoned arena), so no peer blocks in the all-reduce and
+                    # EVERY rank raises together
+                    allreduce(trainer, failed=failed)
                 trainer.apply()
                 tot += np.asarray(losses) * len(idx)            # keras reports the sample-weighted running mean
                 seen += len(idx)

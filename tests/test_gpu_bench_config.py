@@ -277,6 +277,38 @@ def test_free_running_driver_at_config2_size_equals_lock_step(oz, dedup, cap):
     assert a.tobytes() == b.tobytes()
 
 
+def test_evaluation_cache_at_config2_size_changes_no_record(oz):
+    """the network's persistent evaluation cache at the bench's own size: 4096 staggered 8x8 games x 100 simulations on the 512-filter
+    network (f16x2), free-running driver with the batch cap, de-duplication on: every game that completes with and without the cache has
+    the same records bit for bit, and root visit counts agree; a large share of the leaves never reaches the network"""
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    n, G, sims = 8, B, 100
+    net = NNetWrapper((n, n), num_channels_1=C, max_batch=G, seed=0, precision="f16x2")
+
+    def run(cache):
+        e = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=0, game_id_stride=G, q_mode=1, refill=True,
+                           record_cap=G * 16, dedup=True, batch_cap=3640, eval_cache=cache)
+        e.stagger(8)
+        e.run_steps(3 * sims + 60)
+        return e.records(), e.stats()
+    r0, s0 = run(False)
+    net.set_eval_cache(1 << 22)
+    r1, s1 = run(True)
+    assert s0["overflow"] == 0 and s1["overflow"] == 0
+    both = sorted(set(int(x) for x in np.unique(r0["game_id"])) & set(int(x) for x in np.unique(r1["game_id"])))
+    assert len(both) >= 150
+    order = lambda r: r[np.lexsort((r["ply"], r["game_id"]))]
+    a, b = order(r0[np.isin(r0["game_id"], both)]), order(r1[np.isin(r1["game_id"], both)])
+    assert a.tobytes() == b.tobytes()
+    st = net.eval_cache_stats()
+    # (steady-state self-play: the games sit at every ply, only the opening plies recur across games and generations -- a few per cent of
+    #  the lookups in a window this short, on top of the ~25 % the same-batch de-duplication already shares)
+    assert st["hits"] > 20000 and st["hits"] + st["inserts"] <= st["lookups"] and s1["leaves_evaluated"] < 0.9 * s1["expansions"]
+    assert s1["leaves_evaluated"] < s0["leaves_evaluated"]
+    assert s1["expansions"] >= s0["expansions"]              # hits need no batch slot: the same number of batches serves at least as many leaves
+
+
 def test_config3_last_rank_shard_at_full_size(oz):
     """BASELINE configs[2] (32768 games over 8 GPUs) as ONE rank sees it: the engine of rank 7 of 8 -- 4096 slots holding
     global game ids [28672, 32768), refills stepping by the job-wide 32768 -- at 100 sims/move: per-game RNG streams are keyed

@@ -854,6 +854,94 @@ def test_conv_pattern_tables_vs_float64(oz, n, cin, C, B, precision):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,driver", [("stub", "lockstep"), ("onn", "lockstep"), ("stub", "free"), ("onn", "free_capped")])
+def test_persistent_evaluation_cache_changes_nothing_but_the_work(oz, kind, driver):
+    """oz_selfplay_config.eval_cache: leaves whose board the network has evaluated before -- in an earlier batch, another game, a game that
+    ended long ago -- take (pi, v) from the network's HBM cache (the reference's _predict_cache, othelo_mcts.py:82-88, generalised).
+    Records, visit counts and per-game statistics are those of the engine without it; far fewer positions reach the network; new
+    weights (oz_net_commit) empty the cache"""
+    from othellozero_amd.NNet import NNetWrapper, StubNetWrapper
+    from othellozero_amd.training import SelfPlayEngine
+    from othellozero_amd.weights import init_weights
+    n, G, sims = 6, 96, 12
+
+    def network():
+        return (StubNetWrapper((n, n), 5, 0, max_batch=G) if kind == "stub" else
+                NNetWrapper((n, n), num_channels_1=256, max_batch=G, seed=4, precision="f16x2"))
+
+    def run(net, cache, dedup=True):
+        eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=77, first_game_id=0, game_id_stride=G, refill=True,
+                             record_cap=G * 4 * n * n, dedup=dedup, eval_cache=cache, batch_cap=64 if driver == "free_capped" else 0)
+        if driver == "lockstep":
+            eng.run(2 * n * n)
+        else:
+            eng.run_steps(2 * n * n * sims)
+        return eng.records(), eng.stats(), eng.last_counts()
+    net = network()
+    r0, s0, c0 = run(net, False)
+    net.set_eval_cache(1 << 16)
+    r1, s1, c1 = run(net, True)
+    st = net.eval_cache_stats()
+    def same_games(ra, rb):
+        """records of the games both runs completed, bit for bit (under a batch cap a hit frees a slot for another leaf: the cached run gets
+        further in the same number of batches, so it completes at least the games of the other)"""
+        ids_a, ids_b = set(int(x) for x in np.unique(ra["game_id"])), set(int(x) for x in np.unique(rb["game_id"]))
+        both = sorted(ids_a & ids_b)
+        assert len(both) >= 0.7 * max(len(ids_a), len(ids_b)) and len(both) >= G
+        return ra[np.isin(ra["game_id"], both)].tobytes() == rb[np.isin(rb["game_id"], both)].tobytes()
+    if driver == "free_capped":
+        assert same_games(r0, r1) and s1["games_completed"] >= s0["games_completed"]
+    else:
+        assert r1.tobytes() == r0.tobytes() and np.array_equal(c1, c0)
+        for k in ("simulations", "node_visits", "expansions", "terminal_hits", "moves", "games_completed"):
+            assert s1[k] == s0[k], k
+        assert s1["leaves_evaluated"] < s0["leaves_evaluated"]
+    assert st["hits"] > 0 and 0.9 * s1["leaves_evaluated"] < st["inserts"] <= s1["leaves_evaluated"]
+    # a second engine on the same network starts with a warm cache: (almost) every position of the same games is a hit; still the same records
+    r2, s2, _ = run(net, True, dedup=False)
+    assert same_games(r0, r2) and s2["leaves_evaluated"] < 0.25 * s0["leaves_evaluated"]
+    if kind == "onn":
+        # new weights: the cache is emptied by the commit -- the engine must reproduce a fresh network's games, not serve stale (pi, v)
+        w = init_weights(n, seed=9, channels=256)
+        net.set_weights(w)
+        assert net.eval_cache_stats()["entries"] >= 1 << 16
+        r3, _, _ = run(net, True)
+        fresh = NNetWrapper((n, n), num_channels_1=256, max_batch=G, weights=w, precision="f16x2")
+        r4, _, _ = run(fresh, False)
+        assert same_games(r4, r3) and not same_games(r0, r3)
+    # a tiny cache (one bucket row per 1024 positions): constant replacement, still exact
+    net2 = network()
+    net2.set_eval_cache(1)
+    r5, _, _ = run(net2, True)
+    assert same_games(r0, r5)
+
+
+@pytest.mark.gpu
+def test_c_abi_exchange_step_over_rccl_on_one_rank(oz):
+    """oz_comm_* / oz_selfplay_gather_records: the path's one collective behind the C ABI, RCCL bound at run time.  One GPU here, so a
+    one-rank communicator: id, communicator, counts all-gather, padded record all-gather -- the pooled records equal the engine's own
+    (the 8-rank run is the driver's; bench.py --gpus N repeats this check against the torch.distributed pool after its line)"""
+    from othellozero_amd.NNet import StubNetWrapper
+    from othellozero_amd.distributed import Comm
+    from othellozero_amd.training import SelfPlayEngine
+    n, G = 6, 32
+    eng = SelfPlayEngine(StubNetWrapper((n, n), 3, 0, max_batch=G), n, G, 8, 1.0, 1.0, 0.9, seed=5, refill=True, record_cap=G * 4 * n * n)
+    comm = Comm(0, 1)
+    rec, per = comm.gather_records(eng)                       # nothing completed yet: an empty gather must work
+    assert rec.size == 0 and per.tolist() == [0]
+    eng.run(n * n)
+    own = eng.records()
+    rec, per = comm.gather_records(eng)
+    assert per.tolist() == [own.size] and own.size > G * 20
+    assert rec[np.lexsort((rec["ply"], rec["game_id"]))].tobytes() == own.tobytes()
+    eng.run(8)
+    more = eng.stats()["records"]
+    tail, per = comm.gather_records(eng, first_record=own.size)   # only what completed since
+    assert per.tolist() == [more - own.size] and tail.size == more - own.size
+    comm.close()
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_rehearsal(tmp_path):
     """bench.py's N > 1 control flow (sharded game ids, barrier, max-over-ranks time, all-gather of records, one JSON line
     on rank 0) with two ranks on this one GPU over gloo -- the driver runs the real thing over RCCL on 8 GPUs"""

@@ -106,6 +106,39 @@ def test_f16x2_step_at_a_large_batch():
     assert lg == l2 and all(np.array_equal(g1[i], g2[i]) for i in g1)
 
 
+def test_f16x2_range_error_is_reported_once_and_the_trainer_recovers():
+    """an activation above the fp16 range makes the f16x2 step fail with OZ_ERR_STATE -- once: the sticky flag is cleared when
+    it has been reported, so after set_weights reloads good weights the same trainer steps again (and matches a fresh trainer bit for
+    bit); weights holding Inf fail loudly too instead of producing garbage power-of-two scales"""
+    from othellozero_amd import _lib
+    from othellozero_amd.trainer import Trainer
+    from othellozero_amd.weights import init_weights
+    n, C, B = 6, 256, 16
+    w = init_weights(n, seed=5, channels=C, randomize_all=True)
+    batch = _batch(n, B, 3)
+    make = lambda: Trainer(n, C, 2, max_batch=B, lr=1e-3, clipvalue=0.5, dropout=0.0, seed=1, precision="f16x2")
+    good = make(); good.set_weights(w)
+    want = good.forward_backward(*batch)
+    t = make()
+    big = [a.copy() for a in w]
+    big[2] = big[2] * 1e7                                     # gamma of the first BN: activations ~1e7
+    t.set_weights(big)
+    with pytest.raises(_lib.OzError) as e:
+        t.forward_backward(*batch)
+    assert e.value.code == _lib.OZ_ERR_STATE and "fp16 range" in str(e.value)
+    t.set_weights(w)
+    got = t.forward_backward(*batch)                          # the flag was cleared when it was reported
+    assert np.array_equal(np.asarray(got), np.asarray(want))
+    bad = [a.copy() for a in w]
+    bad[12][0, 0, 0, 0] = np.inf                              # conv3 kernel
+    t.set_weights(bad)
+    with pytest.raises(_lib.OzError) as e:
+        t.forward_backward(*batch)
+    assert e.value.code == _lib.OZ_ERR_STATE
+    t.set_weights(w)
+    assert np.array_equal(np.asarray(t.forward_backward(*batch)), np.asarray(want))
+
+
 def test_no_dropout_no_clip_and_determinism():
     ref, gpu = _pair(6, 128, 2, 16, seed=4, dropout=0.0, clip=0.0)
     own, opp, pi, z = _batch(6, 16, 12)

@@ -172,6 +172,20 @@ for g in range(7):
 # an empty rank must not break the gather
 pooled2 = tensor_to_records(gather_records(records_to_tensor(rec if rank == 0 else rec[:0])))
 assert pooled2.size == (sum(3 + g for g in range(4)))
+# data-parallel training: a rank whose step failed still joins the gradient all-reduce (poisoned arena) and EVERY rank raises (ADVICE r2)
+from othellozero_amd.distributed import GradientAllReduce
+class FakeTrainer:
+    def sync(self): pass
+ar = GradientAllReduce(6, 128, 2, device="cpu")
+ar.flat.fill_(float(rank + 1))
+ar(FakeTrainer())
+assert float(ar.flat[5]) == 1.5                     # the average of the two arenas
+err = _lib.OzError(_lib.OZ_ERR_STATE, "range guard") if rank == 1 else None
+try:
+    ar(FakeTrainer(), failed=err)
+    raise SystemExit("the poisoned all-reduce did not raise on rank %d" % rank)
+except _lib.OzError as e:
+    assert e.code == _lib.OZ_ERR_STATE and (("range guard" in str(e)) == (rank == 1))
 dist.barrier()
 print("RANK_OK", rank)
 """
