@@ -103,6 +103,19 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
     return r
 
 
+def measured_tree_bytes():
+    """HBM-side bytes per simulation of the tree kernels from the committed PMC profile (profiles/tree_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE over the 100 launches of one timed step, tools/profile_round.sh) -> (bytes with the gfx950 x2 read
+    correction, source label); falls back to SURVEY 8(d)'s algorithmic estimate when the file is absent"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "tree_traffic.json")))
+        t = tj["tree_side_bytes_per_sim"]
+        return float(t["total_with_x2_fetch"]), ("profiles/tree_traffic.json: measured FETCH_SIZE x2 + WRITE_SIZE per simulation (PMC, one timed step of a "
+                                                   "profiling run of this command; not re-measured in this run)")
+    except Exception:
+        return float(TREE_BYTES_PER_SIM), "SURVEY.md 8(d) algorithmic estimate (no measured profile found)"
+
+
 def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tables, driver="lockstep"):
     """every kernel of a move round against its own roof.  net_k / tree_k: {name: (ms_total, launches)} over `rounds` move
     rounds that evaluated `leaves` positions and ran `sims_done` simulations."""
@@ -117,10 +130,16 @@ def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tabl
         row = {"name": name, "ms_per_step": ms / rounds, "launches_per_step": cnt / rounds}
         sec = ms * 1e-3
         if name == "conv2" and tables:
-            # k_conv2_lut: per pixel 9 table rows of C fp32 read (L2 / Infinity Cache: the 363 MB table does not fit in L2,
-            # the pattern distribution is skewed) + one row written (HBM)
-            byts = leaves * n * n * (9 * C * 4 + C * 4)
-            row.update(kernel="k_conv2_lut" + ("_f32" if precision == "f32" else ""), bound="l2", achieved=byts / sec / 1e9, peak=PEAK_L2_GBPS, unit="GB/s")
+            # the table gather: bound by the bytes that miss L2 -- PMC (profiles/r3_conv2_gather_pmc.csv, tools/conv2_lut_probe.py): 7.1 M
+            # L2->fabric read requests of 128 B + the compulsory output row per pixel.  `achieved` = HBM-side bytes per launch from
+            # that profile (per leaf: 0.91 GB / 3640 read + n*n*C*4 written) / this run's time; the 363 MB table cannot live in the
+            # 256 MB Infinity Cache, so these are HBM bytes
+            per_leaf = 0.91e9 / 3640 * (n * n / 64.0) * (C / 512.0) + n * n * C * 4
+            byts = leaves * per_leaf
+            row.update(kernel=("k_conv2_lut_xcd" if C == 512 else "k_conv2_lut") + (" (fp32 rows)" if precision == "f32" else " (h2 rows)"), bound="hbm",
+                       achieved=byts / sec / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s",
+                       bytes_source="read bytes per leaf from profiles/r3_conv2_gather_pmc.csv (TCC_EA0_RDREQ x 128 B on mid-game positions), written bytes exact; "
+                                    "not re-measured in this run")
         elif name in flop:
             kern = "k_gemm_f32" if precision == "f32" else "k_gemm_h2"
             row.update(kernel=f"{kern} ({name})", bound="mfma", achieved=leaves * flop[name] / sec / 1e12, peak=peak_mm, unit="TFLOP/s")
@@ -133,6 +152,7 @@ def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tabl
         row["frac"] = row["achieved"] / row["peak"]
         out.append(row)
     tree_ms = sum(ms for name, (ms, cnt) in tree_k.items() if name != "network")
+    tree_bytes, tree_src = measured_tree_bytes()
     for name, (ms, cnt) in tree_k.items():
         if name == "network" or cnt == 0:
             continue
@@ -144,10 +164,11 @@ def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tabl
                   "compact": "k_compact", "expand_backup": "k_expand_backup (closing one of a round)", "roots_move": "k_sp_roots + k_sp_move"})
         out.append({"name": name, "kernel": label[name],
                     "ms_per_step": ms / rounds, "launches_per_step": cnt / rounds, "bound": "hbm (latency-bound integer work)",
-                    # the tree side as a whole moves ~1.3 KB of algorithmic HBM bytes per simulation; this kernel's share of it by time
-                    "achieved": sims_done * TREE_BYTES_PER_SIM / (tree_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": sims_done * TREE_BYTES_PER_SIM / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                    "note": "achieved / frac are those of the four tree kernels together"})
+                    # the tree side as a whole: measured HBM-side bytes per simulation (PMC profile) over the time of the tree kernels together
+                    "achieved": sims_done * tree_bytes / (tree_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": sims_done * tree_bytes / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                    "bytes_per_sim": tree_bytes, "bytes_source": tree_src,
+                    "note": "achieved / frac are those of the tree kernels together (latency-bound pointer chasing: one dependent HBM round trip per tree level)"})
     return out
 
 
@@ -155,9 +176,10 @@ def tree_side(sims_per_s):
     """the tree / rules side is latency-bound integer work; ~1.3 KB of algorithmic HBM bytes per simulation.
     The measured bytes (PMC FETCH_SIZE / WRITE_SIZE of k_select / k_expand_backup / k_compact over one timed move round) come
     from the committed profile, labelled as such."""
-    r = {"bytes_per_sim": TREE_BYTES_PER_SIM, "bytes_per_sim_source": "SURVEY.md 8(d) algorithmic estimate",
-         "achieved_GBps": sims_per_s * TREE_BYTES_PER_SIM / 1e9, "peak_GBps": PEAK_HBM_GBPS,
-         "frac": sims_per_s * TREE_BYTES_PER_SIM / (PEAK_HBM_GBPS * 1e9), "note": "not the binding roof; reported per SURVEY 8(d)"}
+    tree_bytes, tree_src = measured_tree_bytes()
+    r = {"bytes_per_sim": tree_bytes, "bytes_per_sim_source": tree_src, "algorithmic_bytes_per_sim": TREE_BYTES_PER_SIM,
+         "achieved_GBps": sims_per_s * tree_bytes / 1e9, "peak_GBps": PEAK_HBM_GBPS,
+         "frac": sims_per_s * tree_bytes / (PEAK_HBM_GBPS * 1e9), "note": "not the binding roof; reported per SURVEY 8(d)"}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "tree_traffic.json")))
         t = tj["tree_side_bytes_per_sim"]

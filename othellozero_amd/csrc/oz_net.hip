@@ -486,6 +486,73 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ f2 /*[B
     }
 }
 
+// the same sums in the same order with the f2 rows of HEADS_LP positions staged in LDS once (the loop above issues 8 broadcast global loads
+// per weight row; here they are LDS broadcasts and only the weight rows come from global memory)
+#define HEADS_LP 16
+__global__ __launch_bounds__(256) void k_heads_lds(const float* __restrict__ f2 /*[B][512]*/, const int* __restrict__ d_count,
+                                                   int A, const float* __restrict__ Wpi /*[512][A]*/, const float* __restrict__ bpi,
+                                                   const float* __restrict__ Wv /*[512]*/, const float* __restrict__ bv,
+                                                   float* __restrict__ pi, float* __restrict__ v) {
+    __shared__ __attribute__((aligned(16))) float xs[HEADS_LP][512];
+    __shared__ float part[4][HEADS_LP][64];
+    __shared__ float vpart_s[4][HEADS_LP];
+    const int b0 = blockIdx.x * HEADS_LP, lane = threadIdx.x & 63, w = threadIdx.x >> 6, count = *d_count;
+    if (b0 >= count) return;
+    for (int q = threadIdx.x; q < HEADS_LP * 128; q += 256) {                 // 16-byte pieces; rows beyond the batch repeat the last one (never stored)
+        const int p = q >> 7, c4 = (q & 127) * 4;
+        *reinterpret_cast<f32x4*>(&xs[p][c4]) = *reinterpret_cast<const f32x4*>(f2 + (size_t)(b0 + p < count ? b0 + p : count - 1) * 512 + c4);
+    }
+    __syncthreads();
+    const bool act = lane < A;
+    float logit[HEADS_LP], vp[HEADS_LP];
+#pragma unroll
+    for (int p = 0; p < HEADS_LP; ++p) { logit[p] = 0.f; vp[p] = 0.f; }
+#pragma unroll 4
+    for (int i4 = 0; i4 < 128; i4 += 4) {
+        float wgt[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wgt[j] = act ? Wpi[(size_t)(w * 128 + i4 + j) * A + lane] : 0.f;
+#pragma unroll
+        for (int p = 0; p < HEADS_LP; ++p) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[p][w * 128 + i4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) logit[p] = fmaf(x[j], wgt[j], logit[p]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float wv = Wv[w * 128 + lane * 2 + i];
+#pragma unroll
+        for (int p = 0; p < HEADS_LP; ++p) vp[p] = fmaf(xs[p][w * 128 + lane * 2 + i], wv, vp[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < HEADS_LP; ++p) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vp[p] += __shfl_xor(vp[p], off, 64);
+        part[w][p][lane] = logit[p];
+        if (lane == 0) vpart_s[w][p] = vp[p];
+    }
+    __syncthreads();
+    const float bl = act ? bpi[lane] : 0.f, bvv = bv[0];
+#pragma unroll
+    for (int q = 0; q < HEADS_LP / 4; ++q) {
+        const int p = w * (HEADS_LP / 4) + q;
+        const float sum = ((part[0][p][lane] + part[1][p][lane]) + part[2][p][lane]) + part[3][p][lane];
+        const float lg = act ? sum + bl : -INFINITY;
+        float mx = lg;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float e = act ? expf(lg - mx) : 0.f;
+        float s = e;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (b0 + p < count) {
+            if (act) pi[(size_t)(b0 + p) * A + lane] = e / s;
+            if (lane == 0) v[b0 + p] = tanhf(((vpart_s[0][p] + vpart_s[1][p]) + vpart_s[2][p]) + vpart_s[3][p] + bvv);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- stub evaluator (test nets)
 __global__ __launch_bounds__(64) void k_stub(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
                                              const int* __restrict__ d_count, int n, uint64_t salt, uint64_t keep,
@@ -643,6 +710,7 @@ struct OnnNet : oz_net {
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Mid>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Mid::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Thin>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Thin::LDS));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Thin4w>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Thin4w::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small2::LDS));
             OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Thin2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Thin2::LDS));
             h2_attr_set = true;
@@ -669,6 +737,13 @@ struct OnnNet : oz_net {
     // measured SLOWER (one position: 0.152 -> 0.186 ms).  Bit-identical either way (tools/pp_race_check.py compares networks of both kinds).
     template <typename CF3, typename CF2, typename... Args> int launch_small(Args... args) {
         return max_batch <= 32 ? launch_gemm_h2<CF2>(args...) : launch_gemm_h2<CF3>(args...);
+    }
+
+    // policy / value heads: batches stage the f2 rows of 16 positions in LDS; few positions (the latency path) keep the 8-position kernel
+    // (same sums in the same order either way)
+    void launch_heads(int max_count, const int* d_count, float* d_pi, float* d_v, hipStream_t s) {
+        if (max_count >= 64) hipLaunchKernelGGL(k_heads_lds, dim3((max_count + HEADS_LP - 1) / HEADS_LP), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        else hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
     }
 
     // conv1 + conv2 as the table gather-sum: one table slice per XCD at 512 filters, the thread-per-(pixel, 8 channels) kernel otherwise
@@ -839,10 +914,12 @@ struct OnnNet : oz_net {
         mark(4, false);
         mark(5, true);
         // fc2: one position has 4 blocks of 32 k-tiles -> small networks split k 8 ways too, medium ones 4 ways (from max_batch)
-        if (int rc = launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, small ? 8 : max_batch <= 512 ? 4 : 1)) return rc;
+        // (large networks: one k-slice on the four-wave form of the thin tile, bit-identical to the two-wave one)
+        if (int rc = max_batch > 512 ? launch_gemm_h2<H2Thin4w>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, 1)
+                                    : launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, small ? 8 : max_batch <= 512 ? 4 : 1)) return rc;
         mark(5, false);
         mark(6, true);
-        hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        launch_heads(max_count, d_count, d_pi, d_v, s);
         mark(6, false);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
@@ -896,7 +973,7 @@ struct OnnNet : oz_net {
         if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
         mark(5, false);
         mark(6, true);
-        hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        launch_heads(max_count, d_count, d_pi, d_v, s);
         mark(6, false);
         OZ_HIP(hipGetLastError());
         return OZ_OK;

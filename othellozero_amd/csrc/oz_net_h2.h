@@ -103,6 +103,11 @@ typedef H2Cfg<1, 2, 2, 2> H2Thin2;    // 64 x 128, 2 waves, two stages
 // but SLOWER on the 16-way split-K launches of one-position networks (9 k-tiles per block) -- oz_net.hip picks per network.
 typedef H2Cfg<2, 2, 2, 2, 3> H2Small; // 128 x 128, 3 x 32 KB of LDS
 typedef H2Cfg<1, 2, 2, 2, 3> H2Thin;  // dense layers (M = batch): 64 x 128, 2 waves -> 512 / 256 blocks at B = 4096; 3 x 24 KB
+// fc2 at large batches (one k-slice, 228 blocks of 32 k-tiles: at most one block per CU): the same 64 x 128 tile on FOUR waves of 32 x 64 --
+// every SIMD has a wave and the MFMA section of a k-tile halves.  Same accumulation order per output element as H2Thin: bit-identical.
+// Measured at 3640 positions (tools/tail_layers_probe.py, round 3): H2Thin 40.2 us, six stages instead of three 41.4 (not DMA-latency
+// bound), a 32 x 128 tile on two waves (twice the blocks) 33.5, this 27.8.
+typedef H2Cfg<2, 2, 1, 2, 3> H2Thin4w;
 
 struct H2Geom {
     int Hin, Hout, pad, Cin, taps;        // taps 9 (3x3 conv) or 1 (dense, Hin = Hout = 1)
@@ -427,6 +432,7 @@ __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restric
             ra[t] = *reinterpret_cast<const f32x4*>(rec);
             rb[t] = *reinterpret_cast<const f32x4*>(rec + 32);
         }
+        __builtin_amdgcn_sched_barrier(0);                    // all 18 record loads in flight before the first add (-6 %: 0.303 -> 0.285 ms; 1, 4 or 8 pixel groups per thread: +-0 or slower)
         f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 9; ++t) { lo += ra[t]; hi += rb[t]; }

@@ -8,10 +8,10 @@ dispatch order (N = steps x sims; run bench.py with --no-compare so that nothing
 The untimed stagger / warm-up launches before it run on partly filled batches; the `trace` summary lists both windows.
   python tools/summarize_prof.py traffic <pmc_by_shape_csv> <out_json> <precision> <kernel substring> <grid_threads> [layer=conv2] [leaves_per_launch]
 
-`trace`   : per (kernel, grid) averages from *_kernel_trace.csv; the OthelloNN layers are recognised by grid size
-            (launched for 4096 slots) and get their algorithmic fp32 TFLOP/s for `leaves_per_launch` positions actually
-            evaluated per launch -- take it from the bench line of the same run (leaves_evaluated_rank0 / roofline.launches;
-            ~3760 in whole-game self-play, because ~8 % of the simulations end on finished boards); default 4096 = full batches.
+`trace`   : per (kernel, grid, layer) averages from *_kernel_trace.csv; the OthelloNN layers are recognised by the ORDER of the launches
+            inside a forward (k_lut_ids / k_conv1* starts one) and -- in the timed window -- get their algorithmic fp32 TFLOP/s and
+            fraction of the matrix peak for `leaves_per_launch` positions per launch: take it from the bench line of the same run
+            (leaves_evaluated_rank0 / roofline.launches; 3640 under bench.py's batch cap); default 4096 = full batches.
 `pmc`     : per (kernel, grid, counter) per-launch averages from one or more *_counter_collection.csv (separate passes).
   python tools/summarize_prof.py tree   <pmc_by_shape_csv> <out_json> <simulations_per_launch>
 `tree`    : FETCH_SIZE / WRITE_SIZE of k_select / k_expand_backup / k_compact per simulation -> profiles/tree_traffic.json
@@ -44,8 +44,57 @@ def find(d, suffix):
     return hits[-1]
 
 
+PEAK = {"k_gemm_h2": 2500.0, "k_gemm_f32": 157.3}          # dense fp16 / fp32 matrix peaks, TFLOP/s (MI355X_MICROARCH.md)
+NET_ORDER_TABLES = ("conv3", "conv4", "fc1", "fc2")          # GEMM launches of one forward, in launch order, conv1 + conv2 from the tables
+NET_ORDER_GEMM = ("conv2", "conv3", "conv4", "fc1", "fc2")   # ... with conv2 as a GEMM (oz_net_set_tables 0 / 1)
+
+
+def label_layers(records):
+    """records: dispatch-ordered (kernel, ...) tuples.  Returns one layer name (or "") per record: a forward starts at k_lut_ids / k_conv1*,
+    whether it uses the table gather decides which GEMM comes first, and the n-th k_gemm launch after the start is the n-th layer of
+    OthelloNN -- launch ORDER, not grid size, so every batch size, tile choice and board is labelled the same way.  The table build at
+    oz_net_commit (nine GEMMs in a row without a forward start) stays unlabelled."""
+    out = [""] * len(records)
+    order, idx, open_fw = None, 0, False
+    for i, k in enumerate(records):
+        if k.startswith("k_lut_ids") or k.startswith("k_conv1"):
+            open_fw, idx = True, 0
+            order = None if k.startswith("k_lut_ids") else NET_ORDER_GEMM      # k_lut_ids: decided by what follows
+            continue
+        if not open_fw:
+            continue
+        if k.startswith("k_conv2_lut"):
+            order = NET_ORDER_TABLES
+            out[i] = "conv1+conv2 (table gather)"
+            continue
+        if k.startswith("k_gemm"):
+            if order is None:
+                order = NET_ORDER_GEMM                        # k_lut_ids followed by a GEMM: conv1 from its table inside conv2's gather
+            if idx < len(order):
+                out[i] = order[idx]
+            idx += 1
+            if idx >= len(order):
+                open_fw = False
+        elif k.startswith("k_heads"):
+            open_fw = False
+    return out
+
+
+DESCENT = ("k_select", "k_backup_select", "k_advance", "k_backup_advance")      # the tree launch that opens a batch
+
+
+def batch_ids(kernels):
+    """dispatch-ordered kernel names -> the running number of the network batch each launch belongs to (a batch opens with its descent kernel)"""
+    out, b = [], 0
+    for k in kernels:
+        if k in DESCENT:
+            b += 1
+        out.append(b)
+    return out
+
+
 def trace(d, out, header, leaves=LEAVES, last_n=0):
-    rows = defaultdict(list)
+    recs = []
     with open(find(d, "_kernel_trace.csv")) as f:
         for r in sorted(csv.DictReader(f), key=lambda r: int(r["Dispatch_Id"])):
             k = short(r["Kernel_Name"])
@@ -53,42 +102,41 @@ def trace(d, out, header, leaves=LEAVES, last_n=0):
                 continue
             grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
             wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
-            rows[(k, grid, wg, int(r["LDS_Block_Size"]), int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"]),
-                  int(r["Scratch_Size"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    # name the GEMM launches.  precision f16x2 (k_gemm_h2): by tile configuration and grid at 4096 leaves per launch;
-    # precision f32: the gemm shapes ordered by total time (conv2 > conv3 > conv4 > fc1 > fc2 holds for this net)
-    names = {}
-    h2 = {("H2BigPPLut", 1048576): "conv2", ("H2BigPP>", 1048576): "conv2", ("H2MidPP", 786432): "conv3", ("H2BigPP>", 262144): "conv4",
-          ("H2BigPP>", 131072): "fc1", ("H2Cfg<1, 2, 2, 2>", 32768): "fc2",
-          # precision f32: k_gemm_f32, 128 x 128 tiles, 256 threads
-          ("k_gemm_f32", 2097152): "conv2", ("k_gemm_f32", 1179648): "conv3", ("k_gemm_f32", 524288): "conv4",
-          ("k_gemm_f32", 65536): "fc1", ("k_gemm_f32", 32768): "fc2"}
-    for k in rows:
-        for (sub, grid), lay in h2.items():
-            if "k_gemm" in k[0] and sub in k[0] and k[1] == grid and len(rows[k]) >= 50:
-                names[k] = lay
-    if not names:
-        gemm = sorted((k for k in rows if "k_gemm" in k[0] and len(rows[k]) >= 50), key=lambda k: -sum(rows[k]))
-        for k, lay in zip(gemm, ("conv2", "conv3", "conv4", "fc1", "fc2")):
-            names[k] = lay
+            recs.append((k, grid, wg, int(r["LDS_Block_Size"]), int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"]), int(r["Scratch_Size"]),
+                         int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    layers = label_layers([r[0] for r in recs])
+    bid = batch_ids([r[0] for r in recs])
+    first_timed = (bid[-1] - last_n + 1) if last_n and bid else 0           # the timed region = the last `last_n` batches of the run
+    rows, timed = defaultdict(list), defaultdict(list)
+    for r, lay, b in zip(recs, layers, bid):
+        rows[r[:7] + (lay,)].append(r[7])
+        if last_n and b >= first_timed:
+            timed[r[:7] + (lay,)].append(r[7])
     with open(out, "w") as f:
         f.write(f"# {header}\n")
-        f.write(f"# per (kernel, grid) averages from the kernel trace; {leaves:g} leaves evaluated per launch; TFLOP_per_s = ALGORITHMIC fp32 FLOP "
-                "(precision f16x2 executes 3x that on the matrix pipe)\n")
+        f.write(f"# per (kernel, grid, layer) averages from the kernel trace; layer = position of the launch inside its forward (launch order); "
+                f"{leaves:g} leaves evaluated per launch in the timed window; TFLOP_per_s = ALGORITHMIC fp32 FLOP (precision f16x2 executes 3x that on "
+                "the matrix pipe); frac = TFLOP_per_s / the dense matrix peak of the kernel's arithmetic (2500 fp16, 157.3 fp32)\n")
         if last_n:
-            f.write(f"# timed_* columns: the last {last_n} launches of the kernel in dispatch order = bench.py's timed region (full batches); "
+            f.write(f"# timed_* columns: the launches of the row inside the last {last_n} network batches of the run = bench.py's timed region (full batches); "
                     "calls / avg_us / total_ms: every launch of the run incl. the untimed stagger and warm-up rounds (partly filled batches) -- "
                     "the population rocprofv3's own --stats file averages over\n")
-        f.write("kernel,grid_threads,wg,lds_bytes,vgpr,agpr,scratch,calls,avg_us,min_us,max_us,total_ms,timed_calls,timed_avg_us,layer,algorithmic_TFLOP_per_s\n")
+        f.write("kernel,grid_threads,wg,lds_bytes,vgpr,agpr,scratch,calls,avg_us,min_us,max_us,total_ms,timed_calls,timed_avg_us,layer,leaves_per_launch,"
+                "algorithmic_TFLOP_per_s,frac\n")
         for k in sorted(rows, key=lambda k: -sum(rows[k])):
             t = rows[k]
             avg = sum(t) / len(t)
-            lay = names.get(k, "")
-            tw = t[-last_n:] if last_n and len(t) >= last_n else []
+            lay = k[7]
+            tw = timed.get(k, [])
             tavg = sum(tw) / len(tw) if tw else avg
-            tf = f"{FLOP[lay] * leaves / (tavg * 1e-9) / 1e12:.1f}" if lay else ""
+            tf = frac = lv = ""
+            if lay in FLOP and tw:                            # a layer of the timed window: its leaves per launch are known
+                val = FLOP[lay] * leaves / (tavg * 1e-9) / 1e12
+                peak = next((p for n, p in PEAK.items() if k[0].startswith(n)), None)
+                tf, lv = f"{val:.1f}", f"{leaves:g}"
+                frac = f"{val / peak:.3f}" if peak else ""
             f.write(f"\"{k[0]}\",{k[1]},{k[2]},{k[3]},{k[4]},{k[5]},{k[6]},{len(t)},{avg / 1e3:.1f},{min(t) / 1e3:.1f},"
-                    f"{max(t) / 1e3:.1f},{sum(t) / 1e6:.1f},{len(tw) if tw else ''},{tavg / 1e3 if tw else 0:.1f},{lay},{tf}\n")
+                    f"{max(t) / 1e3:.1f},{sum(t) / 1e6:.1f},{len(tw) if tw else ''},{tavg / 1e3 if tw else 0:.1f},{lay},{lv},{tf},{frac}\n")
 
 
 def pmc(out, header, dirs, last_n=0):
@@ -96,14 +144,23 @@ def pmc(out, header, dirs, last_n=0):
     for d in dirs:
         per = defaultdict(list)
         with open(find(d, "_counter_collection.csv")) as f:
-            for r in sorted(csv.DictReader(f), key=lambda r: int(r["Dispatch_Id"])):
-                k = short(r["Kernel_Name"])
-                if k.startswith("__amd") or "at::" in k or "elementwise" in k:
-                    continue
-                per[(k, int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+            rows = [r for r in sorted(csv.DictReader(f), key=lambda r: int(r["Dispatch_Id"]))
+                    if not (short(r["Kernel_Name"]).startswith("__amd") or "at::" in r["Kernel_Name"] or "elementwise" in r["Kernel_Name"])]
+        # one row per (dispatch, counter): label the dispatches by launch order, then fan the label out to their counter rows
+        disp = []
+        for r in rows:
+            if not disp or disp[-1][0] != r["Dispatch_Id"]:
+                disp.append((r["Dispatch_Id"], short(r["Kernel_Name"])))
+        lab = dict(zip((x[0] for x in disp), label_layers([x[1] for x in disp])))
+        bid = dict(zip((x[0] for x in disp), batch_ids([x[1] for x in disp])))
+        first_timed = (max(bid.values()) - last_n + 1) if last_n and bid else 0     # the timed region = the last `last_n` batches of the run
+        for r in rows:
+            if bid[r["Dispatch_Id"]] < first_timed:
+                continue
+            k = short(r["Kernel_Name"])
+            name = k + (f" [{lab[r['Dispatch_Id']]}]" if lab.get(r["Dispatch_Id"]) else "")
+            per[(name, int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
         for key, vals in per.items():
-            if last_n and len(vals) >= last_n:
-                vals = vals[-last_n:]                       # the timed region's launches only
             acc[key][0] += sum(vals)
             acc[key][1] += len(vals)
     with open(out, "w") as f:
@@ -124,7 +181,7 @@ def tree(src, out, games):
     with open(src) as f:
         for r in csv.DictReader(l for l in f if not l.startswith("#")):
             vals[r["kernel"]][r["counter"]] = float(r["avg_per_launch"])
-    j = {"round": 2, "simulations_per_launch": float(games), "algorithmic_bytes_per_sim": 1300, "source": src, "kernels": {}}
+    j = {"round": 3, "simulations_per_launch": float(games), "algorithmic_bytes_per_sim": 1300, "source": src, "kernels": {}}
     tot_raw = tot_w = 0.0
     # (k_backup_select = expand + backup of the previous simulation fused with the descent: 99 of the 100 launches of a round;
     #  k_select / k_expand_backup = the first descent and the closing backup of a round, one launch each)
@@ -149,7 +206,7 @@ def traffic(src, out, precision, kernel_sub, grid, layer="conv2", leaves=LEAVES)
     vals = {}
     with open(src) as f:
         for r in csv.DictReader(l for l in f if not l.startswith("#")):
-            if kernel_sub in r["kernel"] and int(r["grid_threads"]) == int(grid):
+            if kernel_sub in r["kernel"] and (int(grid) <= 0 or int(r["grid_threads"]) == int(grid)):
                 vals[r["counter"]] = float(r["avg_per_launch"])
     fetch = vals["FETCH_SIZE"] * 1024 * 2
     write = vals["WRITE_SIZE"] * 1024
@@ -157,7 +214,7 @@ def traffic(src, out, precision, kernel_sub, grid, layer="conv2", leaves=LEAVES)
     alg = {"conv2": 64 * 2048 + 64 * 2048 + 9 * 512 * 512 * 4 / leaves, "conv3": 64 * 2048 + 36 * 2048 + 9 * 512 * 512 * 4 / leaves}[layer]
     if precision == "f32" and layer == "conv2":
         alg = 262144.0 + 18 * 512 * 512 * 4 / LEAVES           # as first committed: the transposed copy of the kernel counted too
-    j = {"round": 2, "precision": precision, "kernel": f"{kernel_sub} {layer}", "leaves_per_launch": leaves,
+    j = {"round": 3, "precision": precision, "kernel": f"{kernel_sub} {layer}", "leaves_per_launch": leaves,
          "fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
          "hbm_bytes_per_leaf": (fetch + write) / leaves,
          "algorithmic_bytes_per_leaf": alg,
