@@ -314,6 +314,60 @@ def parity_sample(net, eng, n, channels, call_size, check=384):
             "checker": "oracle/nn_numpy.py (float64 restatement of Net/OthelloNN.py:42-56)"}
 
 
+def live_traffic(args, layer, grid_leaves, timeout_s=150):
+    """roofline.traffic measured IN this run: two child processes -- `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE`,
+    separate passes as MI355X_MICROARCH.md prescribes, never combined with another trace domain -- each running this bench with one timed
+    step (100 batches of the same capped size; secondary legs off), and the dominant kernel's counters averaged over the launches of
+    that step.  FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads (x2).
+    Returns (bytes per launch, description) or (None, reason).  The children are ordinary child processes of this one."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="oz_bench_pmc_")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--stagger-sims", "8", "--no-compare", "--no-cpu-baseline",
+                   "--precision", args.precision, "--games", str(args.games), "--sims", str(args.sims), "--board", str(args.board),
+                   "--channels", str(args.channels), "--driver", args.driver, "--batch-cap", str(args.batch_cap), "--dedup", args.dedup]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+            files = glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+            # the dominant launch of the timed step: the layer-th GEMM after each k_lut_ids, in the last `sims` forwards (launch order, as
+            # tools/summarize_prof.py labels them)
+            rows = sorted(csv.DictReader(open(files[0])), key=lambda x: int(x["Dispatch_Id"]))
+            picked, order, nth = [], -1, 0
+            want = {3: 1, 2: 1}[layer]                           # conv3 is the first GEMM of a forward that uses the tables; conv2 the first without
+            for x in rows:
+                k = x["Kernel_Name"]
+                if "k_lut_ids" in k or "k_conv1" in k:
+                    nth = 0
+                elif "k_gemm" in k:
+                    nth += 1
+                    if nth == want and x["Counter_Name"] == counter:
+                        picked.append(float(x["Counter_Value"]))
+            picked = picked[-args.sims:]
+            if not picked:
+                return None, f"no dominant-kernel rows in the {counter} pass"
+            vals[counter] = sum(picked) / len(picked)
+    except Exception as e:                                       # noqa: BLE001 -- a measurement aid, never a reason to fail the bench
+        return None, f"live PMC pass failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    byts = vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024
+    return byts, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate child runs of bench.py --steps 1 --stagger-sims 8 "
+                  f"--no-compare), average over the {args.sims} launches of the timed step at {grid_leaves} leaves per launch; FETCH_SIZE x2 (gfx950) "
+                  f"= {vals['FETCH_SIZE'] * 2048 / 1e9:.3f} GB read + {vals['WRITE_SIZE'] * 1024 / 1e9:.3f} GB written")
+
+
 def config5_arena(channels, precision, plies, games=512, sims=800, sample=2):
     """BASELINE configs[4]: arena evaluation (agents.py:44-84, duel_between_agents) -- `games` parallel 8x8 games, `sims` simulations per
     move per agent, two REAL networks (seeds 0 / 1: best vs candidate), deterministic play (temperature 0, RNG_TIE stream), bounded
@@ -485,6 +539,7 @@ def main():
                          "(-1 = --sims: the staggered plies are ordinary self-play at full strength; 0 = no stagger: all games start "
                          "at ply 0 and none completes for ~60 move rounds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic in this run")
     ap.add_argument("--no-dedup-compare", "--no-compare", dest="no_compare", action="store_true",
                     help="skip the secondary measurements (kernels, exact fp32, 6x6, de-duplication on, conv2 as a GEMM, drop-in, parity sample): profiling runs")
     ap.add_argument("--dedup", default="off", choices=["off", "on"],
@@ -758,6 +813,17 @@ def run_rank(args, rank, world, local_rank, t_proc):
             out["kernels_note"] = (f"HIP events around every launch, {rounds} further move rounds of the same engine after the timed region "
                                    "(events between launches add a few us each: the sum is slightly above ms_per_step)")
             wall["kernels_s"] = round(time.perf_counter() - t_sec, 2)
+        if secondary and not args.no_live_traffic:
+            # roofline.traffic: measured now (PMC passes in child processes), not taken from the committed profile
+            t_sec = time.perf_counter()
+            byts, how = live_traffic(args, layer, cap_main or G)
+            if byts is not None:
+                out["roofline"]["traffic_from_committed_profile"] = out["roofline"]["traffic"]
+                out["roofline"]["traffic"] = byts * (d["leaves_evaluated"] / max(dom_launches, 1)) / float(cap_main or G)
+                out["roofline"]["traffic_source"] = how
+            else:
+                out["roofline"]["live_traffic_error"] = how
+            wall["live_traffic_s"] = round(time.perf_counter() - t_sec, 2)
         if secondary and not args.no_cpu_baseline:
             t_sec = time.perf_counter()
             ps = parity_sample(net, eng, n, args.channels, cap_main or G)

@@ -999,7 +999,8 @@ def test_bench_single_rank_contract(tmp_path):
     # the whole metric: the slots are staggered before the timed region, so games complete in ANY window and their records are pooled
     assert out["games_completed"] > 0 and out["games_per_s"] > 0 and out["pooled_records"] >= 40 * out["games_completed"]
     assert out["slot_ply_spread_rank0"][1] - out["slot_ply_spread_rank0"][0] >= 40
-    assert rf["traffic_source"] is None or "profiles/" in rf["traffic_source"]
+    # roofline.traffic is measured in the run (two rocprofv3 --pmc child passes); the committed profile is only the fallback
+    assert "measured in this run" in (rf["traffic_source"] or "") and rf["traffic"] > 0, (rf.get("live_traffic_error"), rf["traffic_source"])
     # the exact-fp32 leg, the 6x6 config and the per-kernel table ride in the same line
     e32 = out["exact_fp32"]
     assert e32["value"] > 0 and e32["dtype"] == "f32" and e32["roofline"]["peak"] == 157.3 and 0 < e32["roofline"]["frac"] < 1

@@ -242,3 +242,48 @@ def test_preferred_batch_cap_makes_conv3_whole_grid_rounds():
         assert (-(-(cap + 1) * (n - 2) ** 2 // 256) * (C // 256)) > tiles          # one more leaf would open another round
     assert preferred_batch_cap(6, 4096, 512) == 0 and preferred_batch_cap(8, 8192, 512) == 0
     assert preferred_batch_cap(8, 512, 512) == 0 and preferred_batch_cap(8, 4096, 128) == 0
+
+
+def test_profile_summaries_label_layers_by_launch_order(tmp_path):
+    """tools/summarize_prof.py: the OthelloNN layers are labelled by the ORDER of the GEMM launches inside a forward, not
+    by hard-coded grid sizes; the timed columns come from the launches inside the last N network batches only -- a kernel shape that only
+    the untimed stagger phase launched gets no timed average and no TFLOP/s (round 2 printed an impossible 1976 TFLOP/s for it)"""
+    import csv
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("summarize_prof", os.path.join(root, "tools", "summarize_prof.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    commit = ["k_gemm_h2<H2BigPP>"] * 9
+    stagger = ["k_select", "k_compact", "k_lut_ids", "k_conv2_lut_xcd<8, true>", "k_gemm_h2<H2MidPP>", "k_gemm_h2<H2BigPP>", "k_gemm_h2<H2BigPP>",
+               "k_splitk_reduce_h2", "k_gemm_h2<H2Thin4w>", "k_heads_lds"]
+    timed = ["k_backup_advance", "k_compact", "k_lut_ids", "k_conv2_lut_xcd<8, true>", "k_gemm_h2<H2BigPP>", "k_gemm_h2<H2BigPP>", "k_gemm_h2<H2BigPP>",
+             "k_splitk_reduce_h2", "k_gemm_h2<H2Thin4w>", "k_heads_lds"]
+    seq = commit + stagger * 5 + timed * 3
+    lab = sp.label_layers(seq)
+    assert lab[:9] == [""] * 9                                            # the table build at commit is not a forward
+    assert [l for l in lab[9:19] if l] == ["conv1+conv2 (table gather)", "conv3", "conv4", "fc1", "fc2"]
+    assert sp.label_layers(["k_conv1_h2", "k_gemm_h2<H2BigPP>", "k_gemm_h2<H2MidPP>"])[1:] == ["conv2", "conv3"]
+    assert sp.label_layers(["k_lut_ids", "k_gemm_h2<H2BigPPLut>", "k_gemm_h2<H2MidPP>"])[1:] == ["conv2", "conv3"]
+    # a synthetic kernel trace: conv3 on the 192-row tile in the stagger phase (200 us), on the 256-row tile in the timed window (1000 us)
+    d = tmp_path / "prof"
+    d.mkdir()
+    with open(d / "run_kernel_trace.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z", "Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z",
+                    "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "Scratch_Size", "Start_Timestamp", "End_Timestamp"])
+        t = 0
+        for i, k in enumerate(seq):
+            dur = 1000000 if (i >= 9 + 50 and lab[i] == "conv3") else 200000
+            grid = 524288 if "BigPP" in k else 786432
+            w.writerow([i + 1, f"void {k}(args)", grid, 1, 1, 512, 1, 1, 0, 128, 0, 0, t, t + dur])
+            t += dur + 1000
+    out = tmp_path / "by_shape.csv"
+    sp.trace(str(d), str(out), "synthetic", 3640.0, 3)
+    rows = list(csv.DictReader(l for l in open(out) if not l.startswith("#")))
+    conv3 = {r["kernel"]: r for r in rows if r["layer"] == "conv3"}
+    big, mid = conv3["k_gemm_h2<H2BigPP>"], conv3["k_gemm_h2<H2MidPP>"]
+    assert mid["timed_calls"] == "" and mid["algorithmic_TFLOP_per_s"] == ""          # stagger-only shape: no timed average, no TFLOP/s
+    assert big["timed_calls"] == "3" and abs(float(big["timed_avg_us"]) - 1000.0) < 1e-6
+    want = 2 * 36 * 4608 * 512 * 3640 / 1e-3 / 1e12
+    assert abs(float(big["algorithmic_TFLOP_per_s"]) - want) < 0.1 and abs(float(big["frac"]) - want / 2500.0) < 1e-3
