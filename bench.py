@@ -948,6 +948,11 @@ def run_rank(args, rank, world, local_rank, t_proc):
             if secondary and n == 8:
                 out["config4"]["cpu_baseline"] = cpu_baseline_config(6, args.channels, args.sims, 5.0, out["cpu_baseline"]["cores"])
             wall["cpu_baseline_s"] = round(time.perf_counter() - t_sec, 2)
+        # the whole metric once more as the LAST key of the line: a reader (or a log) that keeps only the tail of stdout still sees it
+        out["headline"] = {"node_expansions_per_s": out["value"], "games_per_s": out["games_per_s"], "sims_per_s": out["sims_per_s"],
+                           "ms_per_step": out["ms_per_step"], "n_gpus": world, "roofline_frac": out["roofline"]["frac"],
+                           "roofline_avg_launch_ms": out["roofline"]["avg_launch_ms"], "pooled_records": out["pooled_records"],
+                           "games_completed": out["games_completed"]}
         print(json.dumps(out), flush=True)
     if world > 1 and args.backend == "nccl" and not args.no_c_abi_gather:
         # AFTER the line is out (nothing here can cost the measurement): the same exchange step through the C ABI's own RCCL communicator
