@@ -92,10 +92,10 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
         tail = "implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, 4-phase ping-pong loop"
         if layer == 3:
             cfg = "H2BigPP" if conv3_rows == 256 else "H2MidPP"
-            kernel = (f"k_gemm_h2<{cfg}> (conv3: 3x3 valid, 512->512, {n}x{n} -> {n - 2}x{n - 2}, {conv3_rows} x 256 tiles, {tail}); "
+            kernel = (f"k_gemm_h2<{cfg}, 3> (conv3: 3x3 valid, 512->512, {n}x{n} -> {n - 2}x{n - 2}, {conv3_rows} x 256 tiles, {tail}); "
                       "conv1 + conv2 = k_conv2_lut table gather-sum")
         else:
-            kernel = f"k_gemm_h2<H2BigPP> (conv2: 3x3 same, 512->512, {tail}; oz_net_set_tables(0): conv1 as a kernel)"
+            kernel = f"k_gemm_h2<H2BigPP, 2> (conv2: 3x3 same, 512->512, {tail}; oz_net_set_tables(0): conv1 as a kernel)"
         r.update(kernel=kernel, peak=PEAK_F16_MATRIX_TFLOPS, frac=achieved / PEAK_F16_MATRIX_TFLOPS,
                  mfma_products_per_fp32_product=3, matrix_pipe_tflops=3 * achieved,
                  matrix_pipe_frac=3 * achieved / PEAK_F16_MATRIX_TFLOPS,
@@ -965,6 +965,8 @@ def run_rank(args, rank, world, local_rank, t_proc):
         def c_abi():
             try:
                 from othellozero_amd.distributed import Comm, torch_share
+                _lib.check(_lib.load().oz_set_device(local_rank))     # a new host thread starts on device 0: select this rank's GPU
+                torch.cuda.set_device(local_rank)
                 comm = Comm(rank, world, torch_share(dev))
                 t_c = time.perf_counter()
                 rec, per = comm.gather_records(eng_for_c_abi, first_record=s0["records"])

@@ -621,7 +621,6 @@ struct OnnNet : oz_net {
     float *d_one = nullptr, *d_nul = nullptr;
     int* d_rows = nullptr;
     bool t2_ok = false;
-    bool h2_attr_set = false;
     std::vector<void*> allocs;
     // HIP-event timing on the launch stream (oz_net_profile): mode 1 = the dominant launch only (bench.py's timed region),
     // mode 2 = every kernel of the forward (slot order: OZ_NET_KERNELS in the header)
@@ -688,7 +687,7 @@ struct OnnNet : oz_net {
     }
 
     // layer: 1..3 = conv2..4 (3x3, Cin = N = C), 4 = fc1, 5 = fc2 (taps 1)
-    template <typename CF>
+    template <typename CF, int TAG = 0>
     int launch_gemm_h2(const void* in, int layer, void* out, int out_h2, const int* d_count, int max_count, int Hin,
                        int Hout, int pad, int Cin, int taps, int N, hipStream_t s, int ksplit = 1,
                        const unsigned* lut_ids = nullptr, const uint4* w_alt = nullptr, const float* scale_alt = nullptr,
@@ -701,21 +700,14 @@ struct OnnNet : oz_net {
         const int grid = ((num_mt + 7) / 8) * 8 * (N / CF::BN) * ksplit;
         void* out_final = out;
         if (ksplit > 1) out = d_partial;          // raw k-slice sums; k_splitk_reduce_h2 below writes out_final (h2 layout)
-        if (!h2_attr_set) {
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Big>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Big::LDS));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2BigPP::LDS));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2MidPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2MidPP::LDS));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPPLut>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       H2BigPPLut::LDS + 9 * H2BigPPLut::BM * 2));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Mid>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Mid::LDS));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Thin>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Thin::LDS));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Thin4w>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Thin4w::LDS));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small2::LDS));
-            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Thin2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Thin2::LDS));
-            h2_attr_set = true;
+        {   // the dynamic-LDS limit of THIS instantiation, once per device
+            static bool attr_done[64] = {};
+            if (!attr_done[device & 63]) {
+                OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<CF, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS + (CF::LUT ? 9 * CF::BM * 2 : 0)));
+                attr_done[device & 63] = true;
+            }
         }
-        hipLaunchKernelGGL(k_gemm_h2<CF>, dim3(grid), dim3(CF::NT), CF::LDS + (CF::LUT ? 9 * CF::BM * 2 : 0), s, (const uint4*)in,
+        hipLaunchKernelGGL((k_gemm_h2<CF, TAG>), dim3(grid), dim3(CF::NT), CF::LDS + (CF::LUT ? 9 * CF::BM * 2 : 0), s, (const uint4*)in,
                            w_alt ? w_alt : (const uint4*)d_wh[layer - 1], scale_alt ? scale_alt : d_scale_h2[layer - 1],
                            shift_alt ? shift_alt : d_shift[layer], out, d_count, g, num_mt, d_zero, d_flag, lut_ids);
         if (ksplit > 1 && out_h2) {
@@ -887,21 +879,21 @@ struct OnnNet : oz_net {
         if (use_t2) {
             launch_conv2_lut<true>(max_count, d_count, d_scale_h2[0], d_shift[1], act2, s);
         } else if (int rc = small     ? launch_small<H2Small, H2Small2>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, 16)
-                            : use_lut ? launch_gemm_h2<H2BigPPLut>(d_lut, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2, d_lut_ids)
-                            : pp      ? launch_gemm_h2<H2BigPP>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)
+                            : use_lut ? launch_gemm_h2<H2BigPPLut, 2>(d_lut, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2, d_lut_ids)
+                            : pp      ? launch_gemm_h2<H2BigPP, 2>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)
                                       : launch_gemm_h2<H2Big>(act1, 1, act2, 1, d_count, max_count, n, n, 1, C, 9, C, s, k2)) return rc;
         mark(1, false);
         mark(2, true);
         // (a 3-phase loop on the 192-row tile -- 24-MFMA clusters -- measured 0 .. +2 % in round 2: the layer is clock / power bound,
         //  not load-section bound; deleted in round 3)
         if (int rc = small ? launch_small<H2Small, H2Small2>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, 16)
-                     : pp && conv3_big ? launch_gemm_h2<H2BigPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
-                     : pp  ? launch_gemm_h2<H2MidPP>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
+                     : pp && conv3_big ? launch_gemm_h2<H2BigPP, 3>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
+                     : pp  ? launch_gemm_h2<H2MidPP, 3>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                            : launch_gemm_h2<H2Mid>(act2, 2, act3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
         mark(2, false);
         mark(3, true);
         if (int rc = small ? launch_small<H2Small, H2Small2>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, 16)
-                     : pp  ? launch_gemm_h2<H2BigPP>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
+                     : pp  ? launch_gemm_h2<H2BigPP, 4>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
                            : launch_gemm_h2<H2Big>(act3, 3, act4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)) return rc;
         mark(3, false);
         mark(4, true);
@@ -909,13 +901,13 @@ struct OnnNet : oz_net {
         // (large batches: on the 256 x 256 ping-pong tile, 16 x 4 tiles x 4 k-slices = one block per CU; bit-identical to
         //  the 128 x 128 tile because the k-slices and the order inside them are the same -- tools/pp_race_check.py)
         if (int rc = small ? launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)
-                     : (pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
+                     : (pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP, 5>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
                                                           : launch_small<H2Small, H2Small2>(act4, 4, f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
         mark(4, false);
         mark(5, true);
         // fc2: one position has 4 blocks of 32 k-tiles -> small networks split k 8 ways too, medium ones 4 ways (from max_batch)
         // (large networks: one k-slice on the four-wave form of the thin tile, bit-identical to the two-wave one)
-        if (int rc = max_batch > 512 ? launch_gemm_h2<H2Thin4w>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, 1)
+        if (int rc = max_batch > 512 ? launch_gemm_h2<H2Thin4w, 6>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, 1)
                                     : launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, small ? 8 : max_batch <= 512 ? 4 : 1)) return rc;
         mark(5, false);
         mark(6, true);

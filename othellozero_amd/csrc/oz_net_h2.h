@@ -539,7 +539,9 @@ __global__ __launch_bounds__(256) void k_lut_build_f32(int C, const float* __res
 // out[M][N] = act((A[M][K] . W[N][K]^T) * scale + shift); A and W in the h2 layout; M = *d_count * Hout^2.
 // CF::LUT: `in` is the pattern table, lut_ids the per-pixel pattern ids [batch][Hin^2] (k_lut_ids).
 // zero_line: >= 128 B of zeros in global memory (source of out-of-image taps and of rows beyond M).
-template <typename CF>
+// TAG: no effect on the code -- the throughput path instantiates the kernel once per OthelloNN layer (2 = conv2 ... 5 = fc1, 6 = fc2) so that
+// every layer is its own symbol and `rocprofv3 --stats` lists conv3, conv4 and fc1 as separate rows instead of one k_gemm_h2<H2BigPP> average.
+template <typename CF, int TAG = 0>
 __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__ in, const uint4* __restrict__ Wh,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        void* __restrict__ out, const int* __restrict__ d_count, H2Geom g,

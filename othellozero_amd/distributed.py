@@ -89,7 +89,8 @@ def pooled_selfplay_records(engine, device, group=None):
 class Comm:
     """RCCL communicator owned by the library (oz_comm_*): what a non-Python host uses.  Rank 0 makes the 128-byte id, the host hands it
     to every rank (here: any callable `share(id_bytes_or_None) -> id_bytes`, e.g. a torch.distributed broadcast), every rank creates
-    its communicator on its own device."""
+    its communicator on its own device -- the device of the CALLING THREAD (oz_set_device / the HIP runtime's current device are
+    per host thread: a helper thread must select the rank's GPU before it creates the communicator)."""
 
     def __init__(self, rank, world, share=None):
         import ctypes as C
