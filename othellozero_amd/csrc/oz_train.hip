@@ -659,6 +659,164 @@ __global__ __launch_bounds__(256) void k_t_dz_to_h2(const float* __restrict__ dz
     t_store_h2(out + (row * cg + g8) * 2, v);
 }
 
+// ---------------------------------------------------------------- f16x2 weight gradient of the 3x3 layers (round 3)
+// dW[tap][ci][co] = sum over boards b and output pixels p of X[b][p + tap][ci] * dZ[b][p][co]: the contraction runs over (board, pixel),
+// the WRONG major for the fp16 operand map (v_mfma_f32_16x16x32_f16 wants, per lane, 8 consecutive k of one row / column; the tensors are
+// stored pixel-major with the channels contiguous).  The k-groups of 8 are therefore 8 BOARDS at one pixel: a tap shift changes the pixel,
+// never the alignment of a k-group, and the four k-groups of one MFMA are four neighbouring output pixels.  Both tensors are first written
+// as "octet images" -- [octet of 8 boards][row][pixel slot][plane h1 | h2][channel][8 boards] fp16, 16 bytes per (pixel, plane, channel) --
+// by two bandwidth-bound kernels (X with its zero border for 'same' layers and zero columns up to WH_XW; dZ scaled into the fp16 range by the
+// power of two the data gradient uses, zero columns up to WH_ZW: a row of either is two whole k-quads for every layer), so the GEMM kernel
+// stages with LDS-DMA only: no transposes, no staging registers.
+// k_wgrad_h2: a block owns a 64 (ci) x 128 (co) tile for ALL NINE taps (9 x 4 accumulator tiles of 16 x 16 per wave, 8 waves = 4 x 16 ci by
+// 2 x 64 co).  Per octet it walks the output rows: three X rows (a ring of four 20 KB row slots: the row of the next step streams in during
+// the MFMAs of this one) and one dZ row (two 32 KB buffers) are resident; every tap reads the SAME staged rows at a shifted pixel slot, and
+// the dZ fragments of a pixel quad are read once for all nine taps: 26 ds_read_b128 per 108 MFMAs per wave.  fp32 accumulation, three
+// fp16 products per fp32 product (x2*z1 + x1*z2 + x1*z1), 2^-ez folded into the epilogue.  Octet ranges split over blockIdx.y until every CU
+// has a block (raw slabs + k_t_sum_partials, fixed order).  Rows of fewer than 8 real pixels (conv3: 6, conv4: 4) pay for the zero columns
+// (+24 % MFMA work over the three layers) -- the price of one uniform step shape.
+#define WH_CI 64
+#define WH_CO 128
+#define WH_XW 10           // pixel slots of an X row (columns >= Hin + 2 pad hold zeros)
+#define WH_ZW 8            // pixel slots of a dZ row (columns >= Hout hold zeros)
+#define WH_XROW (2 * WH_XW * WH_CI * 16)        // bytes of one staged X row: [plane][slot][ci] x 16 B = 20 KB
+#define WH_ZROW (2 * WH_ZW * WH_CO * 16)        // bytes of one staged dZ row: [plane][slot][co] x 16 B = 32 KB
+#define WH_LDS (4 * WH_XROW + 2 * WH_ZROW)      // 144 KB
+// X octet image of a[l - 1] ([B][Hin][Hin][C] fp32): out[octet][row < Hin + 2 pad][slot < WH_XW][plane][C] x 16 B
+__global__ __launch_bounds__(256) void k_t_x_octets(const float* __restrict__ a, const int* __restrict__ d_count, int Hin, int pad, int C, uint4* __restrict__ out) {
+    const int B = *d_count, XR = Hin + 2 * pad, noct = (B + 7) >> 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)noct * XR * WH_XW * C) return;
+    const int ch = (int)(idx % C);
+    const long long cell = idx / C;
+    const int c = (int)(cell % WH_XW), r = (int)((cell / WH_XW) % XR), oct = (int)(cell / ((long long)WH_XW * XR));
+    const int iy = r - pad, ix = c - pad;
+    const bool inside = iy >= 0 && iy < Hin && ix >= 0 && ix < Hin;
+    t_f16x8 h1, h2;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int bb = oct * 8 + b;
+        const float v = (inside && bb < B) ? a[(((size_t)bb * Hin + iy) * Hin + ix) * C + ch] : 0.f;
+        const _Float16 x = (_Float16)v;
+        h1[b] = x; h2[b] = (_Float16)(v - (float)x);
+    }
+    uint4* dst = out + (size_t)cell * 2 * C + ch;
+    dst[0] = *reinterpret_cast<uint4*>(&h1);
+    dst[C] = *reinterpret_cast<uint4*>(&h2);
+}
+// dZ octet image of dz[l] (zero-bordered [B][Hz][Hz][C] fp32, interior Hout^2 at offset zoff), scaled by 2^ez (ez from the tensor's maximum):
+// out[octet][row < Hout][slot < WH_ZW][plane][C] x 16 B
+__global__ __launch_bounds__(256) void k_t_z_octets(const float* __restrict__ dz, const int* __restrict__ d_count, int Hout, int Hz, int zoff, int C,
+                                                    const unsigned* __restrict__ dzmax, uint4* __restrict__ out, int* __restrict__ flag) {
+    const int B = *d_count, noct = (B + 7) >> 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0 && t_bad_max(*dzmax)) atomicOr(flag, 2);
+    if (idx >= (long long)noct * Hout * WH_ZW * C) return;
+    const int ez = t_exp_for(*dzmax, 8192.0f);
+    const int ch = (int)(idx % C);
+    const long long cell = idx / C;
+    const int c = (int)(cell % WH_ZW), r = (int)((cell / WH_ZW) % Hout), oct = (int)(cell / ((long long)WH_ZW * Hout));
+    t_f16x8 h1, h2;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int bb = oct * 8 + b;
+        const float v = (c < Hout && bb < B) ? ldexpf(dz[(((size_t)bb * Hz + r + zoff) * Hz + c + zoff) * C + ch], ez) : 0.f;
+        const _Float16 x = (_Float16)v;
+        h1[b] = x; h2[b] = (_Float16)(v - (float)x);
+    }
+    uint4* dst = out + (size_t)cell * 2 * C + ch;
+    dst[0] = *reinterpret_cast<uint4*>(&h1);
+    dst[C] = *reinterpret_cast<uint4*>(&h2);
+}
+typedef float t_f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void* t_gptr;
+typedef __attribute__((address_space(3))) void* t_lptr;
+struct WhGeom { int XR, Hout, Cin, Cout; };
+__global__ __launch_bounds__(512, 2) void k_wgrad_h2(const uint4* __restrict__ Xt, const uint4* __restrict__ Zt, const int* __restrict__ d_count, WhGeom g,
+                                                     const unsigned* __restrict__ dzmax, float* __restrict__ dW, int msplit, float* __restrict__ partial,
+                                                     long long slab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wh_lds[];
+    unsigned char* const Xring = wh_lds;
+    unsigned char* const Zbuf = wh_lds + 4 * WH_XROW;
+    const int nco = g.Cout / WH_CO;
+    const int ci0 = (blockIdx.x / nco) * WH_CI, co0 = (blockIdx.x % nco) * WH_CO;
+    const int noct = (*d_count + 7) >> 3;
+    const int per = (noct + msplit - 1) / msplit, o0 = blockIdx.y * per, o1 = o0 + per < noct ? o0 + per : noct;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, g4 = lane >> 4;
+
+    // LDS-DMA: one instruction = 64 consecutive 16-byte entries.  X row = 20 instructions q = (plane, slot): lanes = the 64 ci of the tile;
+    // dZ row = 32 instructions q = (plane, slot, half): lanes = 64 of the tile's 128 co.  Wave w issues q = w, w + 8, ...
+    auto dma_x = [&](int oct, int row, int slot) {
+        const uint4* src = Xt + (((size_t)oct * g.XR + row) * WH_XW) * 2 * g.Cin + ci0 + lane;
+        for (int q = wave; q < 2 * WH_XW; q += 8) {
+            const int p = q / WH_XW, c = q - p * WH_XW;
+            __builtin_amdgcn_global_load_lds((t_gptr)(src + ((size_t)c * 2 + p) * g.Cin), (t_lptr)(Xring + slot * WH_XROW + q * 1024), 16, 0, 0);
+        }
+    };
+    auto dma_z = [&](int oct, int row, int buf) {
+        const uint4* src = Zt + (((size_t)oct * g.Hout + row) * WH_ZW) * 2 * g.Cout + co0 + lane;
+        for (int q = wave; q < 4 * WH_ZW; q += 8) {
+            const int h = q & 1, c = (q >> 1) % WH_ZW, p = q / (2 * WH_ZW);
+            __builtin_amdgcn_global_load_lds((t_gptr)(src + ((size_t)c * 2 + p) * g.Cout + h * 64), (t_lptr)(Zbuf + buf * WH_ZROW + ((p * WH_ZW + c) * 2 + h) * 1024), 16, 0, 0);
+        }
+    };
+
+    t_f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int oct = o0; oct < o1; ++oct) {
+        // the three X rows and the dZ row of output row 0 (the previous octet's last step ended with a barrier: every slot is free)
+        dma_x(oct, 0, 0); dma_x(oct, 1, 1); dma_x(oct, 2, 2); dma_z(oct, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int oy = 0; oy < g.Hout; ++oy) {
+            if (oy + 1 < g.Hout) { dma_x(oct, oy + 3, (oy + 3) & 3); dma_z(oct, oy + 1, (oy + 1) & 1); }     // slots last read in step oy - 1
+            const unsigned char* Zr = Zbuf + (oy & 1) * WH_ZROW + (wn * 64 + r16) * 16;
+#pragma unroll
+            for (int quad = 0; quad < 2; ++quad) {
+                const int px = quad * 4 + g4;
+                t_f16x8 z1[4], z2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    z1[j] = *reinterpret_cast<const t_f16x8*>(Zr + ((0 * WH_ZW + px) * WH_CO + j * 16) * 16);
+                    z2[j] = *reinterpret_cast<const t_f16x8*>(Zr + ((1 * WH_ZW + px) * WH_CO + j * 16) * 16);
+                }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = t / 3, dx = t - 3 * dy;
+                    const unsigned char* Xr = Xring + ((oy + dy) & 3) * WH_XROW + (wm * 16 + r16) * 16;
+                    const t_f16x8 x1 = *reinterpret_cast<const t_f16x8*>(Xr + ((0 * WH_XW + px + dx) * WH_CI) * 16);
+                    const t_f16x8 x2 = *reinterpret_cast<const t_f16x8*>(Xr + ((1 * WH_XW + px + dx) * WH_CI) * 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x2, z1[j], acc[t][j], 0, 0, 0);
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x1, z2[j], acc[t][j], 0, 0, 0);
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x1, z1[j], acc[t][j], 0, 0, 0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next step's rows have landed (this wave's pieces) ...
+            __syncthreads();                                       // ... everybody's, and everybody is done reading this step's
+        }
+    }
+    // C/D layout of the 16 x 16 MFMA: col = lane & 15 (co), row = (lane >> 4) * 4 + reg (ci)
+    const float sc = ldexpf(1.0f, -t_exp_for(*dzmax, 8192.0f));
+    float* __restrict__ outp = msplit > 1 ? partial + (size_t)blockIdx.y * slab : dW;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + wm * 16 + g4 * 4 + r, co = co0 + wn * 64 + j * 16 + r16;
+                outp[((size_t)t * g.Cin + ci) * g.Cout + co] = acc[t][j][r] * sc;
+            }
+}
+
 // ---------------------------------------------------------------- Adam (tf.keras formulation) with clipvalue
 __global__ __launch_bounds__(256) void k_t_adam(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M1, float* __restrict__ V2,
                                                 long long count, float lr_t, float clip) {
@@ -706,7 +864,8 @@ struct oz_trainer {
     float* bnb2[6] = {};                 // per-layer row-block partials of the bias gradient (mid-size BN backward)
     bool overlap = true;                 // weight gradients on the second stream beside the data-gradient chain (false: all on the main stream)
     long long gpartial_floats = 40LL << 20;      // 160 MB each: 16 row-split slabs of a 3x3 x 512 x 512 weight gradient
-    bool wconv_attr = false;
+    bool wconv_attr = false, wh_attr = false;
+    uint4 *xt_oct[4] = {}, *zt_oct[4] = {};     // f16x2 weight gradient: octet images of a[l - 1] / dz[l] (k_t_x_octets / k_t_z_octets)
     // HBM-resident data set of a fit (oz_trainer_set_dataset / oz_trainer_fit_epoch)
     uint64_t *ds_own = nullptr, *ds_opp = nullptr;
     float *ds_pi = nullptr, *ds_z = nullptr;
@@ -857,6 +1016,9 @@ OZ_API int oz_trainer_set_precision(oz_trainer* t, int mode) {
             T_ALLOC(t->wscale[l], C); T_ALLOC(t->dscale[l], C);
             T_ALLOC(t->a_h2[l - 1], (size_t)t->Bmax * t->P_[l - 1] * C / 4);
             T_ALLOC(t->dz_h2[l], (size_t)t->Bmax * t->Hz[l] * t->Hz[l] * C / 4);      // zeroed: the border stays zero
+            const size_t noct = (size_t)(t->Bmax + 7) / 8;
+            T_ALLOC(t->xt_oct[l], noct * (t->Hout[l] + 2) * WH_XW * 2 * C);
+            T_ALLOC(t->zt_oct[l], noct * t->Hout[l] * WH_ZW * 2 * C);
         }
         T_ALLOC(t->wmax, 4); T_ALLOC(t->dzmax, 8); T_ALLOC(t->h2flag, 1);
         OZ_HIP(hipStreamSynchronize(t->s));
@@ -1102,7 +1264,24 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
             }
             // (measured on one MI355X, 8x8 / 512 filters: the board-resident kernel wins from batch 256 on -- 6.01 vs 6.36 ms per step, 17.0 vs
             //  19.9 at 1024 -- and loses 3-4 % at 32 .. 128, where the tap-per-block kernel's 144 x 4 short blocks finish sooner)
-            if (taps[l] == 9 && B >= 192 && Cin[l] % WC_CI == 0 && Cc % WC_CO == 0) {
+            if (taps[l] == 9 && t->h2 && have_dzmax && l >= 1 && B >= 128 && Cin[l] % WH_CI == 0 && Cc % WH_CO == 0) {
+                // f16x2: octet images of a[l - 1] and of the scaled dz[l], then the MFMA kernel on the fp16 matrix cores (three products per fp32 product)
+                const int noct = (B + 7) / 8, XR = t->Hout[l] + 2;
+                const int tiles = (Cin[l] / WH_CI) * (Cc / WH_CO);
+                msplit = 1;
+                while (msplit < 32 && tiles * msplit < 256 && msplit * 2 <= noct && wcount * msplit * 2 <= t->gpartial_floats) msplit *= 2;
+                const long long xthr = (long long)noct * XR * WH_XW * Cin[l], zthr = (long long)noct * t->Hout[l] * WH_ZW * Cc;
+                hipLaunchKernelGGL(k_t_x_octets, dim3((unsigned)((xthr + 255) / 256)), dim3(256), 0, sw, t->a[l - 1], t->d_count, Hin[l], pad[l], Cin[l], t->xt_oct[l]);
+                hipLaunchKernelGGL(k_t_z_octets, dim3((unsigned)((zthr + 255) / 256)), dim3(256), 0, sw, t->dz[l], t->d_count, t->Hout[l], t->Hz[l], t->zoff[l], Cc,
+                                   t->dzmax + l, t->zt_oct[l], t->h2flag);
+                if (!t->wh_attr) {
+                    OZ_HIP(hipFuncSetAttribute((const void*)k_wgrad_h2, hipFuncAttributeMaxDynamicSharedMemorySize, WH_LDS));
+                    t->wh_attr = true;
+                }
+                WhGeom wg; wg.XR = XR; wg.Hout = t->Hout[l]; wg.Cin = Cin[l]; wg.Cout = Cc;
+                hipLaunchKernelGGL(k_wgrad_h2, dim3(tiles, msplit), dim3(512), WH_LDS, sw, t->xt_oct[l], t->zt_oct[l], t->d_count, wg, t->dzmax + l, t->grad(6 * l),
+                                   msplit, wp, wcount);
+            } else if (taps[l] == 9 && B >= 192 && Cin[l] % WC_CI == 0 && Cc % WC_CO == 0) {
                 // board-resident kernel: (Cin / 64) x (Cout / 128) tiles, boards split over blockIdx.y until every CU has a block
                 WconvGeom cg; cg.Hin = Hin[l]; cg.Hout = t->Hout[l]; cg.pad = pad[l]; cg.Cin = Cin[l]; cg.Cout = Cc; cg.Hz = t->Hz[l]; cg.zoff = t->zoff[l];
                 const int tiles = (Cin[l] / WC_CI) * (Cc / WC_CO);
