@@ -682,51 +682,62 @@ __global__ __launch_bounds__(256) void k_t_dz_to_h2(const float* __restrict__ dz
 #define WH_XROW (2 * WH_XW * WH_CI * 16)        // bytes of one staged X row: [plane][slot][ci] x 16 B = 20 KB
 #define WH_ZROW (2 * WH_ZW * WH_CO * 16)        // bytes of one staged dZ row: [plane][slot][co] x 16 B = 32 KB
 #define WH_LDS (4 * WH_XROW + 2 * WH_ZROW)      // 144 KB
-// X octet image of a[l - 1] ([B][Hin][Hin][C] fp32): out[octet][row < Hin + 2 pad][slot < WH_XW][plane][C] x 16 B
+// X octet image of a[l - 1] ([B][Hin][Hin][C] fp32): out[octet][row < Hin + 2 pad][slot < WH_XW][plane][C] x 16 B.
+// One thread per (cell, 4 channels): eight 16-byte loads (one per board), eight 16-byte stores (4 channels x 2 planes).
+__device__ __forceinline__ void t_store_octet4(uint4* __restrict__ dst, int C, const f32x4* v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        t_f16x8 h1, h2;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const _Float16 x = (_Float16)v[b][q];
+            h1[b] = x; h2[b] = (_Float16)(v[b][q] - (float)x);
+        }
+        dst[q] = *reinterpret_cast<uint4*>(&h1);
+        dst[C + q] = *reinterpret_cast<uint4*>(&h2);
+    }
+}
 __global__ __launch_bounds__(256) void k_t_x_octets(const float* __restrict__ a, const int* __restrict__ d_count, int Hin, int pad, int C, uint4* __restrict__ out) {
-    const int B = *d_count, XR = Hin + 2 * pad, noct = (B + 7) >> 3;
+    const int B = *d_count, XR = Hin + 2 * pad, noct = (B + 7) >> 3, C4 = C >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)noct * XR * WH_XW * C) return;
-    const int ch = (int)(idx % C);
-    const long long cell = idx / C;
+    if (idx >= (long long)noct * XR * WH_XW * C4) return;
+    const int ch = (int)(idx % C4) * 4;
+    const long long cell = idx / C4;
     const int c = (int)(cell % WH_XW), r = (int)((cell / WH_XW) % XR), oct = (int)(cell / ((long long)WH_XW * XR));
     const int iy = r - pad, ix = c - pad;
     const bool inside = iy >= 0 && iy < Hin && ix >= 0 && ix < Hin;
-    t_f16x8 h1, h2;
+    f32x4 v[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const int bb = oct * 8 + b;
-        const float v = (inside && bb < B) ? a[(((size_t)bb * Hin + iy) * Hin + ix) * C + ch] : 0.f;
-        const _Float16 x = (_Float16)v;
-        h1[b] = x; h2[b] = (_Float16)(v - (float)x);
+        v[b] = (inside && bb < B) ? *reinterpret_cast<const f32x4*>(a + (((size_t)bb * Hin + iy) * Hin + ix) * C + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    uint4* dst = out + (size_t)cell * 2 * C + ch;
-    dst[0] = *reinterpret_cast<uint4*>(&h1);
-    dst[C] = *reinterpret_cast<uint4*>(&h2);
+    t_store_octet4(out + (size_t)cell * 2 * C + ch, C, v);
 }
 // dZ octet image of dz[l] (zero-bordered [B][Hz][Hz][C] fp32, interior Hout^2 at offset zoff), scaled by 2^ez (ez from the tensor's maximum):
 // out[octet][row < Hout][slot < WH_ZW][plane][C] x 16 B
 __global__ __launch_bounds__(256) void k_t_z_octets(const float* __restrict__ dz, const int* __restrict__ d_count, int Hout, int Hz, int zoff, int C,
                                                     const unsigned* __restrict__ dzmax, uint4* __restrict__ out, int* __restrict__ flag) {
-    const int B = *d_count, noct = (B + 7) >> 3;
+    const int B = *d_count, noct = (B + 7) >> 3, C4 = C >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0 && t_bad_max(*dzmax)) atomicOr(flag, 2);
-    if (idx >= (long long)noct * Hout * WH_ZW * C) return;
+    if (idx >= (long long)noct * Hout * WH_ZW * C4) return;
     const int ez = t_exp_for(*dzmax, 8192.0f);
-    const int ch = (int)(idx % C);
-    const long long cell = idx / C;
+    const int ch = (int)(idx % C4) * 4;
+    const long long cell = idx / C4;
     const int c = (int)(cell % WH_ZW), r = (int)((cell / WH_ZW) % Hout), oct = (int)(cell / ((long long)WH_ZW * Hout));
-    t_f16x8 h1, h2;
+    f32x4 v[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const int bb = oct * 8 + b;
-        const float v = (c < Hout && bb < B) ? ldexpf(dz[(((size_t)bb * Hz + r + zoff) * Hz + c + zoff) * C + ch], ez) : 0.f;
-        const _Float16 x = (_Float16)v;
-        h1[b] = x; h2[b] = (_Float16)(v - (float)x);
+        v[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < Hout && bb < B) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(dz + (((size_t)bb * Hz + r + zoff) * Hz + c + zoff) * C + ch);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[b][q] = ldexpf(x[q], ez);
+        }
     }
-    uint4* dst = out + (size_t)cell * 2 * C + ch;
-    dst[0] = *reinterpret_cast<uint4*>(&h1);
-    dst[C] = *reinterpret_cast<uint4*>(&h2);
+    t_store_octet4(out + (size_t)cell * 2 * C + ch, C, v);
 }
 typedef float t_f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) void* t_gptr;
@@ -1270,7 +1281,7 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
                 const int tiles = (Cin[l] / WH_CI) * (Cc / WH_CO);
                 msplit = 1;
                 while (msplit < 32 && tiles * msplit < 256 && msplit * 2 <= noct && wcount * msplit * 2 <= t->gpartial_floats) msplit *= 2;
-                const long long xthr = (long long)noct * XR * WH_XW * Cin[l], zthr = (long long)noct * t->Hout[l] * WH_ZW * Cc;
+                const long long xthr = (long long)noct * XR * WH_XW * (Cin[l] / 4), zthr = (long long)noct * t->Hout[l] * WH_ZW * (Cc / 4);
                 hipLaunchKernelGGL(k_t_x_octets, dim3((unsigned)((xthr + 255) / 256)), dim3(256), 0, sw, t->a[l - 1], t->d_count, Hin[l], pad[l], Cin[l], t->xt_oct[l]);
                 hipLaunchKernelGGL(k_t_z_octets, dim3((unsigned)((zthr + 255) / 256)), dim3(256), 0, sw, t->dz[l], t->d_count, t->Hout[l], t->Hz[l], t->zoff[l], Cc,
                                    t->dzmax + l, t->zt_oct[l], t->h2flag);
