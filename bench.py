@@ -130,16 +130,24 @@ def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tabl
         row = {"name": name, "ms_per_step": ms / rounds, "launches_per_step": cnt / rounds}
         sec = ms * 1e-3
         if name == "conv2" and tables:
-            # the table gather: bound by the bytes that miss L2 -- PMC (profiles/r3_conv2_gather_pmc.csv, tools/conv2_lut_probe.py): 7.1 M
-            # L2->fabric read requests of 128 B + the compulsory output row per pixel.  `achieved` = HBM-side bytes per launch from
-            # that profile (per leaf: 0.91 GB / 3640 read + n*n*C*4 written) / this run's time; the 363 MB table cannot live in the
-            # 256 MB Infinity Cache, so these are HBM bytes
-            per_leaf = 0.91e9 / 3640 * (n * n / 64.0) * (C / 512.0) + n * n * C * 4
+            # the table gather: bound by the bytes that miss L2 (the 363 MB table cannot live in the 256 MB Infinity Cache, so they are HBM
+            # bytes).  `achieved` = HBM-side bytes per leaf from the committed PMC summary of this command (FETCH_SIZE x2 + WRITE_SIZE of
+            # the gather's launches in the timed step, profiles/r3_*_bench_pmc_by_shape.csv) x the leaves of this run / this run's time
+            per_leaf, src = None, None
+            try:
+                import csv
+                rel = os.path.join("profiles", f"r3_{precision}_bench_pmc_by_shape.csv")
+                rows = [r for r in csv.DictReader(l for l in open(os.path.join(ROOT, rel)) if not l.startswith("#")) if "k_conv2_lut" in r["kernel"]]
+                fetch = max(float(r["avg_per_launch"]) for r in rows if r["counter"] == "FETCH_SIZE")
+                write = max(float(r["avg_per_launch"]) for r in rows if r["counter"] == "WRITE_SIZE")
+                per_leaf = (fetch * 2048 + write * 1024) / 3640.0 * (n * n / 64.0) * (C / 512.0)
+                src = f"{rel}: FETCH_SIZE x2 + WRITE_SIZE of the gather per 3640-leaf launch (PMC passes of this command); not re-measured in this run"
+            except Exception:
+                per_leaf = 0.58e9 / 3640 * (n * n / 64.0) * (C / 512.0) + n * n * C * 4
+                src = "0.58 GB read (PMC, round 3) + the compulsory output row per pixel per 3640-leaf launch; not re-measured in this run"
             byts = leaves * per_leaf
             row.update(kernel=("k_conv2_lut_xcd" if C == 512 else "k_conv2_lut") + (" (fp32 rows)" if precision == "f32" else " (h2 rows)"), bound="hbm",
-                       achieved=byts / sec / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s",
-                       bytes_source="read bytes per leaf from profiles/r3_conv2_gather_pmc.csv (TCC_EA0_RDREQ x 128 B on mid-game positions), written bytes exact; "
-                                    "not re-measured in this run")
+                       achieved=byts / sec / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s", bytes_source=src)
         elif name in flop:
             kern = "k_gemm_f32" if precision == "f32" else "k_gemm_h2"
             row.update(kernel=f"{kern} ({name})", bound="mfma", achieved=leaves * flop[name] / sec / 1e12, peak=peak_mm, unit="TFLOP/s")
