@@ -388,9 +388,15 @@ def config5_arena(channels, precision, plies, games=512, sims=800, sample=2):
     n = 8
     nets = [NNetWrapper((n, n), num_channels_1=channels, max_batch=games, seed=sd, precision=precision) for sd in (0, 1)]
     arena_batch(nets[0], nets[1], n, games, 8, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=2)      # untimed: allocation, code load
+    # headline of the leg: every expansion evaluated by itself (cross-game de-duplication off, as in the self-play headline); then the
+    # library default (on) -- arena games start from ONE opening and play deterministically, so most expansions of a step share a board
     t0 = time.perf_counter()
-    r = arena_batch(nets[0], nets[1], n, games, sims, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=plies)
+    r = arena_batch(nets[0], nets[1], n, games, sims, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=plies, dedup=False)
     dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rd = arena_batch(nets[0], nets[1], n, games, sims, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=plies, dedup=True)
+    dtd = time.perf_counter() - t0
+    same = bool(np.array_equal(r["actions"], rd["actions"]) and np.array_equal(r["final_black"], rd["final_black"]) and np.array_equal(r["final_white"], rd["final_white"]))
     moves = int(r["n_moves"].sum())
     st = r["stats_black"] + r["stats_white"]
     caches = [{}, {}]
@@ -415,6 +421,10 @@ def config5_arena(channels, precision, plies, games=512, sims=800, sample=2):
             "seconds": dt, "plies_per_game": plies, "moves": moves, "simulations": int(st[0]), "expansions": int(st[2]),
             "sims_per_s": float(st[0]) / dt, "value": float(st[2]) / dt, "unit": "node-expansions/s", "moves_per_s": moves / dt,
             "games_per_s_extrapolated_60_plies": games / (dt * 60.0 / plies), "precision": precision,
+            "leaves_evaluated": int(r["leaves_evaluated"]),
+            "with_cross_game_dedup": {"seconds": dtd, "sims_per_s": float(rd["stats_black"][0] + rd["stats_white"][0]) / dtd,
+                                      "leaves_evaluated": int(rd["leaves_evaluated"]), "identical_games": same,
+                                      "note": "library default: a board several games reach in one step is evaluated once"},
             "sample_games_replayed_by_oracle": sample, "sample_mismatches": bad, "oracle_replay_s": round(time.perf_counter() - t1, 2),
             "note": "oz_arena_run_rounds: BLACK movers search in net A's trees, WHITE movers in net B's, one searched ply per game and round; "
                     "the oracle's arena (agents.py restated, oracle/oz_oracle.c orc_arena_plies) is fed the GPU networks' own (pi, v), so "

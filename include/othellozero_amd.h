@@ -275,6 +275,10 @@ int oz_arena_run(oz_arena* a);       /* plays all games to the end (synchronous)
 int oz_arena_run_rounds(oz_arena* a, int max_rounds);
 /* search counters of the BLACK / WHITE agent since creation, layout of oz_mcts_stats */
 int oz_arena_stats(oz_arena* a, int64_t* black5, int64_t* white5);
+/* cross-game leaf de-duplication of both agents' searches (default on; identical results either way) and the positions the two
+ * networks have evaluated so far (<= expansions when concurrent games share boards -- arena games start from one opening) */
+int oz_arena_set_dedup(oz_arena* a, int enable);
+int oz_arena_leaves_evaluated(oz_arena* a, int64_t* black, int64_t* white);
 int oz_arena_results(oz_arena* a, int8_t* winner /* +1 net_a */, int32_t* points, int32_t* n_moves,
                      uint8_t* actions /* [num_games][128] */, int8_t* players /* [num_games][128] */,
                      uint64_t* final_black, uint64_t* final_white);

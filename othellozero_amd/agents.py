@@ -74,22 +74,27 @@ def duel_between_agents(game, agent_1, agent_2):
 
 
 def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, degree_exploration=1.0, seed=0,
-                first_game_id=0, q_mode=_lib.QMODE_F64, node_cap=0, edge_cap=0, max_rounds=0):
+                first_game_id=0, q_mode=_lib.QMODE_F64, node_cap=0, edge_cap=0, max_rounds=0, dedup=True):
     """num_games games of net_a (BLACK) vs net_b (WHITE), temperature 0, max-visit ties broken by the RNG_TIE
     stream keyed (seed, game id, ply).  One of the two may be None: RandomOthelloAgent plays that colour.
     max_rounds > 0 stops after that many plies per game (unfinished boards: winner / points then describe the position reached).
     Returns dict(winner (+1 = BLACK's agent), points, n_moves, actions, players, final boards, stats_black / stats_white =
-    the two agents' search counters [simulations, node visits, expansions, terminal hits, fallbacks])."""
+    the two agents' search counters [simulations, node visits, expansions, terminal hits, fallbacks], leaves_evaluated = positions the
+    networks evaluated: fewer than the expansions with dedup=True (the default), where a board several games reach in one step is evaluated once)."""
     lib = _lib.require_gpu()
     h = C.c_void_p()
     _lib.check(lib.oz_arena_create(C.byref(h), board_size, num_games, num_simulations, float(degree_exploration), q_mode,
                                    seed, first_game_id, net_a._h if net_a is not None else None,
                                    net_b._h if net_b is not None else None, node_cap, edge_cap))
     try:
+        if not dedup:                                        # every expansion evaluated by itself (identical results; bench.py's config5 headline)
+            _lib.check(lib.oz_arena_set_dedup(h, 0))
         _lib.check(lib.oz_arena_run_rounds(h, int(max_rounds)))
         G = num_games
         sa, sb = np.zeros(5, np.int64), np.zeros(5, np.int64)
         _lib.check(lib.oz_arena_stats(h, _lib.p_i64(sa), _lib.p_i64(sb)))
+        ea, eb = C.c_int64(), C.c_int64()
+        _lib.check(lib.oz_arena_leaves_evaluated(h, C.byref(ea), C.byref(eb)))
         winner, points, nm = np.zeros(G, np.int8), np.zeros(G, np.int32), np.zeros(G, np.int32)
         acts, pls = np.zeros((G, 128), np.uint8), np.zeros((G, 128), np.int8)
         fb, fw = np.zeros(G, np.uint64), np.zeros(G, np.uint64)
@@ -98,4 +103,4 @@ def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, 
     finally:
         lib.oz_arena_destroy(h)
     return dict(winner=winner, points=points, n_moves=nm, actions=acts, players=pls, final_black=fb, final_white=fw,
-                stats_black=sa, stats_white=sb)
+                stats_black=sa, stats_white=sb, leaves_evaluated=ea.value + eb.value)

@@ -1607,6 +1607,27 @@ OZ_API int oz_arena_stats(oz_arena* a, int64_t* black5, int64_t* white5) {
     return mcts_stats_locked(a->mb, white5);
 }
 
+// cross-game leaf de-duplication of both agents' searches (default on, as everywhere in the library; results are identical either way)
+OZ_API int oz_arena_set_dedup(oz_arena* a, int enable) {
+    OZ_REQUIRE(a, "null arena");
+    std::lock_guard<std::mutex> lk(a->mu);
+    a->games.m->d.dedup = enable ? 1 : 0;
+    a->mb->d.dedup = enable ? 1 : 0;
+    return OZ_OK;
+}
+// positions the two agents' networks have evaluated so far (<= expansions when boards are shared between games)
+OZ_API int oz_arena_leaves_evaluated(oz_arena* a, int64_t* black, int64_t* white) {
+    OZ_REQUIRE(a && black && white, "null argument");
+    std::lock_guard<std::mutex> lk(a->mu);
+    hipSetDevice(a->games.m->device);
+    OZ_HIP(hipStreamSynchronize(a->games.m->stream));
+    unsigned long long eb = 0, ew = 0;
+    OZ_HIP(hipMemcpy(&eb, a->games.m->d.eval_leaves, sizeof eb, hipMemcpyDeviceToHost));
+    OZ_HIP(hipMemcpy(&ew, a->mb->d.eval_leaves, sizeof ew, hipMemcpyDeviceToHost));
+    *black = (int64_t)eb; *white = (int64_t)ew;
+    return OZ_OK;
+}
+
 OZ_API int oz_arena_run_rounds(oz_arena* a, int max_rounds_arg) {
     OZ_REQUIRE(a, "null arena");
     OZ_REQUIRE(max_rounds_arg >= 0, "oz_arena_run_rounds: max_rounds %d", max_rounds_arg);

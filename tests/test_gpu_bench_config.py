@@ -157,6 +157,9 @@ def test_config5_real_networks_bounded_plies_vs_oracle(oz):
     assert out["sample_mismatches"] == 0 and out["sample_games_replayed_by_oracle"] == 2
     assert out["moves"] == 512 * 3 and out["simulations"] == 512 * 3 * 800 and out["expansions"] > 0.8 * out["simulations"]
     assert out["sims_per_s"] > 0 and out["value"] > 0
+    # the leg's headline evaluates every expansion by itself; the library default shares boards between the games of a step -- same games
+    assert out["leaves_evaluated"] == out["expansions"]
+    assert out["with_cross_game_dedup"]["identical_games"] and out["with_cross_game_dedup"]["leaves_evaluated"] < out["expansions"]
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "f32"])
