@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_t_bnb_apply(const float* __restrict__ d
     const float inv = 1.0f / (float)((long long)(*d_count) * P);
     f32x4 sb = {0.f, 0.f, 0.f, 0.f};
     float amax = 0.f;
-    for (long long m = (long long)sp * rpp + rsub; m < M; m += (long long)RS * rpp) {
+    _Pragma("unroll 4") for (long long m = (long long)sp * rpp + rsub; m < M; m += (long long)RS * rpp) {          // 12 independent 16-byte loads in flight per thread; the adds stay in row order
         const size_t i = (size_t)m * C + c;
         const f32x4 av = *reinterpret_cast<const f32x4*>(a + i), xv = *reinterpret_cast<const f32x4*>(dA + i), zv = *reinterpret_cast<const f32x4*>(z + i);
         f32x4 g;
