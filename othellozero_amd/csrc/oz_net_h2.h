@@ -360,6 +360,12 @@ __global__ __launch_bounds__(256) void k_lut_build(int C, const float* __restric
 // instruction issue: a wave-per-pixel variant with 4x fewer VALU instructions (130 against the round-2 kernel's 462) measured the
 // same 0.39 ms as the round-2 kernel, and half-line stores (16 B per lane at a 32-byte stride) inflated the written bytes to
 // 0.83 GB and cancelled the gain until the stores became whole lines.
+// Ablation of THIS kernel (same probe, 0.278 ms whole): without the stores 0.118 ms -- the floor of the CU's vector-memory path for
+// the 3.6 GB of records a launch pulls through the L1s (64 B/clk/CU: 0.105 ms); with every pixel reading the same nine records (all L1
+// hits) and the real stores 0.145 ms; the stores alone (tools/ubench/store_patterns.hip) 0.075 ms = 6.2 TB/s, random 256-byte records
+// alone (tools/ubench/random_records.hip) 6.4 TB/s.  So neither HBM nor the store pattern is the wall: reads that miss L2 and the
+// output stream share the CU's memory pipe and do not overlap (0.118 + 0.145 ~ 0.278).  Plain instead of streaming stores: 0.297;
+// sc0 sc1 nt / sc1 stores: +-0 / 0.307; 1, 4 or 8 pixel groups per thread: +-0 or slower.
 #define OZ_C2L_SLICE 64       // channels per slice record (256 B)
 __device__ __forceinline__ size_t t2_record(int slice, int t, unsigned id) {          // float index of record (slice, tap, id)
     return (((size_t)slice * 9 + t) * OZ_LUT_ROWS + id) * OZ_C2L_SLICE;
