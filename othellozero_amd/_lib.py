@@ -136,6 +136,27 @@ SIGNATURES = {
 }
 
 _LIB = None
+PRELOAD_TORCH_HIP = True          # set to False before the first load() to bind the library to the system ROCm runtime even where PyTorch is installed
+
+
+def _one_hip_runtime():
+    """PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's) and load it by path.  If this
+    library is loaded first it binds to the system runtime, a later `import torch` brings the bundled one in as well, and the process
+    holds TWO HIP / HSA runtimes: streams and device pointers of one are invalid handles in the other (torch tensors handed to the
+    library, the library's RCCL exchange step on torch's RCCL -- `ncclCommInitRank: unhandled cuda error`).  So where PyTorch is
+    installed but not imported yet, its runtime is loaded first and the library's DT_NEEDED entry resolves to it (SONAME match);
+    where PyTorch is absent (a C host, examples/selfplay_host.c) the system runtime and the system RCCL are used together."""
+    import importlib.util
+    import sys
+    if not PRELOAD_TORCH_HIP or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
+        if cand and os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:            # no PyTorch, or an unusual layout: the system runtime it is
+        pass
 
 
 def load(path=None):
@@ -148,6 +169,7 @@ def load(path=None):
         raise OzLibraryError(
             f"{p} not found: the HIP extension is required (no CPU fallback). Build it with "
             "`python -m othellozero_amd.build` (hipcc --offload-arch=gfx950).")
+    _one_hip_runtime()
     try:
         lib = C.CDLL(p)
     except OSError as e:

@@ -319,3 +319,18 @@ def test_c_host_example_plays_and_pools_records(tmp_path):
     exe = _build_c_host(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SELFPLAY_HOST_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_library_and_pytorch_share_one_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as the system one) and load it by path: with the library loaded first a process
+    used to hold TWO HIP runtimes, whose streams / device pointers are invalid in each other (torch tensors handed to the library; RCCL's
+    `unhandled cuda error` in oz_comm_create).  _lib.load() now brings PyTorch's runtime in first where PyTorch is installed: either import
+    order ends with exactly one libamdhip64 mapped."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tail = ("; print(sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l)))")
+    for head in ("from othellozero_amd import _lib; _lib.load(); import torch", "import torch; from othellozero_amd import _lib; _lib.load()"):
+        r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {root!r}); " + head + tail], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-800:]
+        libs = eval(r.stdout.strip().splitlines()[-1])
+        assert len(libs) == 1, (head, libs)
