@@ -396,7 +396,10 @@ def config5_arena(channels, precision, plies, games=512, sims=800, sample=2):
     t0 = time.perf_counter()
     rd = arena_batch(nets[0], nets[1], n, games, sims, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=plies, dedup=True)
     dtd = time.perf_counter() - t0
-    same = bool(np.array_equal(r["actions"], rd["actions"]) and np.array_equal(r["final_black"], rd["final_black"]) and np.array_equal(r["final_white"], rd["final_white"]))
+    live = np.arange(128)[None, :] < r["n_moves"][:, None]                     # the moves actually played
+    same = bool(np.array_equal(r["n_moves"], rd["n_moves"]) and np.array_equal(r["actions"][live], rd["actions"][live])
+                and np.array_equal(r["players"][live], rd["players"][live])
+                and np.array_equal(r["final_black"], rd["final_black"]) and np.array_equal(r["final_white"], rd["final_white"]))
     moves = int(r["n_moves"].sum())
     st = r["stats_black"] + r["stats_white"]
     caches = [{}, {}]

@@ -1569,6 +1569,7 @@ OZ_API int oz_arena_create(oz_arena** out, int n, int num_games, int sims, doubl
     if (!rc && hipMalloc((void**)&a->d_players, (size_t)num_games * 128) != hipSuccess) rc = OZ_ERR_HIP;
     if (!rc && hipMalloc((void**)&a->d_nmoves, 4ull * num_games) != hipSuccess) rc = OZ_ERR_HIP;
     if (!rc && hipMalloc((void**)&a->d_movers, 8) != hipSuccess) rc = OZ_ERR_HIP;
+    if (!rc && (hipMemset(a->d_actions, 0, (size_t)num_games * 128) != hipSuccess || hipMemset(a->d_players, 0, (size_t)num_games * 128) != hipSuccess)) rc = OZ_ERR_HIP;   // entries beyond n_moves read 0
     if (rc) {
         for (void* p : sp->allocs) hipFree(p);
         mcts_destroy(sp->m); mcts_destroy(a->mb);
