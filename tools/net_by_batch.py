@@ -1,5 +1,7 @@
-import sys, numpy as np
-sys.path.insert(0, "/root/repo")
+"""Per-kernel time of the OthelloNN forward at medium batch sizes (the arena's 512 games, 1024, 2048): where the launches of a small batch go.
+    python tools/net_by_batch.py      (on the GPU box)"""
+import os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from othellozero_amd.NNet import NNetWrapper
 rs = np.random.RandomState(0)
 for B in (512, 1024, 2048):
