@@ -387,6 +387,7 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
     bool& attr_set = attr_set_dev[dev_now & 63];
     if (!attr_set) {
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2BigPP::LDS));
+        OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2MidPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2MidPP::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small2::LDS));
         attr_set = true;
@@ -397,7 +398,12 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
     g.slab = Mmax * N;
     const long long big_blocks = ((Mmax + 255) / 256) * (N / 256);
     const bool big = big_blocks >= 192;
-    const int BM = big ? 256 : 128, BN = big ? 256 : 128;
+    // between the two ping-pong tiles, the one whose grid pays fewer tile-rows (rounds of 256 CUs x tile height), as the inference forward
+    // picks conv3's: 1024 boards of conv3 = 36864 rows -> 256-row tiles 288 blocks = 2 rounds x 256, 192-row tiles 384 blocks = 2 x 192.
+    // Both add every output's products in the same order.
+    auto tile_cost = [&](int bm) { return ((((Mmax + bm - 1) / bm) * (N / 256) + 255) / 256) * bm; };
+    const bool mid = big && tile_cost(192) < tile_cost(256);
+    const int BM = mid ? 192 : big ? 256 : 128, BN = big ? 256 : 128;
     const int num_mt = (int)((Mmax + BM - 1) / BM);
     int ksplit = 1;
     if (!big && partial) {
@@ -408,7 +414,10 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
     g.ksplit = ksplit;
     const int grid = ((num_mt + 7) / 8) * 8 * (N / BN) * ksplit;
     void* dst = ksplit > 1 ? (void*)partial : (void*)out;
-    if (big)
+    if (mid)
+        hipLaunchKernelGGL(k_gemm_h2<H2MidPP>, dim3(grid), dim3(H2MidPP::NT), H2MidPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
+                           d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
+    else if (big)
         hipLaunchKernelGGL(k_gemm_h2<H2BigPP>, dim3(grid), dim3(H2BigPP::NT), H2BigPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
                            d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
     else if (ksplit <= 4)
