@@ -360,12 +360,20 @@ __global__ __launch_bounds__(256) void k_lut_build(int C, const float* __restric
 // instruction issue: a wave-per-pixel variant with 4x fewer VALU instructions (130 against the round-2 kernel's 462) measured the
 // same 0.39 ms as the round-2 kernel, and half-line stores (16 B per lane at a 32-byte stride) inflated the written bytes to
 // 0.83 GB and cancelled the gain until the stores became whole lines.
-// Ablation of THIS kernel (same probe, 0.278 ms whole): without the stores 0.118 ms -- the floor of the CU's vector-memory path for
-// the 3.6 GB of records a launch pulls through the L1s (64 B/clk/CU: 0.105 ms); with every pixel reading the same nine records (all L1
-// hits) and the real stores 0.145 ms; the stores alone (tools/ubench/store_patterns.hip) 0.075 ms = 6.2 TB/s, random 256-byte records
-// alone (tools/ubench/random_records.hip) 6.4 TB/s.  So neither HBM nor the store pattern is the wall: reads that miss L2 and the
-// output stream share the CU's memory pipe and do not overlap (0.118 + 0.145 ~ 0.278).  Plain instead of streaming stores: 0.297;
-// sc0 sc1 nt / sc1 stores: +-0 / 0.307; 1, 4 or 8 pixel groups per thread: +-0 or slower.
+// Ablation of THIS kernel (same probe, 0.285 ms whole on the box of the second series): the stores compiled in but never taken 0.208 ms;
+// the same with the pattern ids masked to 1024 (every record an L2 hit) and the real stores 0.200 ms; real reads with the stores folded onto
+// 4096 pixels (L2-resident lines) 0.27 ms; every pixel reading the same nine records (all L1 hits) and the real stores 0.145 ms; the stores
+// alone (tools/ubench/store_patterns.hip) 0.075 ms = 6.2 TB/s; random 256-byte records alone (tools/ubench/random_records.hip) 6.4 TB/s.
+// So the wall is neither HBM nor L2 misses nor the store pattern: it is the 3.6 GB of records that the L1s pull out of the L2s per launch
+// (84 % of the lines: the nine records of a pixel are almost never in a 32 KB L1 -- on positions of all plies the 128 most frequent
+// (tap, pattern) records cover 22 % of the reads, the 8192 most frequent 64 %) at ~21 TB/s of L2 -> L1 traffic, ~55 % of the eight L2s' peak,
+// the same with the table L2-resident.  Skipping the off-board taps (16 % of the loads, all L1 hits of the zero record) under the exec mask
+// +-0 (and the compiler serialises the predicated loads).  Plain instead of streaming stores: 0.297; sc0 sc1 nt / sc1 stores: +-0 / 0.307;
+// 1, 4 or 8 pixel groups per thread: +-0 or slower.
+// Hiding it instead (round 3, measured and removed): the batch as 2 / 4 position ranges, the gather of range i + 1 on a second stream under
+// conv3 of range i (the gather leaves the matrix cores idle, conv3 the L2s at ~40 %) -- bit-identical, the kernels do overlap, and conv3
+// slows by what the gather gains (conv3 per batch 1.094 -> 1.113 / 1.239 ms, whole step 213.4 -> 218.3 / 219.9 ms): the chip is power
+// limited, the overlapped work is paid in clock.
 #define OZ_C2L_SLICE 64       // channels per slice record (256 B)
 __device__ __forceinline__ size_t t2_record(int slice, int t, unsigned id) {          // float index of record (slice, tap, id)
     return (((size_t)slice * 9 + t) * OZ_LUT_ROWS + id) * OZ_C2L_SLICE;
