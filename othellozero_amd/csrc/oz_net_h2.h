@@ -364,12 +364,18 @@ __global__ __launch_bounds__(256) void k_lut_build(int C, const float* __restric
 // the same with the pattern ids masked to 1024 (every record an L2 hit) and the real stores 0.200 ms; real reads with the stores folded onto
 // 4096 pixels (L2-resident lines) 0.27 ms; every pixel reading the same nine records (all L1 hits) and the real stores 0.145 ms; the stores
 // alone (tools/ubench/store_patterns.hip) 0.075 ms = 6.2 TB/s; random 256-byte records alone (tools/ubench/random_records.hip) 6.4 TB/s.
-// So the wall is neither HBM nor L2 misses nor the store pattern: it is the 3.6 GB of records that the L1s pull out of the L2s per launch
-// (84 % of the lines: the nine records of a pixel are almost never in a 32 KB L1 -- on positions of all plies the 128 most frequent
-// (tap, pattern) records cover 22 % of the reads, the 8192 most frequent 64 %) at ~21 TB/s of L2 -> L1 traffic, ~55 % of the eight L2s' peak,
-// the same with the table L2-resident.  Skipping the off-board taps (16 % of the loads, all L1 hits of the zero record) under the exec mask
-// +-0 (and the compiler serialises the predicated loads).  Plain instead of streaming stores: 0.297; sc0 sc1 nt / sc1 stores: +-0 / 0.307;
-// 1, 4 or 8 pixel groups per thread: +-0 or slower.
+// So the wall is neither HBM nor the store pattern.  Counters (profiles/r3_conv2_gather_tcp_counters.txt): 2 183 TLB misses in 93 M translations;
+// 93.9 M 64-byte L1 accesses = 57 % of the launch's cycles per CU, another 39 % the L1 waits on L2 data; 22.6 M L1 -> L2 read requests (2.9 GB:
+// L1 hit rate 33 % -- the L1 holds 256 lines and 16 waves x 144 lines are in flight, so only same-instruction duplicates and the zero record
+// hit; on positions of all plies the 128 most frequent (tap, pattern) records cover 22 % of the reads, the 8192 most frequent 64 %) at 372
+// cycles average latency, 7.5 M 64-byte write requests.  What the launch time follows is the traffic through the eight L2s -- 2.9 GB of record
+// reads + 0.56 GB of miss fills + 0.47 GB of writes at half the read rate, ~5 GB-equivalent at the ~17 TB/s the L2s sustain on random lines
+// (half their 34 TB/s peak) = 0.28 ms; every variant that leaves that traffic alone measured +-0 (bit-identical outputs each time):
+//   the off-board taps (16 % of the record loads) dropped by the range check of per-tap buffer descriptors: 0.277 -> 0.285 / 0.280 ms;
+//   the 30 neighbourhood ids of a wave's board row loaded once per wave and handed out by ds_bpermute (8 lanes x 8 pixels x 9 ids before): 0.273;
+//   both (25 % fewer L1 accesses): 0.268 .. 0.280;  5 instead of 4 waves per SIMD (scale / shift loaded late, 88 VGPRs): 0.291 .. 0.302;
+//   HALF the waves per CU: 0.345 (so not latency-bound either);  pixels ordered by their centre pattern (host-sorted probe): 0.283 against 0.292.
+// Plain instead of streaming stores: 0.297; sc0 sc1 nt / sc1 stores: +-0 / 0.307; 1, 4 or 8 pixel groups per thread: +-0 or slower.
 // Hiding it instead (round 3, measured and removed): the batch as 2 / 4 position ranges, the gather of range i + 1 on a second stream under
 // conv3 of range i (the gather leaves the matrix cores idle, conv3 the L2s at ~40 %) -- bit-identical, the kernels do overlap, and conv3
 // slows by what the gather gains (conv3 per batch 1.094 -> 1.113 / 1.239 ms, whole step 213.4 -> 218.3 / 219.9 ms): the chip is power
