@@ -932,7 +932,7 @@ struct OnnNet : oz_net {
         if (max_count > max_batch) { oz_set_error("batch %d exceeds max_batch %d", max_count, max_batch); return OZ_ERR_ARG; }
         if (precision == 1) return forward_h2(d_own, d_opp, d_count, max_count, d_pi, d_v, s);
         const int P = n * n;
-        // precision f32: conv1 + conv2 from the fp32 pattern tables (default), or conv1 kernel + conv2 GEMM (oz_net_set_tables 0 / 1, OZ_H2_T2=0)
+        // precision f32: conv1 + conv2 from the fp32 pattern tables (default), or conv1 kernel + conv2 GEMM (oz_net_set_tables 0 / 1)
         const bool use_t2f = (tables_mode < 0 || tables_mode >= 2) && t2f_ok;
         last_conv3_rows = GM_BM;
         profiled_layer = use_t2f ? 3 : 2;

@@ -54,8 +54,8 @@
 //     LDS-DMA pieces per wave and tile (~13 %) and barrier round trips.
 //
 // conv1 and conv2 no longer run as convolutions in this precision mode: the input planes are discrete, so both layers
-// are evaluated from tables over the 3^9 neighbourhood patterns (k_lut_ids, k_lut_build, k_conv2_lut below; switches
-// OZ_H2_T2 / OZ_H2_LUT in oz_net.hip) -- the whole-bench rate went 0.94 M -> 1.55 M expansions/s and the dominant
+// are evaluated from tables over the 3^9 neighbourhood patterns (k_lut_ids, k_lut_build, k_conv2_lut below; switch:
+// oz_net_set_tables) -- the whole-bench rate went 0.94 M -> 1.55 M expansions/s and the dominant
 // GEMM is conv3.  The GEMM kernel still serves conv2 when the tables are switched off and builds the tables at commit.
 #pragma once
 #include <type_traits>

@@ -1108,3 +1108,37 @@ def test_mcts_template_hooks_and_geometry_helpers(oz, golden_rules):
     rays = [list(r) for r in OthelloGame.get_all_directions_squares(n, 2, 3)]
     assert len(rays) == 8 and rays[0] == [(3, 4), (4, 5)] and rays[5] == [(1, 3), (0, 3)]
     assert g.is_square_free(0, 0) and not g.is_square_free(n // 2, n // 2)
+
+
+@pytest.mark.gpu
+def test_thread_workers_share_one_network_like_the_reference(oz):
+    """workers.py:33-37,82-90 + main.py:353-354: N ThreadWorkers call execute_episode concurrently, each with its own OthelloMCTS, all
+    sharing ONE NNetWrapper.  The drop-in must be thread-safe: with e_greedy = 1 an episode is a pure function of the network (the coin is
+    drawn but cannot change the move), so every thread must return exactly the examples of a serial run -- and the ctypes calls release
+    the GIL, so the threads really are inside the library at the same time."""
+    import threading
+    from othellozero_amd import training
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.weights import init_weights
+    n, C_, sims, workers = 6, 128, 10, 6
+    net = NNetWrapper((n, n), num_channels_1=C_, max_batch=1, weights=init_weights(n, seed=11, channels=C_, randomize_all=True))
+    want = training.execute_episode(n, net, 1.0, sims, 1.0, 1.0, snapshot_boards=True)
+    assert len(want) % 8 == 0 and len(want) >= 8 * 20
+    got, errors = [None] * workers, []
+
+    def work(i):
+        try:
+            got[i] = training.execute_episode(n, net, 1.0, sims, 1.0, 1.0, snapshot_boards=True)
+        except Exception as e:              # noqa: BLE001 -- reported below, in the main thread
+            errors.append((i, repr(e)))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a worker thread is stuck inside the library"
+    assert not errors, errors
+    for i in range(workers):
+        assert len(got[i]) == len(want)
+        for (b0, p0, z0), (b1, p1, z1) in zip(want, got[i]):
+            assert z0 == z1 and np.array_equal(b0, b1) and np.array_equal(p0, p1)
