@@ -1142,3 +1142,45 @@ def test_thread_workers_share_one_network_like_the_reference(oz):
         assert len(got[i]) == len(want)
         for (b0, p0, z0), (b1, p1, z1) in zip(want, got[i]):
             assert z0 == z1 and np.array_equal(b0, b1) and np.array_equal(p0, p1)
+
+
+@pytest.mark.gpu
+def test_reference_conventions_inputs_untouched_and_error_types(oz, tmp_path):
+    """SURVEY.md 8(b) conventions: the search never mutates the state it is given (np.copy at othelo_mcts.py:23,44), OthelloGame.play
+    mutates in place and refuses a finished game with AssertionError('Game has ended') (Othello/__init__.py:143), load_checkpoint asserts
+    the .h5 extension (Net/NNet.py:95), board() refuses a non-BoardView (TypeError), N() of an unknown state is 0 and of an expanded but
+    never selected state raises KeyError (MCTS/__init__.py:73-84,172-175)."""
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.Othello import BoardView, OthelloGame, OthelloPlayer
+    from othellozero_amd.othelo_mcts import OthelloMCTS
+    n = 6
+    net = PyStubNet(n, 3, 0, True)
+    g = OthelloGame(n)
+    state = g.board(BoardView.TWO_CHANNELS)
+    assert state is g.board(BoardView.TWO_CHANNELS)                       # the live array, no copy (Othello/__init__.py:77-78)
+    before = state.copy()
+    m = OthelloMCTS(n, net, 1.0, q_mode=1)
+    assert m.N(state) == 0                                                # unknown state
+    m.simulate(state, OthelloPlayer.BLACK)                                # expands the root only
+    with pytest.raises(KeyError):
+        m.N(state, (0, 0))
+    for _ in range(12):
+        m.simulate(state, OthelloPlayer.BLACK)
+    m.get_policy_action_probabilities(state, 1)
+    assert np.array_equal(state, before), "the search wrote into the caller's state"
+    r, c = m.get_state_actions(state)[0]
+    g.play(r, c)
+    assert not np.array_equal(state, before) and state is g.board(BoardView.TWO_CHANNELS)      # play() mutates the live board in place
+    with pytest.raises(TypeError):
+        g.board("two")
+    # a finished game refuses another move
+    while not g.has_finished():
+        first = next(iter(OthelloGame.get_player_valid_actions(g.board(BoardView.TWO_CHANNELS), g.current_player)))      # a generator, as in the reference
+        g.play(*tuple(int(x) for x in first))
+    with pytest.raises(AssertionError, match="Game has ended"):
+        g.play(0, 0)
+    with pytest.raises(AssertionError, match="Board size must be even"):
+        OthelloGame(5)
+    real = NNetWrapper((n, n), num_channels_1=128, max_batch=1, seed=1)
+    with pytest.raises(AssertionError, match=".h5"):
+        real.load_checkpoint(str(tmp_path / "weights.bin"))
