@@ -874,6 +874,11 @@ struct OnnNet : oz_net {
         // ... and on either board the tile whose grid pays fewer tile-rows for the batch this call may hold: rounds of 256 CUs x tile height
         // (4096 boards of 8x8: 192 rows -> 6 rounds x 192; a caller that caps its batches at 3640 gets 256 rows -> 4.0 rounds x 256, -13 % per launch).
         // Both tiles add every output element's products in the same order: bit-identical results.
+        // (round 3, measured and removed: a MIXED plan -- whole rounds of 256-row tiles, the rest of the rows on 192-row tiles in a second launch over
+        //  a position range -- with the cap that suits it, 3584 leaves: conv4 = 2048 boards on 256-row + 1536 on 192-row tiles = 1.75 rounds instead
+        //  of 2.0.  conv4 547 / 529 -> 508 us, not the 483 the round count promises (a round of 192-row tiles costs 0.84 of a 256-row round on conv4,
+        //  235 against 280 us, not 0.75), and the layers that do not shrink with the cap eat most of it: 1.696 / 1.680 M -> 1.696 / 1.691 M
+        //  expansions/s, within the run-to-run spread.)
         auto tile_cost = [&](int BM) {
             const long long blocks = (((long long)max_count * (n - 2) * (n - 2) + BM - 1) / BM) * (C / 256);
             return ((blocks + 255) / 256) * BM;
