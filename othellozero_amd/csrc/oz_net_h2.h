@@ -52,6 +52,10 @@
 //     select for the pad-0 layers pushed spills into the loop (2.19 -> 2.53 ms); s_setprio 1 for wave row 1 over the whole loop
 //     -1 %; the nt cache policy on the A pieces -5 %.  What is left is the issue cost of the 8
 //     LDS-DMA pieces per wave and tile (~13 %) and barrier round trips.
+//   The clock is the other half of the story (round 3, conv3 at 3640 leaves, same binary otherwise): with every h2 (residual) plane forced to
+//   zero -- wrong results, same instruction stream -- the launch takes 1.004 instead of 1.126 ms (-11 %); with the low 3 or 5 mantissa bits of
+//   the residuals masked (19 / 17 instead of 22 significant bits) 1.096 ms (-2.7 %, mostly small residuals that become exact zeros).  The matrix
+//   pipe's power, and with it the sustained clock, depends on the operand bits; the product keeps the full 22-bit split.
 //
 // conv1 and conv2 no longer run as convolutions in this precision mode: the input planes are discrete, so both layers
 // are evaluated from tables over the 3^9 neighbourhood patterns (k_lut_ids, k_lut_build, k_conv2_lut below; switch:
