@@ -1184,3 +1184,31 @@ def test_reference_conventions_inputs_untouched_and_error_types(oz, tmp_path):
     real = NNetWrapper((n, n), num_channels_1=128, max_batch=1, seed=1)
     with pytest.raises(AssertionError, match=".h5"):
         real.load_checkpoint(str(tmp_path / "weights.bin"))
+
+
+@pytest.mark.gpu
+def test_c_abi_empty_ragged_and_invalid_inputs(oz):
+    """the boundary's own edge cases: an empty batch is a no-op, a batch beyond max_batch is refused with an error code and a message (no
+    exception crosses the C ABI, nothing is written), the Python mirror chunks a ragged batch over max_batch-sized calls with the same
+    bits as single calls, null pointers are refused"""
+    from othellozero_amd.NNet import NNetWrapper
+    lib = oz.load()
+    n = 6
+    net = NNetWrapper((n, n), num_channels_1=128, max_batch=8, seed=4)
+    rs = np.random.RandomState(9)
+    valid = np.uint64(sum(1 << (r * 8 + c) for r in range(n) for c in range(n)))
+    own = rs.randint(0, 2**63, size=21, dtype=np.uint64) & valid
+    opp = rs.randint(0, 2**63, size=21, dtype=np.uint64) & valid & ~own
+    pi0, v0 = net.predict_batch(own[:0], opp[:0])
+    assert pi0.shape == (0, n, n) and v0.shape == (0,)
+    pi, v = net.predict_batch(own, opp)                                   # 21 positions over calls of 8, 8, 5
+    for i in (0, 7, 8, 20):
+        p1, v1 = net.predict_batch(own[i:i + 1], opp[i:i + 1])
+        assert np.array_equal(p1[0], pi[i]) and v1[0] == v[i]
+    out_pi, out_v = np.full((9, n * n), 7.0, np.float32), np.full(9, 7.0, np.float32)
+    rc = lib.oz_net_predict(net._h, oz.p_u64(own[:9].copy()), oz.p_u64(opp[:9].copy()), 9, oz.p_f32(out_pi), oz.p_f32(out_v))
+    assert rc == oz.OZ_ERR_ARG and b"max_batch" in lib.oz_last_error()
+    assert np.all(out_pi == 7.0) and np.all(out_v == 7.0)
+    assert lib.oz_net_predict(net._h, None, None, 1, oz.p_f32(out_pi), oz.p_f32(out_v)) == oz.OZ_ERR_ARG
+    assert lib.oz_net_predict(net._h, oz.p_u64(own[:1].copy()), oz.p_u64(opp[:1].copy()), 0, oz.p_f32(out_pi), oz.p_f32(out_v)) == oz.OZ_OK
+    assert np.all(out_pi == 7.0)
