@@ -11,7 +11,8 @@ episode / arena drivers, as hand-written HIP kernels for gfx950 in `lib/libothel
                  SelfPlayEngine, selfplay_batch, expand_examples      (training.py)
     agents       NeuralNetworkOthelloAgent, RandomOthelloAgent,
                  duel_between_agents, arena_batch                     (agents.py)
-    distributed  shard_games, gather_records (RCCL all-gather)        (workers.py's role)
+    distributed  shard_games, gather_records (RCCL all-gather),
+                 arena_sharded                                        (workers.py's role)
 
 Importing the package loads nothing heavy; the first call that computes loads the HIP library and
 fails loudly if it (or a GPU) is missing -- there is no CPU fallback.

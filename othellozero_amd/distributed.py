@@ -36,7 +36,7 @@ def tensor_to_records(t):
 
 
 def gather_records(local, group=None, single_rank_collective=False):
-    """all-gather variable-length record tensors (uint8 [R_i, 48]) -> uint8 [sum R_i, 48] on every rank,
+    """all-gather variable-length record tensors (uint8 [R_i, W]; W = 48 for move records) -> uint8 [sum R_i, W] on every rank,
     ordered by rank.  Counts are gathered first, payloads are padded to the per-rank maximum.
     A one-rank group returns `local` without a collective unless single_rank_collective is set (the one-GPU test of
     the RCCL calls themselves)."""
@@ -53,9 +53,10 @@ def gather_records(local, group=None, single_rank_collective=False):
     mx = max(counts)
     if mx == 0:
         return local
-    padded = torch.zeros((mx, RECORD_BYTES), dtype=torch.uint8, device=dev)
+    width = int(local.shape[1])
+    padded = torch.zeros((mx, width), dtype=torch.uint8, device=dev)
     padded[: local.shape[0]] = local
-    out = torch.empty((world * mx, RECORD_BYTES), dtype=torch.uint8, device=dev)
+    out = torch.empty((world * mx, width), dtype=torch.uint8, device=dev)
     if dev.type == "cuda" and hasattr(dist, "all_gather_into_tensor"):
         dist.all_gather_into_tensor(out, padded, group=group)
     else:
@@ -83,6 +84,33 @@ def pooled_selfplay_records(engine, device, group=None):
     """records of every rank's completed games, identical on all ranks, sorted by (game_id, ply)"""
     allrec = tensor_to_records(gather_records(engine_records_tensor(engine, device), group))
     return allrec[np.lexsort((allrec["ply"], allrec["game_id"]))]
+
+
+# ---------------------------------------------------------------- arena games sharded over the ranks (SURVEY.md 8(e): all-gather of (winner, points))
+ARENA_RESULT_DTYPE = np.dtype([("game_id", "<i4"), ("points", "<i4"), ("n_moves", "<i4"), ("winner", "i1"), ("pad", "u1", 3)])
+
+
+def arena_sharded(net_a, net_b, board_size=8, total_games=512, num_simulations=800, degree_exploration=1.0, seed=0, device="cpu",
+                  group=None, **arena_kwargs):
+    """agents.arena_batch with the games sharded over the ranks (contiguous blocks of global game ids, shard_games) and ONE all-gather of
+    the per-game results -- 16 bytes per game: id, winner (+1 = BLACK's agent), points, moves -- so that every rank holds the whole match,
+    sorted by game id.  Replaces the reference's fan-out of duels over workers and the concatenation of their result lists
+    (workers.py:168-184, main.py:196-214).  A game's moves depend on its global id only (RNG streams are keyed by it), never on the
+    rank that played it: the pooled result equals one arena_batch of all the games.  `device`: where the gathered tensor lives
+    ("cuda" for the nccl = RCCL backend, "cpu" for gloo); extra keyword arguments go to arena_batch."""
+    from .agents import arena_batch
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    first, count = shard_games(total_games, rank, world)
+    rows = np.zeros(count, dtype=ARENA_RESULT_DTYPE)
+    if count:
+        res = arena_batch(net_a, net_b, board_size, count, num_simulations, degree_exploration, seed=seed, first_game_id=first, **arena_kwargs)
+        rows["game_id"] = first + np.arange(count)
+        rows["winner"], rows["points"], rows["n_moves"] = res["winner"], res["points"], res["n_moves"]
+    t = torch.from_numpy(rows.view(np.uint8).reshape(-1, ARENA_RESULT_DTYPE.itemsize).copy()).to(device)
+    pooled = gather_records(t, group).detach().cpu().contiguous().numpy().reshape(-1).view(ARENA_RESULT_DTYPE)
+    pooled = pooled[np.argsort(pooled["game_id"], kind="stable")]
+    return dict(game_id=pooled["game_id"].copy(), winner=pooled["winner"].copy(), points=pooled["points"].copy(), n_moves=pooled["n_moves"].copy())
 
 
 # ---------------------------------------------------------------- the same exchange step behind the C ABI (no torch on the data path)

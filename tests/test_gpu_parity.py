@@ -1212,3 +1212,25 @@ def test_c_abi_empty_ragged_and_invalid_inputs(oz):
     assert lib.oz_net_predict(net._h, None, None, 1, oz.p_f32(out_pi), oz.p_f32(out_v)) == oz.OZ_ERR_ARG
     assert lib.oz_net_predict(net._h, oz.p_u64(own[:1].copy()), oz.p_u64(opp[:1].copy()), 0, oz.p_f32(out_pi), oz.p_f32(out_v)) == oz.OZ_OK
     assert np.all(out_pi == 7.0)
+
+
+@pytest.mark.gpu
+def test_arena_shards_equal_the_whole_arena(oz):
+    """arena games shard over ranks like self-play games.  A game depends on its GLOBAL id only (the RNG streams of the
+    random agent and of the max-visit tie-break are keyed by it), so two shards played separately equal one arena of all the games, and
+    distributed.arena_sharded on a one-rank world equals agents.arena_batch."""
+    from othellozero_amd.agents import arena_batch
+    from othellozero_amd.distributed import arena_sharded
+    n, sims, G = 6, 10, 10
+    from othellozero_amd.NNet import StubNetWrapper
+    a = StubNetWrapper((n, n), 21, 0, max_batch=G)
+    whole = arena_batch(a, None, n, G, sims, 1.0, seed=5)                        # stub network (BLACK) against the random agent (WHITE)
+    lo = arena_batch(a, None, n, 6, sims, 1.0, seed=5, first_game_id=0)
+    hi = arena_batch(a, None, n, 4, sims, 1.0, seed=5, first_game_id=6)
+    for k in ("winner", "points", "n_moves", "final_black", "final_white"):
+        assert np.array_equal(whole[k], np.concatenate([lo[k], hi[k]])), k
+    assert len(set(whole["final_black"].tolist())) > 1                           # the random agent makes the games differ
+    pooled = arena_sharded(a, None, n, G, sims, 1.0, seed=5)
+    assert np.array_equal(pooled["game_id"], np.arange(G))
+    for k in ("winner", "points", "n_moves"):
+        assert np.array_equal(pooled[k], whole[k]), k

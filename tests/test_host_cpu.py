@@ -186,6 +186,18 @@ try:
     raise SystemExit("the poisoned all-reduce did not raise on rank %d" % rank)
 except _lib.OzError as e:
     assert e.code == _lib.OZ_ERR_STATE and (("range guard" in str(e)) == (rank == 1))
+# arena games sharded over the ranks: ONE all-gather of 16-byte results, every rank ends with the whole match sorted by game id
+import othellozero_amd.agents as agents
+from othellozero_amd.distributed import arena_sharded
+def fake_arena(net_a, net_b, board_size, num_games, num_simulations, degree_exploration, seed=0, first_game_id=0, **kw):
+    ids = first_game_id + np.arange(num_games)
+    return dict(winner=(1 - 2 * (ids & 1)).astype(np.int8), points=(30 + ids).astype(np.int32), n_moves=(50 + ids).astype(np.int32))
+agents.arena_batch = fake_arena
+res = arena_sharded(None, None, 6, 7, 10)            # 7 games: 4 + 3
+assert np.array_equal(res["game_id"], np.arange(7)) and np.array_equal(res["winner"], 1 - 2 * (np.arange(7) & 1))
+assert np.array_equal(res["points"], 30 + np.arange(7)) and np.array_equal(res["n_moves"], 50 + np.arange(7))
+res1 = arena_sharded(None, None, 6, 1, 10)           # fewer games than ranks: rank 1 plays none
+assert np.array_equal(res1["game_id"], [0]) and res1["points"][0] == 30
 dist.barrier()
 print("RANK_OK", rank)
 """
