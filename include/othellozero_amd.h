@@ -87,6 +87,8 @@ int oz_net_check(oz_net* net);
 int oz_net_commit(oz_net* net);
 /* NNetWrapper.predict (Net/NNet.py:70-87) for `count` canonical boards: pi[count][n*n] float32, v[count] float32 */
 int oz_net_predict(oz_net* net, const uint64_t* own, const uint64_t* opp, int count, float* pi, float* v);
+/* the same on boards in the reference's layout (Net/NNet.py:80-84): count x (n, n, 2) bytes NHWC, channel 0 = the mover, non-zero = a disc */
+int oz_net_predict_boards(oz_net* net, const uint8_t* boards_nhwc, int count, float* pi, float* v);
 /* timing hook for bench.py: run the forward `iters` times on `count` resident boards, return avg ms per forward (HIP events) */
 int oz_net_time_forward(oz_net* net, int count, int iters, float* ms_avg);
 /* HIP-event timing of the dominant launch on the stream it is launched on: the conv3 implicit GEMM when conv1 + conv2

@@ -80,6 +80,7 @@ SIGNATURES = {
     "oz_net_commit": [_vp],
     "oz_net_set_precision": [_vp, C.c_int], "oz_net_get_precision": [_vp], "oz_net_check": [_vp],
     "oz_net_predict": [_vp, _u64p, _u64p, C.c_int, _f32p, _f32p],
+    "oz_net_predict_boards": [_vp, _u8p, C.c_int, _f32p, _f32p],
     "oz_net_time_forward": [_vp, C.c_int, C.c_int, _f32p],
     "oz_net_profile": [_vp, C.c_int], "oz_net_profile_read": [_vp, _f64p, _i64p],
     "oz_net_profiled_layer": [_vp, C.POINTER(C.c_int)], "oz_net_set_tables": [_vp, C.c_int],

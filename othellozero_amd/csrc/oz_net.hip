@@ -1280,6 +1280,28 @@ OZ_API int oz_net_predict(oz_net* net, const uint64_t* own, const uint64_t* opp,
     return flag ? net->check() : OZ_OK;
 }
 
+// The same call on boards in the reference's own layout: `boards` = count x (n, n, 2) bytes, NHWC, channel 0 = the mover's discs, any
+// non-zero byte = a disc -- what Net/NNet.py:80-84 feeds Keras (np.bool (n, n, 2) boards).  Packed to bitboards here, on the host.
+OZ_API int oz_net_predict_boards(oz_net* net, const uint8_t* boards, int count, float* pi, float* v) {
+    OZ_REQUIRE(net && boards && pi && v, "null argument");
+    OZ_REQUIRE(count >= 0 && count <= net->max_batch, "count %d outside [0, max_batch=%d]", count, net->max_batch);
+    const int n = net->n;
+    std::vector<uint64_t> own((size_t)count), opp((size_t)count);
+    for (int b = 0; b < count; ++b) {
+        const uint8_t* p = boards + (size_t)b * n * n * 2;
+        uint64_t o = 0, q = 0;
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) {
+                const uint8_t* cell = p + (size_t)(r * n + c) * 2;
+                OZ_REQUIRE(!(cell[0] && cell[1]), "board %d: square (%d, %d) holds a disc in both channels", b, r, c);
+                if (cell[0]) o |= 1ull << (r * 8 + c);
+                if (cell[1]) q |= 1ull << (r * 8 + c);
+            }
+        own[b] = o; opp[b] = q;
+    }
+    return oz_net_predict(net, own.data(), opp.data(), count, pi, v);
+}
+
 __global__ void k_fill_boards(uint64_t* own, uint64_t* opp, int count, uint64_t valid) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;

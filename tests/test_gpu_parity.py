@@ -1212,6 +1212,13 @@ def test_c_abi_empty_ragged_and_invalid_inputs(oz):
     assert lib.oz_net_predict(net._h, None, None, 1, oz.p_f32(out_pi), oz.p_f32(out_v)) == oz.OZ_ERR_ARG
     assert lib.oz_net_predict(net._h, oz.p_u64(own[:1].copy()), oz.p_u64(opp[:1].copy()), 0, oz.p_f32(out_pi), oz.p_f32(out_v)) == oz.OZ_OK
     assert np.all(out_pi == 7.0)
+    # the reference's own board layout at the boundary (Net/NNet.py:80-84): (n, n, 2) NHWC bytes, channel 0 = the mover
+    boards = np.stack([oz.unpack_board(int(o), int(p), n) for o, p in zip(own[:8], opp[:8])]).astype(np.uint8)
+    bp, bv = np.zeros((8, n * n), np.float32), np.zeros(8, np.float32)
+    assert lib.oz_net_predict_boards(net._h, oz.p_u8(np.ascontiguousarray(boards)), 8, oz.p_f32(bp), oz.p_f32(bv)) == oz.OZ_OK
+    assert np.array_equal(bp.reshape(8, n, n), pi[:8]) and np.array_equal(bv, v[:8])
+    both = boards[:1].copy(); both[0, 2, 2, :] = 1
+    assert lib.oz_net_predict_boards(net._h, oz.p_u8(both), 1, oz.p_f32(bp), oz.p_f32(bv)) == oz.OZ_ERR_ARG
 
 
 @pytest.mark.gpu
