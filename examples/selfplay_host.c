@@ -1,5 +1,5 @@
 /* selfplay_host.c -- the hot path driven from plain C through the C ABI (include/othellozero_amd.h), no Python, no torch:
- * one rank of a (possibly multi-GPU) self-play job.  It builds an OthelloNN with pseudo-random weights, plays `games` concurrent
+ * one rank of a (possibly multi-GPU) self-play job.  It builds a freshly initialised OthelloNN (oz_net_init_random), plays `games` concurrent
  * 6x6 games to the end with the batched engine, and pools the move records of all ranks with the library's own RCCL communicator
  * (oz_comm_* / oz_selfplay_gather_records -- the role of WorkerManager.get_results, workers.py:168-184).
  *
@@ -7,6 +7,9 @@
  *   ./selfplay_host [rank world id_file]          (one process per GPU; rank 0 writes the 128-byte communicator id to id_file,
  *                                                  the other ranks read it; without arguments: one rank)
  */
+#ifndef _DEFAULT_SOURCE
+#define _DEFAULT_SOURCE            /* usleep */
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,12 +20,6 @@
 
 #define CHECK(call) do { int rc_ = (call); if (rc_ != OZ_OK) { fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, oz_last_error()); return 1; } } while (0)
 
-static uint64_t lcg = 88172645463325252ULL;
-static float frand(void) {                       /* xorshift, uniform in [-1, 1) */
-    lcg ^= lcg << 13; lcg ^= lcg >> 7; lcg ^= lcg << 17;
-    return (float)((double)(lcg >> 11) / 9007199254740992.0 * 2.0 - 1.0);
-}
-
 int main(int argc, char** argv) {
     const int rank = argc > 2 ? atoi(argv[1]) : 0, world = argc > 2 ? atoi(argv[2]) : 1;
     const char* id_file = argc > 3 ? argv[3] : NULL;
@@ -30,18 +27,11 @@ int main(int argc, char** argv) {
     if (oz_device_count() <= 0) { fprintf(stderr, "no HIP device\n"); return 2; }
     CHECK(oz_set_device(rank % oz_device_count()));
 
-    /* the network: same weights on every rank (same generator state); kernels ~ U(-s, s), BN gamma / variance 1, everything else 0 */
+    /* the network: a fresh OthelloNN as Keras would initialise it, the same weights on every rank (same seed).  A trained network comes in through
+     * oz_net_set_weight(net, i, data, count), i = 0 .. oz_net_num_weights(net) - 1 in Keras' get_weights() order. */
     oz_net* net = NULL;
     CHECK(oz_net_create(&net, n, channels, games));
-    for (int i = 0; i < oz_net_num_weights(net); ++i) {
-        int64_t cnt = 0;
-        CHECK(oz_net_weight_size(net, i, &cnt));
-        float* w = (float*)malloc(sizeof(float) * (size_t)cnt);
-        const int is_kernel = (i < 36 && i % 6 == 0) || i == 36 || i == 38, is_one = i < 36 && (i % 6 == 2 || i % 6 == 5);
-        for (int64_t k = 0; k < cnt; ++k) w[k] = is_kernel ? 0.05f * frand() : is_one ? 1.0f : 0.0f;
-        CHECK(oz_net_set_weight(net, i, w, cnt));
-        free(w);
-    }
+    CHECK(oz_net_init_random(net, 2024));
     CHECK(oz_net_commit(net));
 
     /* games sharded by global id: rank r owns ids [r * games, (r + 1) * games); per-game RNG streams are keyed by the global id */

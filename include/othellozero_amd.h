@@ -75,6 +75,9 @@ int oz_net_num_weights(const oz_net* net);
 int oz_net_weight_size(const oz_net* net, int index, int64_t* nelem);
 int oz_net_set_weight(oz_net* net, int index, const float* data, int64_t nelem);
 int oz_net_get_weight(const oz_net* net, int index, float* data, int64_t nelem);
+/* a fresh OthelloNN as Keras initialises it (Net/OthelloNN.py:42-56: glorot_uniform kernels, zero biases, identity BatchNormalization) from a
+ * deterministic stream keyed by `seed`; follow with oz_net_commit.  Not NumPy's numbers for that seed: read them back with oz_net_get_weight. */
+int oz_net_init_random(oz_net* net, uint64_t seed);
 /* arithmetic of the 3x3 convolutions: 0 = exact fp32 matrix cores (v_mfma_f32_32x32x2_f32);
  * 1 = "f32 via 2 x fp16 split": x = h1 + h2, products a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_16x16x32_f16 with fp32
  * accumulation (<= 2^-22 relative per product, the class of fp32 accumulation error; needs channels % 256 == 0 and

@@ -73,6 +73,13 @@ class NNetWrapper(_NetHandle):
             _lib.check(lib.oz_net_set_weight(self._h, i, _lib.p_f32(a), a.size))
         _lib.check(lib.oz_net_commit(self._h))
 
+    def init_random(self, seed):
+        """a fresh network as Keras initialises it (glorot_uniform kernels, zero biases, identity BatchNormalization) from the LIBRARY's own
+        deterministic stream (oz_net_init_random: what a C host gets; not NumPy's numbers for that seed), committed"""
+        lib = _lib.load()
+        _lib.check(lib.oz_net_init_random(self._h, int(seed)))
+        _lib.check(lib.oz_net_commit(self._h))
+
     def get_weights(self):
         lib = _lib.load()
         out = []

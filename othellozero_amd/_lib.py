@@ -79,6 +79,7 @@ SIGNATURES = {
     "oz_net_get_weight": [_vp, C.c_int, _f32p, C.c_int64],
     "oz_net_commit": [_vp],
     "oz_net_set_precision": [_vp, C.c_int], "oz_net_get_precision": [_vp], "oz_net_check": [_vp],
+    "oz_net_init_random": [_vp, C.c_uint64],
     "oz_net_predict": [_vp, _u64p, _u64p, C.c_int, _f32p, _f32p],
     "oz_net_predict_boards": [_vp, _u8p, C.c_int, _f32p, _f32p],
     "oz_net_time_forward": [_vp, C.c_int, C.c_int, _f32p],

@@ -1102,6 +1102,37 @@ OZ_API int oz_net_set_weight(oz_net* net, int index, const float* data, int64_t 
     o->committed = false;
     return OZ_OK;
 }
+// Keras' defaults for a fresh OthelloNN (Net/OthelloNN.py:42-56): glorot_uniform kernels -- U(-l, l), l = sqrt(6 / (fan_in + fan_out)), fan = receptive
+// field x channels for the 3x3 layers -- zero biases, BatchNormalization gamma 1, beta 0, moving mean 0, moving variance 1.  The stream is
+// splitmix64 keyed by (seed, array index, element): the same weights on every rank and every host that asks for the same seed (they are NOT the
+// numbers NumPy would draw for that seed; read them back with oz_net_get_weight).  oz_net_commit afterwards, as after oz_net_set_weight.
+OZ_API int oz_net_init_random(oz_net* net, uint64_t seed) {
+    OnnNet* o = as_onn(net);
+    OZ_REQUIRE(o, "not an OthelloNN network");
+    std::lock_guard<std::mutex> lk(o->mu);
+    const int C_ = o->C, n2 = o->A;
+    for (int i = 0; i < 40; ++i) {
+        std::vector<float>& a = o->w[i];
+        const int layer = i < 36 ? i / 6 : 6 + (i - 36) / 2, part = i < 36 ? i % 6 : (i - 36) % 2;      // part 0 = kernel, 1 = bias, 2..5 = gamma, beta, mean, variance
+        if (part == 0) {
+            double fan_in, fan_out;
+            if (layer < 4) { fan_in = 9.0 * (layer == 0 ? o->cin : C_); fan_out = 9.0 * C_; }
+            else if (layer == 4) { fan_in = o->F; fan_out = 1024; }
+            else if (layer == 5) { fan_in = 1024; fan_out = 512; }
+            else { fan_in = 512; fan_out = layer == 6 ? n2 : 1; }
+            const double lim = sqrt(6.0 / (fan_in + fan_out));
+            for (size_t k = 0; k < a.size(); ++k) {
+                const uint64_t r = oz_sm64(oz_sm64(seed * 0x9E3779B97F4A7C15ull + (uint64_t)i) + k);
+                a[k] = (float)((2.0 * ((double)(r >> 11) * (1.0 / 9007199254740992.0)) - 1.0) * lim);
+            }
+        } else {
+            const float fill = (part == 2 || part == 5) ? 1.0f : 0.0f;
+            for (auto& x : a) x = fill;
+        }
+    }
+    o->committed = false;
+    return OZ_OK;
+}
 OZ_API int oz_net_get_weight(const oz_net* net, int index, float* data, int64_t nelem) {
     const OnnNet* o = as_onn(const_cast<oz_net*>(net));
     OZ_REQUIRE(o && data, "not an OthelloNN network");

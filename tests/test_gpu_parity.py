@@ -1241,3 +1241,35 @@ def test_arena_shards_equal_the_whole_arena(oz):
     assert np.array_equal(pooled["game_id"], np.arange(G))
     for k in ("winner", "points", "n_moves"):
         assert np.array_equal(pooled[k], whole[k]), k
+
+
+@pytest.mark.gpu
+def test_library_side_random_initialisation_is_keras_default_and_deterministic(oz):
+    """oz_net_init_random (the C host's way to a fresh OthelloNN): glorot_uniform limits per layer, zero biases, identity BatchNormalization
+    (Net/OthelloNN.py:42-56 with Keras defaults), the same weights for the same seed, and a network the float64 oracle agrees with"""
+    from othellozero_amd.NNet import NNetWrapper
+    n, C_ = 6, 128
+    net = NNetWrapper((n, n), num_channels_1=C_, max_batch=8, seed=1)
+    net.init_random(42)
+    w = net.get_weights()
+    other = NNetWrapper((n, n), num_channels_1=C_, max_batch=8, seed=2)
+    other.init_random(42)
+    assert all(np.array_equal(a, b) for a, b in zip(w, other.get_weights()))
+    other.init_random(43)
+    assert not np.array_equal(w[6], other.get_weights()[6])
+    fans = [(9 * 2, 9 * C_), (9 * C_, 9 * C_), (9 * C_, 9 * C_), (9 * C_, 9 * C_), ((n - 4) ** 2 * C_, 1024), (1024, 512)]
+    for layer, (fi, fo) in enumerate(fans):
+        k, bias, gamma, beta, mean, var = w[6 * layer: 6 * layer + 6]
+        lim = np.sqrt(6.0 / (fi + fo))
+        assert np.abs(k).max() <= lim * (1 + 1e-6) and np.abs(k).max() > 0.98 * lim and abs(float(k.mean())) < 0.02 * lim
+        assert abs(float(k.std()) - lim / np.sqrt(3.0)) < 0.03 * lim                 # uniform on (-lim, lim)
+        assert not bias.any() and np.all(gamma == 1) and not beta.any() and not mean.any() and np.all(var == 1)
+    for k, bias, fo in ((w[36], w[37], n * n), (w[38], w[39], 1)):
+        assert np.abs(k).max() <= np.sqrt(6.0 / (512 + fo)) * (1 + 1e-6) and not bias.any()
+    rs = np.random.RandomState(3)
+    valid = np.uint64(sum(1 << (r * 8 + c) for r in range(n) for c in range(n)))
+    own = rs.randint(0, 2**63, size=8, dtype=np.uint64) & valid
+    opp = rs.randint(0, 2**63, size=8, dtype=np.uint64) & valid & ~own
+    pi, v = net.predict_batch(own, opp)
+    pi64, v64 = nn_numpy.forward(w, own, opp, n)
+    assert np.abs(pi.reshape(8, -1) - pi64).max() <= 1e-5 and np.abs(v - v64).max() <= 1e-5       # tolerance 1e-5 (north_star)
