@@ -150,6 +150,11 @@ int oz_mcts_last_value(oz_mcts* m, double* value, int32_t* vtype, int32_t* depth
 /* N(state, action) of the current root for every square (MCTS/__init__.py:73-84): counts[g][64];
  * rc[g]: 0 ok, 1 root unknown (all zero), 2 KeyError (root never selected from) */
 int oz_mcts_root_counts(oz_mcts* m, int32_t* counts, uint64_t* legal, int32_t* rc);
+/* get_policy_action_probabilities (othelo_mcts.py:51-67) of every game's current root: policy[g] = float64 (n, n) row-major.
+ * temperature != 0: N ** (1 / T) on the legal squares over their np.sum (NumPy's summation order; or 1 if it is 0); temperature == 0: one-hot of
+ * a best square, of the max-count squares in row-major order the one tie_draws[g] % (how many) picks (random.choice in the reference; null: the
+ * first).  rc[g] as in oz_mcts_root_counts; rc 2 (KeyError in the reference) leaves a zero row. */
+int oz_mcts_policy(oz_mcts* m, double temperature, const uint64_t* tie_draws, double* policy, int32_t* rc);
 /* table inspection (parity tests): nodes of slot `game` in expansion order */
 int oz_mcts_num_nodes(oz_mcts* m, int32_t* num_nodes /* [num_games] */);
 int oz_mcts_dump_node(oz_mcts* m, int game, int index, uint64_t* own, uint64_t* opp, int32_t* Ns, uint64_t* legal,

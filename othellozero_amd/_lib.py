@@ -96,6 +96,7 @@ SIGNATURES = {
     "oz_mcts_backup": [_vp, _f32p, _f32p],
     "oz_mcts_last_value": [_vp, _f64p, _i32p, _i32p],
     "oz_mcts_root_counts": [_vp, _i32p, _u64p, _i32p],
+    "oz_mcts_policy": [_vp, C.c_double, _u64p, C.POINTER(C.c_double), _i32p],
     "oz_mcts_num_nodes": [_vp, _i32p],
     "oz_mcts_dump_node": [_vp, C.c_int, C.c_int, _u64p, _u64p, _i32p, _u64p, _i32p, _f64p, _u8p, _f64p],
     "oz_mcts_stats": [_vp, _i64p],

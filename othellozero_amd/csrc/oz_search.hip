@@ -174,7 +174,7 @@ __device__ __forceinline__ uint32_t ht_entry(uint64_t own, uint64_t opp, int nod
 }
 
 // NumPy pairwise sum of a contiguous float64 vector, 8 <= len <= 128 (np.sum at MCTS/__init__.py:49-51)
-__device__ double pairwise_sum(const double* a, int len) {
+__host__ __device__ inline double pairwise_sum(const double* a, int len) {
     double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
     int i;
     for (i = 8; i < len - (len % 8); i += 8) {
@@ -885,6 +885,47 @@ OZ_API int oz_mcts_root_counts(oz_mcts* m, int32_t* counts, uint64_t* legal, int
     OZ_HIP(hipMemcpyAsync(legal, dl, 8ull * G, hipMemcpyDeviceToHost, m->stream));
     OZ_HIP(hipMemcpyAsync(rc, dr, 4ull * G, hipMemcpyDeviceToHost, m->stream));
     OZ_HIP(hipStreamSynchronize(m->stream));
+    return OZ_OK;
+}
+
+// OthelloMCTS.get_policy_action_probabilities (othelo_mcts.py:51-67) of every game's current root: float64 (n, n) row-major rows.
+//   temperature != 0: N ** (1 / T) on the legal squares, divided by np.sum of the (n, n) array (NumPy's pairwise order) -- or by 1 if that is 0;
+//   temperature == 0: one-hot of a best square: of the squares whose count equals the maximum of the (n, n) array, in row-major order (np.argwhere),
+//                     the one `tie_draws[g] % (how many)` picks -- random.choice(bests) in the reference; null tie_draws: the first.
+// rc[g] as oz_mcts_root_counts reports it; a root that was expanded but never selected from (rc 2: KeyError in the reference) gets a zero row.
+OZ_API int oz_mcts_policy(oz_mcts* m, double temperature, const uint64_t* tie_draws, double* policy, int32_t* rc) {
+    OZ_REQUIRE(m && policy && rc, "null argument");
+    const int G = m->d.G, n = m->d.n, n2 = n * n;
+    std::vector<int32_t> counts((size_t)G * 64);
+    std::vector<uint64_t> legal((size_t)G);
+    if (int r = oz_mcts_root_counts(m, counts.data(), legal.data(), rc)) return r;
+    for (int g = 0; g < G; ++g) {
+        double* out = policy + (size_t)g * n2;
+        double arr[64];
+        for (int i = 0; i < n2; ++i) arr[i] = 0.0;
+        for (int i = 0; i < n2; ++i) out[i] = 0.0;
+        if (rc[g] == 2) continue;
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c)
+                if ((legal[g] >> (r * 8 + c)) & 1) {
+                    const int cnt = counts[(size_t)g * 64 + r * 8 + c];
+                    arr[r * n + c] = temperature == 0 ? (double)cnt : pow((double)cnt, 1.0 / temperature);
+                }
+        if (temperature == 0) {
+            double mx = arr[0];
+            for (int i = 1; i < n2; ++i) mx = arr[i] > mx ? arr[i] : mx;
+            int nb = 0;
+            for (int i = 0; i < n2; ++i) nb += arr[i] == mx;
+            int pick = tie_draws ? (int)(tie_draws[g] % (uint64_t)nb) : 0;
+            for (int i = 0; i < n2; ++i)
+                if (arr[i] == mx && pick-- == 0) { out[i] = 1.0; break; }
+        } else {
+            double sum = n2 >= 8 ? pairwise_sum(arr, n2) : 0.0;
+            if (n2 < 8) for (int i = 0; i < n2; ++i) sum += arr[i];
+            if (sum == 0) sum = 1.0;
+            for (int i = 0; i < n2; ++i) out[i] = arr[i] / sum;
+        }
+    }
     return OZ_OK;
 }
 

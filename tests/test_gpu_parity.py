@@ -1273,3 +1273,39 @@ def test_library_side_random_initialisation_is_keras_default_and_deterministic(o
     pi, v = net.predict_batch(own, opp)
     pi64, v64 = nn_numpy.forward(w, own, opp, n)
     assert np.abs(pi.reshape(8, -1) - pi64).max() <= 1e-5 and np.abs(v - v64).max() <= 1e-5       # tolerance 1e-5 (north_star)
+
+
+@pytest.mark.gpu
+def test_c_abi_policy_equals_the_mirror(oz, monkeypatch):
+    """oz_mcts_policy = OthelloMCTS.get_policy_action_probabilities (othelo_mcts.py:51-67) behind the C ABI: bit for bit the float64 (n, n) array
+    the Python mirror computes with the reference's own NumPy expressions, for temperatures 1, 0.5 and 2, and for temperature 0 with the tie
+    draw standing in for random.choice(bests)"""
+    from othellozero_amd.Othello import BoardView, OthelloGame, OthelloPlayer
+    from othellozero_amd.othelo_mcts import OthelloMCTS
+    lib = oz.load()
+    n = 6
+    m = OthelloMCTS(n, PyStubNet(n, 11, 0, True), 1.0, q_mode=1)
+    g = OthelloGame(n)
+    state = g.board(BoardView.TWO_CHANNELS)
+    pol, rc = np.zeros((1, n * n), np.float64), np.zeros(1, np.int32)
+    for sims in (1, 2, 7, 40):
+        while m.N(state) < sims - 1:
+            m.simulate(state, OthelloPlayer.BLACK)
+        if sims == 1:
+            m.simulate(state, OthelloPlayer.BLACK)                       # expanded, never selected from: KeyError in the reference, rc 2 here
+            with pytest.raises(KeyError):
+                m.get_policy_action_probabilities(state, 1)
+            oz.check(lib.oz_mcts_policy(m._h, 1.0, None, pol.ctypes.data_as(C.POINTER(C.c_double)), oz.p_i32(rc)))
+            assert rc[0] == 2 and not pol.any()
+            continue
+        for T in (1, 0.5, 2):
+            want = m.get_policy_action_probabilities(state, T)
+            oz.check(lib.oz_mcts_policy(m._h, float(T), None, pol.ctypes.data_as(C.POINTER(C.c_double)), oz.p_i32(rc)))
+            assert rc[0] == 0 and np.array_equal(pol.reshape(n, n), want), (sims, T)
+        for k in (0, 1, 5):
+            monkeypatch.setattr(random, "choice", lambda seq, k=k: seq[k % len(seq)])
+            want = m.get_policy_action_probabilities(state, 0)
+            draws = np.array([k], np.uint64)
+            oz.check(lib.oz_mcts_policy(m._h, 0.0, oz.p_u64(draws), pol.ctypes.data_as(C.POINTER(C.c_double)), oz.p_i32(rc)))
+            assert np.array_equal(pol.reshape(n, n), want), (sims, k)
+            monkeypatch.undo()
