@@ -78,11 +78,15 @@ int oz_net_get_weight(const oz_net* net, int index, float* data, int64_t nelem);
 /* a fresh OthelloNN as Keras initialises it (Net/OthelloNN.py:42-56: glorot_uniform kernels, zero biases, identity BatchNormalization) from a
  * deterministic stream keyed by `seed`; follow with oz_net_commit.  Not NumPy's numbers for that seed: read them back with oz_net_get_weight. */
 int oz_net_init_random(oz_net* net, uint64_t seed);
-/* arithmetic of the 3x3 convolutions: 0 = exact fp32 matrix cores (v_mfma_f32_32x32x2_f32);
- * 1 = "f32 via 2 x fp16 split": x = h1 + h2, products a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_16x16x32_f16 with fp32
- * accumulation (<= 2^-22 relative per product, the class of fp32 accumulation error; needs channels % 256 == 0 and
- * post-ReLU activations < 65504 -- oz_net_check / predict / selfplay_sync report OZ_ERR_STATE otherwise).
- * Takes effect at the next oz_net_commit. */
+/* arithmetic of the 3x3 convolutions and dense layers: 0 = exact fp32 matrix cores (v_mfma_f32_32x32x2_f32);
+ * 1 = "f32 via 2 x fp16 split" (fp32-EQUIVALENT, not fp32): x = h1 + h2, products a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_16x16x32_f16 with
+ * fp32 accumulation.  An element keeps 22 significant bits while |x| is in [2^-3, 65504] and an ABSOLUTE error of 2^-25 below that, so the
+ * class (<= 2^-22 relative per product, i.e. fp32 accumulation error) holds for values in that window -- oz_net_commit puts them there:
+ * every activation channel and every weight column gets an exact power-of-two scale (activations from the maxima of |BN output| over a
+ * fixed calibration set of positions, landing in [2^8, 2^9); folded into the BN scale / shift and the next layer's weights, the network
+ * function is unchanged; oz_net_get_scaling reads the exponents).  Guards, sticky, reported as OZ_ERR_STATE by oz_net_check / predict /
+ * selfplay_sync: an activation above 65504 (2^7 above its channel's calibration maximum), or a pixel row whose largest scaled
+ * activation is non-zero and below 2^-6 (2^15 below).  Needs channels % 256 == 0.  Takes effect at the next oz_net_commit. */
 int oz_net_set_precision(oz_net* net, int mode);
 int oz_net_get_precision(const oz_net* net);
 int oz_net_check(oz_net* net);
@@ -119,7 +123,20 @@ int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int
  * the 4-phase ping-pong loop.  Same tiles' accumulation order, bit-identical results: the reference form the LDS-DMA race screen
  * (tools/pp_race_check.py, test_pingpong_conv_loop_bit_identical_to_simple_loop) compares the ping-pong schedule against. */
 #define OZ_NET_OPT_SIMPLE_LOOP 1
+/* precision f16x2, both take effect at the next oz_net_commit: the power of two the per-channel calibration maxima are moved below (default 9;
+ * test hook for the overflow guard), and log2 of the low-side guard's row threshold (default -6; <= -100 switches the guard off) */
+#define OZ_NET_OPT_ACT_TARGET_LOG2 2
+#define OZ_NET_OPT_LOW_GUARD_LOG2 3
+/* precision f16x2, default 1: oz_net_commit runs its calibration positions through the f16x2 kernels and through the exact-fp32 kernels and
+ * fails with OZ_ERR_STATE when max |d pi| or max |d v| exceeds 8e-6 (a network that amplifies rounding beyond what 22 of fp32's 24 bits hold
+ * within 1e-5: a conditioning problem no range guard can see; healthy networks measure <= 4e-6, of which up to 3e-6 is the fp32 kernels' own
+ * rounding); 0 = off, 2 = measure only; oz_net_self_check reads what the last commit measured */
+#define OZ_NET_OPT_SELF_CHECK 4
 int oz_net_set_option(oz_net* net, int option, int value);
+int oz_net_self_check(oz_net* net, double* max_dpi, double* max_dv, int* positions);
+/* precision f16x2: the exponents chosen at the last commit.  which = 0 .. 4: per-channel activation exponents of the conv1, conv2, conv3,
+ * conv4 (channels each) and fc1 (1024) outputs; which = 5 .. 9: per-column weight exponents of conv2, conv3, conv4 (channels), fc1 (1024), fc2 (512) */
+int oz_net_get_scaling(oz_net* net, int which, int32_t* out, int64_t nelem);
 /* launch facts of the last forward: OZ_NET_INFO_CONV3_TILE_ROWS = the row-tile height conv3 ran on (f16x2: 256 / 192, chosen per call from
  * the capacity the caller launches with -- 256 at bench.py's batch cap of 3640 leaves; 128 for the latency path and precision f32) */
 #define OZ_NET_INFO_CONV3_TILE_ROWS 1

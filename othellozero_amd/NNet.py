@@ -56,7 +56,9 @@ class NNetWrapper(_NetHandle):
         create = lib.oz_net_create if network is NeuralNets.ONN else lib.oz_net_create_bnn
         _lib.check(create(C.byref(self._h), self.board_size_x, self.num_channels, self.max_batch))
         # precision: "f32" = exact fp32 matrix cores; "f16x2" = f32 via 2 x fp16 split on the 16-bit matrix cores
-        # (same <= 1e-5 tolerance, ~3-4x faster; needs channels % 256 == 0, raises if an activation leaves the fp16 range)
+        # (fp32-equivalent: same <= 1e-5 tolerance, ~4x faster; needs channels % 256 == 0; every activation channel / weight column is moved into the
+        #  fp16 window by an exact power of two at commit, and a position whose activations leave it -- above 65504, or a whole pixel row below 2^-6 --
+        #  raises OzError(OZ_ERR_STATE) instead of returning a degraded answer)
         self.precision = precision
         _lib.check(lib.oz_net_set_precision(self._h, {"f32": 0, "f16x2": 1}[precision]))
         self.set_weights(weights if weights is not None else
@@ -219,8 +221,30 @@ class NNetWrapper(_NetHandle):
         return dict(entries=e.value, lookups=l.value, hits=h.value, inserts=i.value)
 
     def set_option(self, option, value):
-        """diagnostics switches (_lib.NET_OPT_*): NET_OPT_SIMPLE_LOOP = the one-barrier conv loop the race screen compares against"""
+        """switches (_lib.NET_OPT_*): NET_OPT_SIMPLE_LOOP = the one-barrier conv loop the race screen compares against; precision f16x2, effective
+        at the next commit(): NET_OPT_ACT_TARGET_LOG2 (calibration maxima land below 2^value, default 9), NET_OPT_LOW_GUARD_LOG2 (row threshold of the
+        low-side guard, default -6; <= -100 = off)"""
         _lib.check(_lib.load().oz_net_set_option(self._h, int(option), int(value)))
+
+    def commit(self):
+        """oz_net_commit again (options that take effect at commit: NET_OPT_ACT_TARGET_LOG2, NET_OPT_LOW_GUARD_LOG2)"""
+        _lib.check(_lib.load().oz_net_commit(self._h))
+
+    def scaling(self, which):
+        """precision f16x2: the power-of-two exponents of the last commit -- which 0 .. 4 = per-channel activation exponents of the conv1 .. conv4,
+        fc1 outputs, 5 .. 9 = per-column weight exponents of conv2 .. fc2 (oz_net_get_scaling)"""
+        C_ = self.num_channels
+        size = [C_, C_, C_, C_, 1024, C_, C_, C_, 1024, 512][which]
+        out = np.zeros(size, np.int32)
+        _lib.check(_lib.load().oz_net_get_scaling(self._h, int(which), _lib.p_i32(out), size))
+        return out
+
+    def self_check(self):
+        """precision f16x2: what the last commit's self-check measured -- (max |d pi|, max |d v|, positions) between the f16x2 and the
+        exact-fp32 kernels on the calibration positions (negative: it did not run); a commit above 8e-6 raises OzError(OZ_ERR_STATE)"""
+        a, b, k = C.c_double(), C.c_double(), C.c_int()
+        _lib.check(_lib.load().oz_net_self_check(self._h, C.byref(a), C.byref(b), C.byref(k)))
+        return a.value, b.value, k.value
 
     def conv3_tile_rows(self):
         """row-tile height the LAST forward ran conv3 on (f16x2: 256 at bench.py's batch cap, 192 for full 4096-leaf launches)"""

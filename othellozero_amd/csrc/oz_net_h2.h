@@ -1,15 +1,28 @@
 // oz_net_h2.h -- "f32 via 2 x fp16 split" convolution / dense kernels (included by oz_net.hip).
 //
 // Why: OthelloNN is fp32 and the fp32 matrix cores peak at 157 TFLOP/s (1/16 of the 16-bit MFMA rate).
-// Every fp32 value x is carried as two fp16 planes  x = h1 + h2,  h1 = fp16(x), h2 = fp16(x - h1)
-// (22 significand bits), and a product is evaluated as  a1*b1 + a1*b2 + a2*b1  on the fp16 matrix cores
-// with fp32 accumulation: the dropped a2*b2 term and the split residuals are <= 2^-22 relative -- the same
-// class as fp32 accumulation error over K = 4608 (measured: |d pi|, |d v| <= 1e-5 vs float64 in
-// tests/test_gpu_parity.py, like the fp32 path).  3 MFMAs at 16x the fp32 rate.
-// Range: weights are pre-scaled per layer by an exact power of two so max|w| ~ 2^9..2^10 (the inverse
-// goes into the BN scale); activations (post-ReLU) must stay below 65504 -- the epilogue raises a
-// sticky device flag otherwise and the host reports it (use precision f32 for such a net), never a
-// silent wrong answer.
+// Every fp32 value x is carried as two fp16 planes  x = h1 + h2,  h1 = fp16(x), h2 = fp16(x - h1), and a product is
+// evaluated as  a1*b1 + a1*b2 + a2*b1  on the fp16 matrix cores with fp32 accumulation.  3 MFMAs at 16x the fp32 rate.
+// What the split keeps (fp16: 11-bit significand, normal down to 2^-14, subnormal step 2^-24):
+//   |x| in [2^-3, 65504]: h1 and h2 are both normal -> 22 significant bits, error <= 2^-24 |x|; the dropped a2*b2 term and the
+//                         residuals are then <= 2^-22 relative per product -- the class of fp32 accumulation error over K = 4608;
+//   |x| < 2^-3:           h2 falls into fp16 subnormals -> an ABSOLUTE error floor of 2^-25 per element (at 1e-3 about 15 bits
+//                         survive, below 6e-5 h1 itself is subnormal);   |x| > 65504: not representable.
+// So the class holds where the values that matter in a dot product sit in [2^-3, 65504], and it is the job of the SCALING to put
+// them there (round 4; rounds 1-3 scaled the weights per layer by their single largest |w| and the activations not at all):
+//   activations: every channel c of every h2 tensor (conv1..conv4, fc1 outputs) carries an exact power of two 2^aexp[c], chosen at
+//     oz_net_commit from the channel's maximum over a fixed calibration set of positions (all 3^9 patterns for conv1) so that the
+//     maximum lands in [2^8, 2^9): 2^7 of headroom to 65504 for positions the calibration has not seen, and the floor 2^-25 sits 2^-33
+//     below the channel's maximum.  The power is folded into the producing layer's BN scale and shift (exact) and divided out of the
+//     consuming layer's weight rows (exact) -- a diagonal rescaling between layers, the network function is unchanged;
+//   weights: after that division every output column c gets its own 2^kexp[c] (its largest |w| -> [2^9, 2^10)), folded into the
+//     column's BN scale: a column of small weights compensated by its BN variance keeps its 22 bits;
+//   guards (sticky device flag, OZ_ERR_STATE at the next synchronising call -- never a silent wrong answer): HIGH side, an
+//     activation above 65504; LOW side, a pixel row whose largest scaled activation over ALL channels is non-zero and below
+//     2^-6 (every element of that row is then carried with fewer than ~19 bits relative to the row: 2^-25 / 2^-6), detected per
+//     64-channel slice in the producing epilogue with a per-row counter for the rare low slices (h2_low_report).
+// Measured: |d pi|, |d v| <= 1e-5 vs float64 on every tested network incl. small-activation, wide-weight-range and badly scaled BN
+// cases (tests/test_gpu_parity.py::test_f16x2_scaling_*), like the fp32 path.
 //
 // Storage ("h2 layout"): for a row (pixel or output channel) every 8 consecutive k are one 32-byte
 // group  [h1 x 8][h2 x 8]; a row of K values is K/8 groups = 4*K bytes (same footprint as fp32).
@@ -69,6 +82,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define H2_BK 32
 #define H2_F16_MAX 65504.0f
+#define H2_SELF_CHECK_LIMIT 8.0e-6           // oz_net_commit: largest |d pi|, |d v| between the f16x2 and the exact-fp32 kernels on the calibration positions
 
 // tile configurations: NWM x NWN waves, each wave NTI x NTJ blocks of 32 x 32 (= 2 x 2 MFMA tiles of 16 x 16)
 //   H2Big   (3x3 convolutions): 2 x 4 waves, wave tile 128 x 64 -> block 256 x 256, 512 threads, 128 KB LDS
@@ -113,6 +127,37 @@ typedef H2Cfg<1, 2, 2, 2, 3> H2Thin;  // dense layers (M = batch): 64 x 128, 2 w
 // bound), a 32 x 128 tile on two waves (twice the blocks) 33.5, this 27.8.
 typedef H2Cfg<2, 2, 1, 2, 3> H2Thin4w;
 
+// Low-side guard of an h2 tensor (see the header of this file): cnt[row] = (forward number << 6 | low slices seen) for the rows of
+// the tensor a kernel writes; cnt == nullptr switches the guard off (fp32 outputs, the trainer's calls, calibration passes).
+#define H2_FLAG_OVER 1        // an activation above the fp16 range
+#define H2_FLAG_LOW 4         // a row whose largest scaled activation is non-zero and below the threshold (bit 2 = 2 is the trainer's)
+struct H2Low {
+    unsigned* cnt = nullptr;
+    unsigned seq = 0;                     // 26-bit number of the forward (never 0)
+    float thr = 0.f;                      // 2^-6 by default (OZ_NET_OPT_LOW_GUARD_LOG2)
+    int* flag = nullptr;
+};
+// one 64-channel slice of row `row` came out low (0 < max < thr): count it; the row is low when all `nslices` of its slices are.
+// Rare by construction (a slice of 64 channels whose maxima all sit 2^15 below their calibration maxima), so a CAS loop is fine;
+// the forward number makes stale counts of earlier forwards harmless -- the array is never cleared.
+__device__ __forceinline__ void h2_low_report(const H2Low& lo, long long row, int nslices) {
+    unsigned* p = lo.cnt + row;
+    unsigned seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), next;
+    for (;;) {
+        next = (seen >> 6) == lo.seq ? seen + 1 : ((lo.seq << 6) | 1u);
+        const unsigned was = atomicCAS(p, seen, next);
+        if (was == seen) break;
+        seen = was;
+    }
+    if ((int)(next & 63u) >= nslices) atomicOr(lo.flag, H2_FLAG_LOW);
+}
+// max of |x| over the 8 lanes of an aligned lane octet (every lane gets it)
+__device__ __forceinline__ float h2_octet_max(float m) {
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    return fmaxf(m, __shfl_xor(m, 4, 64));
+}
+
 struct H2Geom {
     int Hin, Hout, pad, Cin, taps;        // taps 9 (3x3 conv) or 1 (dense, Hin = Hout = 1)
     int N, K;                             // output channels, taps * Cin
@@ -120,6 +165,7 @@ struct H2Geom {
     int relu;
     int ksplit;                           // > 1: split-K, raw partial sums to slab[ks] (no scale/shift), see k_splitk_reduce_h2
     long long slab;                       // elements between two partial slabs
+    H2Low low;                            // low-side guard of an h2 output (off by default)
 };
 
 // finishes a split-K layer: out[m][n] = act((sum_s slab[s][m][n]) * scale[n] + shift[n]) with the slices added in a
@@ -127,7 +173,7 @@ struct H2Geom {
 __global__ __launch_bounds__(256) void k_splitk_reduce_h2(const float* __restrict__ part, long long slab, int ksplit, int N, int P,
                                                           const int* __restrict__ d_count, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int relu, uint4* __restrict__ out,
-                                                          int* __restrict__ flag) {
+                                                          int* __restrict__ flag, H2Low low) {
     const int ng = N >> 3;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long m = idx / ng;
@@ -144,16 +190,22 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_h2(const float* __restric
     }
     f16x8 h1, h2;
     bool over = false;
+    float vmax = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float v = fmaf(acc[j], scale[c8 + j], shift[c8 + j]);
         if (relu) v = fmaxf(v, 0.f);
         over |= fabsf(v) > H2_F16_MAX;
+        vmax = fmaxf(vmax, fabsf(v));
         const _Float16 a = (_Float16)v;
         h1[j] = a;
         h2[j] = (_Float16)(v - (float)a);
     }
-    if (over) atomicOr(flag, 1);
+    if (over) atomicOr(flag, H2_FLAG_OVER);
+    if (low.cnt) {                                       // 8 adjacent threads = one 64-channel slice of row m (ng % 8 == 0: whole octets pass the row test together)
+        vmax = h2_octet_max(vmax);
+        if ((threadIdx.x & 7) == 0 && vmax > 0.f && vmax < low.thr) h2_low_report(low, m, N >> 6);
+    }
     uint4* dst = out + ((size_t)m * ng + (c8 >> 3)) * 2;
     dst[0] = *reinterpret_cast<uint4*>(&h1);
     dst[1] = *reinterpret_cast<uint4*>(&h2);
@@ -180,7 +232,7 @@ typedef __attribute__((address_space(3))) void* h2_lptr;
 __global__ __launch_bounds__(256) void k_conv1_h2(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
                                                   const int* __restrict__ d_count, int n, int C,
                                                   const float* __restrict__ W /*[9][2][C]*/, const float* __restrict__ scale,
-                                                  const float* __restrict__ shift, uint4* __restrict__ out, int* __restrict__ flag) {
+                                                  const float* __restrict__ shift, uint4* __restrict__ out, int* __restrict__ flag, H2Low low) {
     const int cg = C >> 3;
     const long long R = (long long)(*d_count) * n;                  // board rows
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -231,19 +283,25 @@ __global__ __launch_bounds__(256) void k_conv1_h2(const uint64_t* __restrict__ o
     for (int x = 0; x < 8; ++x) {
         if (x >= n) continue;
         f16x8 h1, h2;
+        float vmax = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float v = fmaxf(fmaf(acc[x][j], sc[j], sh[j]), 0.f);
             over |= v > H2_F16_MAX;
+            vmax = fmaxf(vmax, v);
             _Float16 a, bb;
             h2_split(v, a, bb);
             h1[j] = a; h2[j] = bb;
+        }
+        if (low.cnt) {                                   // cg % 8 == 0: the 8 threads of a 64-channel slice sit in one lane octet, same board row
+            vmax = h2_octet_max(vmax);
+            if ((threadIdx.x & 7) == 0 && vmax > 0.f && vmax < low.thr) h2_low_report(low, br * n + x, C >> 6);
         }
         uint4* dst = out + ((size_t)(br * n + x) * cg + (c8 >> 3)) * 2;
         dst[0] = *reinterpret_cast<uint4*>(&h1);
         dst[1] = *reinterpret_cast<uint4*>(&h2);
     }
-    if (over) atomicOr(flag, 1);
+    if (over) atomicOr(flag, H2_FLAG_OVER);
 }
 
 // ---- weight preparation on the device (oz_net_commit): the Keras kernels are uploaded as stored, [K][N] with k = tap * Cin + ci
@@ -257,20 +315,24 @@ __global__ __launch_bounds__(256) void k_w_transpose(const float* __restrict__ s
     for (int r = ty; r < 32; r += 8)
         if (c0 + r < N && k0 + tx < K) out[(size_t)(c0 + r) * K + k0 + tx] = tile[tx][r];
 }
-// h2 layout [N][K/8][h1 x 8 | h2 x 8] of w * 2^kexp, in the GEMM's k order k' = (slice * taps + tap) * 32 + c32.
+// h2 layout [N][K/8][h1 x 8 | h2 x 8] of  w[k][c] * 2^(colexp[c] - inexp[k % Cmod])  in the GEMM's k order k' = (slice * taps + tap) * 32 + c32:
+// colexp[c] moves column c's largest |w| into [2^9, 2^10), inexp[] divides the consumed tensor's per-channel activation scale out
+// (k % Cmod = the input channel of reduction index k: tap * Cin + ci for the 3x3 layers, pixel * C + c for fc1's flattened input).
 // One thread per (output channel c, group of 8 k'); adjacent threads = adjacent c (coalesced reads of the [K][N] source).
-__global__ __launch_bounds__(256) void k_w_to_h2(const float* __restrict__ src, int K, int N, int taps, int kexp, uint4* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_w_to_h2(const float* __restrict__ src, int K, int N, int taps, const int* __restrict__ colexp,
+                                                 const int* __restrict__ inexp, int Cmod, uint4* __restrict__ out) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c = (int)(idx % N);
     const int grp = (int)(idx / N);
     if (grp >= (K >> 3)) return;
     const int Cin = K / taps;
+    const int ce = colexp[c];
     f16x8 h1, h2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int kp = grp * 8 + j, tile = kp >> 5, c32 = kp & 31, slice = tile / taps, tap = tile - slice * taps;
         const int k = tap * Cin + slice * 32 + c32;
-        const float x = ldexpf(src[(size_t)k * N + c], kexp);
+        const float x = ldexpf(src[(size_t)k * N + c], ce - inexp[k % Cmod]);
         const _Float16 a = (_Float16)x;
         h1[j] = a; h2[j] = (_Float16)(x - (float)a);
     }
@@ -278,13 +340,63 @@ __global__ __launch_bounds__(256) void k_w_to_h2(const float* __restrict__ src, 
     dst[0] = *reinterpret_cast<uint4*>(&h1);
     dst[1] = *reinterpret_cast<uint4*>(&h2);
 }
+// colmax[c] = max over k of |w[k][c]| * 2^-inexp[k % Cmod]  (bit pattern of a non-negative float: atomicMax on unsigned orders them)
+__global__ __launch_bounds__(256) void k_w_colmax(const float* __restrict__ src, int K, int N, const int* __restrict__ inexp, int Cmod,
+                                                  unsigned* __restrict__ colmax) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const int k0 = blockIdx.y * 64, k1 = k0 + 64 < K ? k0 + 64 : K;
+    float m = 0.f;
+    for (int k = k0; k < k1; ++k) m = fmaxf(m, fabsf(ldexpf(src[(size_t)k * N + c], -inexp[k % Cmod])));
+    if (m > 0.f) atomicMax(colmax + c, __float_as_uint(m));
+}
+// colmax[c] = max over rows of |x[row][c]| of fp32 rows [*d_count * P][N] (calibration passes: a layer's BN output, BEFORE the ReLU, before
+// its scale is chosen.  Before the ReLU because the post-ReLU maximum of a channel that hovers around zero is not a scale: it was 3e-5 on 512
+// calibration positions and 300 times that on a self-play position -- measured, round 4 -- while max |z| is a few sigma either way.)
+__global__ __launch_bounds__(256) void k_rows_colmax(const float* __restrict__ x, const int* __restrict__ d_count, int P, int N,
+                                                     unsigned* __restrict__ colmax) {
+    const long long rows = (long long)(*d_count) * P;
+    const long long r0 = (long long)blockIdx.y * 64;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N || r0 >= rows) return;
+    const long long r1 = r0 + 64 < rows ? r0 + 64 : rows;
+    float m = 0.f;
+    for (long long r = r0; r < r1; ++r) {                 // a non-finite value turns the maximum into +Inf, which the host refuses
+        const float a = fabsf(x[(size_t)r * N + c]);
+        m = a <= 3.0e38f ? fmaxf(m, a) : __builtin_inff();
+    }
+    if (m > 0.f) atomicMax(colmax + c, __float_as_uint(m));
+}
+// the same over the 3^9 conv1 rows (k_lut_build's fmaf sequence): the exact supremum of |conv1's BN output| per channel
+__global__ __launch_bounds__(256) void k_lut_colmax(int C, const float* __restrict__ W /*[9][2][C]*/, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, unsigned* __restrict__ colmax) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int id0 = blockIdx.y * 64, id1 = id0 + 64 < OZ_LUT_PATTERNS ? id0 + 64 : OZ_LUT_PATTERNS;
+    const float sc = scale[c], sh = shift[c];
+    float m = 0.f;
+    for (int id = id0; id < id1; ++id) {
+        float acc = 0.f;
+        unsigned rest = (unsigned)id;
+        for (int t = 0; t < 9; ++t) {
+            const unsigned cell = rest % 3; rest /= 3;
+            acc = fmaf(cell == 1 ? 1.f : 0.f, W[(size_t)(t * 2 + 0) * C + c], acc);
+            acc = fmaf(cell == 2 ? 1.f : 0.f, W[(size_t)(t * 2 + 1) * C + c], acc);
+        }
+        m = fmaxf(m, fabsf(fmaf(acc, sc, sh)));             // |BN output| before the ReLU: a stable scale also for a channel that hovers around zero
+    }
+    if (m > 0.f) atomicMax(colmax + c, __float_as_uint(m));
+}
 
 // pattern id of every pixel: sum over the 3 x 3 neighbourhood (ky, kx) of 3^(ky*3+kx) * {0 empty or off the board, 1 own, 2 opponent}.
 // Layout: PADDED boards [batch][(n+2)][(n+2)] of 32-bit ids, the one-cell border holding OZ_LUT_PATTERNS -- the index of the all-zero
 // row every table ends with -- so that the consumers (k_conv2_lut*, the H2BigPPLut gather) read the 3 x 3 window of a pixel with no
 // bounds test and an off-board tap adds an exact +0.0 (wave-uniform 32-bit ids are also what the scalar unit can load).
+// low_rows (optional): low_rows[id] != 0 marks a pattern whose conv1 row is LOW in the h2 layout (k_lut_rowlow, at commit); a batch that
+// holds such a pixel raises the low-side flag -- the act1 leg of the guard costs one byte read per pixel.
 __global__ __launch_bounds__(256) void k_lut_ids(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
-                                                 const int* __restrict__ d_count, int n, unsigned* __restrict__ ids) {
+                                                 const int* __restrict__ d_count, int n, unsigned* __restrict__ ids,
+                                                 const unsigned char* __restrict__ low_rows, int* __restrict__ flag) {
     const int W = n + 2, PW = W * W;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)(*d_count) * PW) return;
@@ -304,6 +416,21 @@ __global__ __launch_bounds__(256) void k_lut_ids(const uint64_t* __restrict__ ow
             pw *= 3;
         }
     ids[idx] = id;
+    if (low_rows && low_rows[id]) atomicOr(flag, H2_FLAG_LOW);
+}
+// low[id] = 1 when the conv1 table row of pattern id is non-zero and its largest h1 value is below thr (one wave per row)
+__global__ __launch_bounds__(64) void k_lut_rowlow(int C, const uint4* __restrict__ table, float thr, unsigned char* __restrict__ low) {
+    const int id = blockIdx.x, lane = threadIdx.x, cg = C >> 3;
+    float m = 0.f;
+    for (int g = lane; g < cg; g += 64) {
+        const uint4 q = table[((size_t)id * cg + g) * 2];          // the h1 chunk of channel group g
+        const f16x8 h = *reinterpret_cast<const f16x8*>(&q);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf((float)h[j]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) low[id] = (m > 0.f && m < thr) ? 1 : 0;
 }
 
 // table[id] = the h2 row k_conv1_h2 writes for a pixel whose neighbourhood is pattern id: the same fmaf sequence (taps in
@@ -343,7 +470,7 @@ __global__ __launch_bounds__(256) void k_lut_build(int C, const float* __restric
     uint4* dst = table + ((size_t)id * cg + (c8 >> 3)) * 2;
     dst[0] = *reinterpret_cast<uint4*>(&h1);
     dst[1] = *reinterpret_cast<uint4*>(&h2);
-    if (over) atomicOr(flag, 1);
+    if (over) atomicOr(flag, H2_FLAG_OVER);
 }
 
 // conv2 as a gather-sum (conv1 AND conv2 folded into tables).  With act1[q] = table[id(q)], conv2's pre-activation at
@@ -391,15 +518,18 @@ __device__ __forceinline__ size_t t2_record(int slice, int t, unsigned id) {    
 // one output row piece: BN + ReLU of 8 channel sums, then the h2 split (two 16-byte streaming stores) or fp32 (two 16-byte stores)
 template <bool OUT_H2>
 __device__ __forceinline__ bool c2l_finish(const f32x4& lo, const f32x4& hi, const float* __restrict__ scale, const float* __restrict__ shift, int c8,
-                                           void* __restrict__ out, size_t pixel, int C) {
+                                           void* __restrict__ out, size_t pixel, int C, float& vmax, float relu_floor) {
     const f32x4 sc0 = *reinterpret_cast<const f32x4*>(scale + c8), sc1 = *reinterpret_cast<const f32x4*>(scale + c8 + 4);
     const f32x4 sh0 = *reinterpret_cast<const f32x4*>(shift + c8), sh1 = *reinterpret_cast<const f32x4*>(shift + c8 + 4);
     float v[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        v[j] = fmaxf(fmaf(lo[j], sc0[j], sh0[j]), 0.f);
-        v[j + 4] = fmaxf(fmaf(hi[j], sc1[j], sh1[j]), 0.f);
+        v[j] = fmaxf(fmaf(lo[j], sc0[j], sh0[j]), relu_floor);
+        v[j + 4] = fmaxf(fmaf(hi[j], sc1[j], sh1[j]), relu_floor);
     }
+    vmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vmax = fmaxf(vmax, v[j]);
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     bool over = false;
     if constexpr (OUT_H2) {
@@ -430,8 +560,9 @@ __device__ __forceinline__ bool c2l_finish(const f32x4& lo, const f32x4& hi, con
 template <int N, bool OUT_H2>
 __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restrict__ ids, const int* __restrict__ d_count,
                                                        const float* __restrict__ T2, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       void* __restrict__ out, int* __restrict__ flag) {
+                                                       void* __restrict__ out, int* __restrict__ flag, H2Low low, float floor) {
     constexpr int P = N * N, W = N + 2, PW = W * W, C = 512;
+    const float relu_floor = OUT_H2 ? 0.f : floor;            // fp32 rows: 0 = ReLU, -inf = the BN output itself (calibration passes)
     const int slice = blockIdx.x & 7, j = threadIdx.x & 7;
     const long long total = (long long)(*d_count) * P;
     // whole 128-byte lines per wave instruction: the 8 lanes of a pixel read 16 B each of line 0 of the record (channels 4 j .. 4 j + 3 of the
@@ -463,8 +594,8 @@ __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restric
         f32x4 va, vb;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            va[q] = fmaxf(fmaf(lo[q], sca[q], sha[q]), 0.f);
-            vb[q] = fmaxf(fmaf(hi[q], scb[q], shb[q]), 0.f);
+            va[q] = fmaxf(fmaf(lo[q], sca[q], sha[q]), relu_floor);
+            vb[q] = fmaxf(fmaf(hi[q], scb[q], shb[q]), relu_floor);
         }
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         if constexpr (OUT_H2) {
@@ -474,6 +605,11 @@ __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restric
             typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
             union Pk { f16x4 h; unsigned u[2]; };
             Pk h1a, h2a, h1b, h2b;
+            if (low.cnt) {                                   // the 8 lanes of a pixel hold its whole 64-channel slice
+                float vmax = fmaxf(fmaxf(fmaxf(va[0], va[1]), fmaxf(va[2], va[3])), fmaxf(fmaxf(vb[0], vb[1]), fmaxf(vb[2], vb[3])));
+                vmax = h2_octet_max(vmax);
+                if (j == 0 && vmax > 0.f && vmax < low.thr) h2_low_report(low, pixel, C >> 6);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 over |= va[q] > H2_F16_MAX || vb[q] > H2_F16_MAX;
@@ -499,14 +635,14 @@ __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restric
             __builtin_nontemporal_store(vb, reinterpret_cast<f32x4*>(dst + 32));
         }
     }
-    if (OUT_H2 && over) atomicOr(flag, 1);
+    if (OUT_H2 && over) atomicOr(flag, H2_FLAG_OVER);
 }
 
 // any channel count: one thread per (pixel, 8 channels); same sums in the same order
 template <bool OUT_H2>
 __global__ __launch_bounds__(256) void k_conv2_lut(const unsigned* __restrict__ ids, const int* __restrict__ d_count, int n, int C,
                                                    const float* __restrict__ T2, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                   void* __restrict__ out, int* __restrict__ flag) {
+                                                   void* __restrict__ out, int* __restrict__ flag, H2Low low, float floor) {
     const int cg = C >> 3, P = n * n, W = n + 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long pixel = idx / cg;
@@ -528,7 +664,12 @@ __global__ __launch_bounds__(256) void k_conv2_lut(const unsigned* __restrict__ 
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 9; ++t) { lo += ra[t]; hi += rb[t]; }
-    if (c2l_finish<OUT_H2>(lo, hi, scale, shift, c8, out, (size_t)pixel, C)) atomicOr(flag, 1);
+    float vmax;
+    if (c2l_finish<OUT_H2>(lo, hi, scale, shift, c8, out, (size_t)pixel, C, vmax, OUT_H2 ? 0.f : floor)) atomicOr(flag, H2_FLAG_OVER);
+    if (OUT_H2 && low.cnt) {                                 // cg % 8 == 0: a 64-channel slice = one lane octet of one pixel
+        vmax = h2_octet_max(vmax);
+        if ((threadIdx.x & 7) == 0 && vmax > 0.f && vmax < low.thr) h2_low_report(low, pixel, C >> 6);
+    }
 }
 
 // commit-time re-layout: one tap's GEMM output rows [OZ_LUT_PATTERNS][C] -> the slice-major records of that tap (row OZ_LUT_PATTERNS = zeros)
@@ -948,9 +1089,20 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
             const long long m = (long long)mt * BM + wm * RI * 16 + hh * PB * 16 + lr;
             const uint4 val = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(slice) + lr * 256 + cq * 16);
             if (m < M) o[(size_t)m * nq + ((nt * BN + wn * RJ * 16) >> 2) + cq] = val;
+            if (g.low.cnt) {     // low-side guard: the 16 lanes of a row hold its 64-channel slice; the even chunks are the h1 planes
+                float vmax = 0.f;
+                if ((cq & 1) == 0) {
+                    const f16x8 h = *reinterpret_cast<const f16x8*>(&val);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vmax = fmaxf(vmax, fabsf((float)h[e]));
+                }
+                vmax = h2_octet_max(vmax);
+                vmax = fmaxf(vmax, __shfl_xor(vmax, 8, 64));
+                if (cq == 0 && m < M && vmax > 0.f && vmax < g.low.thr) h2_low_report(g.low, m, g.N >> 6);
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
     }
-    if (over) atomicOr(flag, 1);
+    if (over) atomicOr(flag, H2_FLAG_OVER);
 }
