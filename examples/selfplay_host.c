@@ -18,12 +18,15 @@
 
 #include "othellozero_amd.h"
 
+#define MAX_WORLD 64
 #define CHECK(call) do { int rc_ = (call); if (rc_ != OZ_OK) { fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, oz_last_error()); return 1; } } while (0)
 
 int main(int argc, char** argv) {
     const int rank = argc > 2 ? atoi(argv[1]) : 0, world = argc > 2 ? atoi(argv[2]) : 1;
     const char* id_file = argc > 3 ? argv[3] : NULL;
     const int n = 6, channels = 128, games = 64, sims = 8;
+    if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world) { fprintf(stderr, "usage: %s [rank world id_file], 0 <= rank < world <= %d\n", argv[0], MAX_WORLD); return 2; }
+    if (world > 1 && !id_file) { fprintf(stderr, "%d ranks need an id_file to pass the communicator id through\n", world); return 2; }
     if (oz_device_count() <= 0) { fprintf(stderr, "no HIP device\n"); return 2; }
     CHECK(oz_set_device(rank % oz_device_count()));
 
@@ -51,18 +54,27 @@ int main(int argc, char** argv) {
     memset(id, 0, sizeof id);
     if (rank == 0) {
         CHECK(oz_comm_unique_id(id));
-        if (id_file) { FILE* f = fopen(id_file, "wb"); if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) return 3; fclose(f); }
+        if (id_file) {       /* written under another name and renamed: a reader sees the whole id or no file at all */
+            char tmp[4096];
+            if (snprintf(tmp, sizeof tmp, "%s.tmp", id_file) >= (int)sizeof tmp) return 3;
+            FILE* f = fopen(tmp, "wb");
+            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) != 0 || rename(tmp, id_file) != 0) { fprintf(stderr, "rank 0: cannot write %s\n", id_file); return 3; }
+        }
     } else {
-        FILE* f = NULL;
-        for (int tries = 0; tries < 600 && !f; ++tries) { f = fopen(id_file, "rb"); if (!f) usleep(100000); }
-        if (!f || fread(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "rank %d: no communicator id in %s\n", rank, id_file); return 3; }
-        fclose(f);
+        size_t got = 0;
+        for (int tries = 0; tries < 600 && got != sizeof id; ++tries) {     /* up to a minute for rank 0 to get there */
+            FILE* f = fopen(id_file, "rb");
+            got = f ? fread(id, 1, sizeof id, f) : 0;
+            if (f) fclose(f);
+            if (got != sizeof id) usleep(100000);
+        }
+        if (got != sizeof id) { fprintf(stderr, "rank %d: no communicator id in %s\n", rank, id_file); return 3; }
     }
     oz_comm* comm = NULL;
     CHECK(oz_comm_create(&comm, id, rank, world));
     const int64_t room = (int64_t)world * games * 64;
     oz_record* pooled = (oz_record*)malloc(sizeof(oz_record) * (size_t)room);
-    int64_t n_pooled = 0, per_rank[64];
+    int64_t n_pooled = 0, per_rank[MAX_WORLD];
     CHECK(oz_selfplay_gather_records(sp, comm, 0, pooled, room, &n_pooled, per_rank));
 
     int64_t z_sum = 0, mine = 0;

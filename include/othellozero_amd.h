@@ -283,7 +283,9 @@ int oz_comm_unique_id(uint8_t* id /* [OZ_COMM_ID_BYTES] */);
 int oz_comm_create(oz_comm** out, const uint8_t* id, int rank, int world);
 int oz_comm_destroy(oz_comm* comm);
 /* COLLECTIVE over `comm`: the records [first_record, completed so far) of every rank's engine, concatenated in rank order, into `out`
- * (host buffer of max_records); *written = their number, per_rank[world] (optional) = what each rank contributed. */
+ * (host buffer of max_records); *written = their number, per_rank[world] (optional) = what each rank contributed.  Room is checked against
+ * the pooled count on EVERY rank's behalf before the payload moves: too little room on any rank fails the call on all of them together
+ * (OZ_ERR_ARG), never on one rank alone.  out == NULL and max_records == 0 on every rank: the counts only (*written = the pooled number). */
 int oz_selfplay_gather_records(oz_selfplay* sp, oz_comm* comm, int64_t first_record, oz_record* out, int64_t max_records, int64_t* written,
                                int64_t* per_rank);
 

@@ -84,6 +84,7 @@ def lib():
     L.orc_mcts_find.restype = i32; L.orc_mcts_find.argtypes = [vp, u64, u64]
     L.orc_mcts_counts.restype = i32; L.orc_mcts_counts.argtypes = [vp, u64, u64, P(i32), P(u64)]
     L.orc_mcts_policy.restype = i32; L.orc_mcts_policy.argtypes = [vp, u64, u64, dbl, u64, P(dbl), P(i32)]
+    L.orc_policy_from_counts.restype = i32; L.orc_policy_from_counts.argtypes = [i32, P(i32), u64, dbl, u64, P(dbl)]
     L.orc_episode.restype = i32; L.orc_episode.argtypes = [vp, i32, dbl, dbl, u64, u64, i32, P(EpisodeOut)]
     L.orc_episode_sched.restype = i32; L.orc_episode_sched.argtypes = [vp, i32, i32, i32, dbl, dbl, u64, u64, i32, P(EpisodeOut)]
     L.orc_arena.restype = i32; L.orc_arena.argtypes = [vp, vp, i32, u64, u64, P(ArenaOut)]
@@ -133,6 +134,14 @@ def stub_predict(own, opp, n, salt=0, keep_mask=0):
     v = C.c_float()
     L.orc_stub_predict(own, opp, n, salt, keep_mask, pi, C.byref(v))
     return np.frombuffer(pi, dtype=np.float32).reshape(n, n).copy(), np.float32(v.value)
+
+
+def policy_from_counts(n, counts, legal, T, tie_u=0):
+    """get_policy_action_probabilities (othelo_mcts.py:51-67) from root visit counts by square and the legal mask"""
+    cnt = np.ascontiguousarray(counts, dtype=np.int32)
+    out = np.zeros(n * n, np.float64)
+    lib().orc_policy_from_counts(n, cnt.ctypes.data_as(C.POINTER(C.c_int)), int(legal), float(T), int(tie_u), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out.reshape(n, n)
 
 
 def pairwise_sum(a):

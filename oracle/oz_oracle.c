@@ -504,6 +504,10 @@ static int policy_from_counts(int n, const int* counts /*by square*/, uint64_t l
     for (int a = 0; a < n * n; ++a) { out[a] = p[a] / s; if (out[a] > out[arg]) arg = a; }
     return arg;                                          /* first maximum, row-major */
 }
+/* the same from given counts (tests: the per-move pi of a golden episode, whose counts and boards are in the fixture) */
+ORC_API int orc_policy_from_counts(int n, const int* counts, uint64_t legal, double T, uint64_t tie_u, double* out) {
+    return policy_from_counts(n, counts, legal, T, tie_u, out);
+}
 ORC_API int orc_mcts_policy(const omcts* m, uint64_t k0, uint64_t k1, double T, uint64_t tie_u, double* out, int* argmax) {
     int counts[64]; uint64_t legal;
     int rc = orc_mcts_counts(m, k0, k1, counts, &legal);

@@ -12,18 +12,18 @@ import numpy as np
 from . import _lib
 
 
-class BoardView(Enum):
+class BoardView(Enum):           # member names and values are public surface (Othello/__init__.py:6-8): callers pass BoardView.TWO_CHANNELS
     ONE_CHANNEL = auto()
     TWO_CHANNELS = auto()
 
 
-class OthelloPlayer(Enum):
+class OthelloPlayer(Enum):       # value = the disc's sign in the one-channel view (Othello/__init__.py:12-14)
     BLACK = 1
     WHITE = -1
 
     @property
     def opponent(self):
-        return OthelloPlayer.WHITE if self is OthelloPlayer.BLACK else OthelloPlayer.BLACK
+        return OthelloPlayer(-self.value)
 
 
 # ---------------------------------------------------------------- batched rule calls (uint64 bitboards)
@@ -154,19 +154,19 @@ class OthelloGame:
 
     @staticmethod
     def get_all_directions_squares(board_size, row, col):
-        """Othello/__init__.py:186-189: one generator of squares per direction (host-side geometry; the kernels walk rays as bit shifts)"""
-        for direction in OthelloGame.ALL_DIRECTIONS:
-            yield OthelloGame.get_direction_squares(board_size, direction, row, col)
+        """the eight rays out of (row, col), in ALL_DIRECTIONS order, each as a generator of squares (Othello/__init__.py:186-189).
+        Host-side geometry for callers of the static surface; the kernels walk rays as bit shifts."""
+        return (OthelloGame.get_direction_squares(board_size, step, row, col) for step in OthelloGame.ALL_DIRECTIONS)
 
     @staticmethod
     def get_direction_squares(board_size, direction, row, col):
-        """Othello/__init__.py:191-198"""
-        row_offset, col_offset = direction
-        row, col = row + row_offset, col + col_offset
-        while 0 <= row < board_size and 0 <= col < board_size:
-            yield row, col
-            row += row_offset
-            col += col_offset
+        """squares of the ray that leaves (row, col) along `direction`, nearest first, up to the edge (Othello/__init__.py:191-198)"""
+        dr, dc = int(direction[0]), int(direction[1])
+
+        def room(pos, step):                        # squares left on this axis before the ray leaves the board
+            return board_size - 1 - pos if step > 0 else pos if step < 0 else board_size
+        for k in range(1, min(room(row, dr), room(col, dc)) + 1):
+            yield row + k * dr, col + k * dc
 
     @staticmethod
     def get_board_free_squares(board):

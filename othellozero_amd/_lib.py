@@ -144,24 +144,84 @@ _LIB = None
 PRELOAD_TORCH_HIP = True          # set to False before the first load() to bind the library to the system ROCm runtime even where PyTorch is installed
 
 
-def _one_hip_runtime():
-    """PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's) and load it by path.  If this
-    library is loaded first it binds to the system runtime, a later `import torch` brings the bundled one in as well, and the process
-    holds TWO HIP / HSA runtimes: streams and device pointers of one are invalid handles in the other (torch tensors handed to the
-    library, the library's RCCL exchange step on torch's RCCL -- `ncclCommInitRank: unhandled cuda error`).  So where PyTorch is
-    installed but not imported yet, its runtime is loaded first and the library's DT_NEEDED entry resolves to it (SONAME match);
-    where PyTorch is absent (a C host, examples/selfplay_host.c) the system runtime and the system RCCL are used together."""
+HIP_RUNTIME_BOUND = None          # after load(): "torch:<path>" (PyTorch's bundled runtime was preloaded) or "system"
+
+
+def _elf_dynamic_strings(path):
+    """(DT_SONAME or None, [DT_NEEDED ...]) of a little-endian ELF64 shared object, read without external tools"""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
+        raise ValueError("not a little-endian ELF64 file")
+    phoff, = struct.unpack_from("<Q", data, 0x20)
+    phentsize, phnum = struct.unpack_from("<HH", data, 0x36)
+    loads, dyn = [], None
+    for k in range(phnum):
+        p_type, _flags, p_offset, p_vaddr, _paddr, p_filesz = struct.unpack_from("<IIQQQQ", data, phoff + k * phentsize)
+        if p_type == 1:
+            loads.append((p_vaddr, p_offset, p_filesz))
+        elif p_type == 2:
+            dyn = (p_offset, p_filesz)
+    if dyn is None:
+        return None, []
+    entries = [struct.unpack_from("<qQ", data, dyn[0] + 16 * k) for k in range(dyn[1] // 16)]
+    strtab = next((v for t, v in entries if t == 5), None)
+    if strtab is None:
+        return None, []
+    off = next((strtab - va + fo for va, fo, sz in loads if va <= strtab < va + sz), strtab)
+
+    def name(idx):
+        end = data.index(b"\0", off + idx)
+        return data[off + idx:end].decode()
+    soname = next((name(v) for t, v in entries if t == 14), None)
+    return soname, [name(v) for t, v in entries if t == 1]
+
+
+def _one_hip_runtime(lib_path):
+    """PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so) and load it by path.  If this library is loaded first it
+    binds to the system runtime, a later `import torch` brings the bundled one in as well, and the process holds TWO HIP / HSA runtimes:
+    streams and device pointers of one are invalid handles in the other (torch tensors handed to the library, the library's RCCL
+    exchange step on torch's RCCL -- `ncclCommInitRank: unhandled cuda error`).  So where PyTorch is installed but not imported yet, its
+    runtime is loaded first and the library's DT_NEEDED entry resolves to it -- ONLY when that is the runtime the library was linked
+    against: the bundled file's SONAME must equal the library's DT_NEEDED name (libamdhip64.so.<major>); otherwise the system runtime is
+    used and a warning says so (a silent major-version mix fails, or loads two runtimes anyway, with no message).  Where
+    PyTorch is absent (a C host, examples/selfplay_host.c) the system runtime and the system RCCL are used together.
+    `othellozero_amd._lib.HIP_RUNTIME_BOUND` records what happened; PRELOAD_TORCH_HIP = False (before the first load) opts out."""
+    global HIP_RUNTIME_BOUND
     import importlib.util
     import sys
-    if not PRELOAD_TORCH_HIP or "torch" in sys.modules:
+    import warnings
+    HIP_RUNTIME_BOUND = "system"
+    if not PRELOAD_TORCH_HIP:
         return
     try:
         spec = importlib.util.find_spec("torch")
         cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
-        if cand and os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
     except Exception:            # no PyTorch, or an unusual layout: the system runtime it is
-        pass
+        return
+    if not cand or not os.path.exists(cand):
+        return
+    try:
+        bundled_soname, _ = _elf_dynamic_strings(cand)
+        _, needed = _elf_dynamic_strings(lib_path)
+        wanted = next((x for x in needed if x.startswith("libamdhip64.so")), None)
+    except Exception as e:
+        warnings.warn(f"othellozero_amd: could not compare PyTorch's bundled HIP runtime with the library's ({e}); using the system runtime")
+        return
+    if "torch" in sys.modules:
+        HIP_RUNTIME_BOUND = "torch:" + cand          # already in the process (loaded by path): DT_NEEDED resolves to it by SONAME, or not at all
+        if wanted and bundled_soname != wanted:
+            warnings.warn(f"othellozero_amd: PyTorch's HIP runtime ({bundled_soname}) is not the one this library was linked against ({wanted}): "
+                          "two HIP runtimes in one process; do not hand torch device pointers or streams to the library")
+            HIP_RUNTIME_BOUND = "system"
+        return
+    if wanted and bundled_soname == wanted:
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        HIP_RUNTIME_BOUND = "torch:" + cand
+    else:
+        warnings.warn(f"othellozero_amd: PyTorch bundles HIP runtime {bundled_soname}, the library was linked against {wanted}: not preloading it; "
+                      "a later `import torch` will put two HIP runtimes in this process (keep torch device pointers away from the library)")
 
 
 def load(path=None):
@@ -174,7 +234,7 @@ def load(path=None):
         raise OzLibraryError(
             f"{p} not found: the HIP extension is required (no CPU fallback). Build it with "
             "`python -m othellozero_amd.build` (hipcc --offload-arch=gfx950).")
-    _one_hip_runtime()
+    _one_hip_runtime(p)
     try:
         lib = C.CDLL(p)
     except OSError as e:

@@ -1806,7 +1806,7 @@ struct oz_comm {
     void* comm = nullptr;
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;
-    long long* d_counts = nullptr;        // [world + 1]: this rank's count, then every rank's
+    long long* d_counts = nullptr;        // [2 + 2 * world]: this rank's (count, room), then every rank's pair
     unsigned char *d_send = nullptr, *d_recv = nullptr;
     long long cap = 0;                    // records per rank the two buffers hold
     std::mutex mu;
@@ -1830,7 +1830,7 @@ OZ_API int oz_comm_create(oz_comm** out, const uint8_t* id, int rank, int world)
     memcpy(uid.b, id, OZ_COMM_ID_BYTES);
     int nrc = g_rccl.CommInitRank(&c->comm, world, uid, rank);
     if (nrc != 0) { oz_set_error("RCCL: %s (ncclCommInitRank, rank %d of %d)", g_rccl.GetErrorString(nrc), rank, world); delete c; return OZ_ERR_HIP; }
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipMalloc((void**)&c->d_counts, sizeof(long long) * (world + 1)) != hipSuccess) {
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipMalloc((void**)&c->d_counts, sizeof(long long) * (2 * world + 2)) != hipSuccess) {
         oz_set_error("oz_comm_create: stream / buffer allocation failed");
         g_rccl.CommDestroy(c->comm);
         delete c;
@@ -1853,11 +1853,16 @@ OZ_API int oz_comm_destroy(oz_comm* c) {
 
 // COLLECTIVE: every rank of `comm` calls it with its own engine.  The records [first_record, records completed so far) of every rank's
 // engine, concatenated in rank order, into `out` (host, caller-owned, max_records long; per_rank[world] gets every rank's count).
-// Counts all-gather (8 bytes per rank) + ONE padded all-gather of 48-byte records, device to device out of the engines' HBM buffers.
+// A (count, room) pair all-gather (16 bytes per rank) + ONE padded all-gather of 48-byte records, device to device out of the engines' HBM
+// buffers.  Every decision that could end the call between the two collectives is taken from the GATHERED pairs, i.e. identically on every
+// rank (a rank-local capacity check let one rank leave while its peers entered the payload all-gather): too little room on ANY
+// rank fails the call on EVERY rank, before the payload moves; a failed buffer allocation is agreed on by one more 8-byte all-gather.
+// out == NULL with max_records == 0 on every rank = the counts only (*written = the pooled number, per_rank filled): size the buffer, call again.
 OZ_API int oz_selfplay_gather_records(oz_selfplay* sp, oz_comm* c, int64_t first_record, oz_record* out, int64_t max_records, int64_t* written,
                                       int64_t* per_rank) {
     OZ_REQUIRE(sp && c && written, "null argument");
     OZ_REQUIRE(first_record >= 0, "first_record %lld", (long long)first_record);
+    OZ_REQUIRE(out || max_records == 0, "oz_selfplay_gather_records: null output buffer with room for %lld records", (long long)max_records);
     std::lock_guard<std::mutex> lk(sp->mu);
     std::lock_guard<std::mutex> lkc(c->mu);
     hipSetDevice(sp->m->device);
@@ -1866,34 +1871,54 @@ OZ_API int oz_selfplay_gather_records(oz_selfplay* sp, oz_comm* c, int64_t first
     unsigned long long total = 0;
     OZ_HIP(hipMemcpy(&total, sp->gm.counters, 8, hipMemcpyDeviceToHost));
     long long have = (long long)total < sp->gm.record_cap ? (long long)total : sp->gm.record_cap;
-    long long mine = have > first_record ? have - first_record : 0;
     const int W = c->world;
-    OZ_HIP(hipMemcpyAsync(c->d_counts, &mine, sizeof(long long), hipMemcpyHostToDevice, c->stream));
-    OZ_NCCL(g_rccl.AllGather(c->d_counts, c->d_counts + 1, 1, OZ_NCCL_INT64, c->comm, c->stream));
-    std::vector<long long> counts((size_t)W);
-    OZ_HIP(hipMemcpyAsync(counts.data(), c->d_counts + 1, sizeof(long long) * W, hipMemcpyDeviceToHost, c->stream));
+    long long pair[2] = {have > first_record ? have - first_record : 0, out ? (long long)max_records : -1};      // room -1 = "counts only"
+    const long long mine = pair[0];
+    OZ_HIP(hipMemcpyAsync(c->d_counts, pair, sizeof pair, hipMemcpyHostToDevice, c->stream));
+    OZ_NCCL(g_rccl.AllGather(c->d_counts, c->d_counts + 2, 2, OZ_NCCL_INT64, c->comm, c->stream));
+    std::vector<long long> pairs((size_t)2 * W);
+    OZ_HIP(hipMemcpyAsync(pairs.data(), c->d_counts + 2, sizeof(long long) * 2 * W, hipMemcpyDeviceToHost, c->stream));
     OZ_HIP(hipStreamSynchronize(c->stream));
     long long mx = 0, sum = 0;
-    for (int r = 0; r < W; ++r) { mx = counts[r] > mx ? counts[r] : mx; sum += counts[r]; if (per_rank) per_rank[r] = counts[r]; }
+    int counts_only = 0, short_rank = -1;
+    for (int r = 0; r < W; ++r) {
+        const long long cnt = pairs[2 * r];
+        mx = cnt > mx ? cnt : mx; sum += cnt;
+        if (per_rank) per_rank[r] = cnt;
+        if (pairs[2 * r + 1] < 0) ++counts_only;
+    }
+    for (int r = 0; r < W && short_rank < 0; ++r) if (pairs[2 * r + 1] >= 0 && pairs[2 * r + 1] < sum) short_rank = r;
     *written = 0;
+    if (counts_only == W) { *written = sum; return OZ_OK; }
+    OZ_REQUIRE(counts_only == 0, "oz_selfplay_gather_records: %d of %d ranks asked for the counts only (out == NULL), the others for the records", counts_only, W);
+    OZ_REQUIRE(short_rank < 0, "oz_selfplay_gather_records: %lld pooled records, rank %d has room for %lld (every rank fails together)", sum, short_rank,
+               pairs[2 * short_rank + 1]);
     if (mx == 0) return OZ_OK;
-    OZ_REQUIRE(out && sum <= max_records, "oz_selfplay_gather_records: %lld pooled records, room for %lld", sum, (long long)max_records);
-    if (mx > c->cap) {                                        // grow the padded send / receive buffers (kept with the communicator)
-        hipFree(c->d_send); hipFree(c->d_recv);
+    if (mx > c->cap) {                                        // grow the padded send / receive buffers (kept with the communicator); every rank's cap
+        hipFree(c->d_send); hipFree(c->d_recv);               // has followed the same mx history, so all of them are here together
         c->d_send = c->d_recv = nullptr; c->cap = 0;
         const long long cap = mx + mx / 4 + 1024;
-        OZ_HIP(hipMalloc((void**)&c->d_send, (size_t)cap * sizeof(oz_record)));
-        OZ_HIP(hipMalloc((void**)&c->d_recv, (size_t)cap * sizeof(oz_record) * W));
-        c->cap = cap;
+        long long failed = hipMalloc((void**)&c->d_send, (size_t)cap * sizeof(oz_record)) != hipSuccess ||
+                           hipMalloc((void**)&c->d_recv, (size_t)cap * sizeof(oz_record) * W) != hipSuccess;
+        if (!failed) c->cap = cap;
+        else { hipFree(c->d_send); hipFree(c->d_recv); c->d_send = c->d_recv = nullptr; (void)hipGetLastError(); }
+        OZ_HIP(hipMemcpyAsync(c->d_counts, &failed, sizeof failed, hipMemcpyHostToDevice, c->stream));
+        OZ_NCCL(g_rccl.AllGather(c->d_counts, c->d_counts + 2, 1, OZ_NCCL_INT64, c->comm, c->stream));
+        std::vector<long long> st((size_t)W);
+        OZ_HIP(hipMemcpyAsync(st.data(), c->d_counts + 2, sizeof(long long) * W, hipMemcpyDeviceToHost, c->stream));
+        OZ_HIP(hipStreamSynchronize(c->stream));
+        for (int r = 0; r < W; ++r)
+            if (st[r]) { oz_set_error("oz_selfplay_gather_records: rank %d could not allocate its exchange buffers (%lld records x %d ranks)", r, cap, W); return OZ_ERR_HIP; }
     }
     if (mine) OZ_HIP(hipMemcpyAsync(c->d_send, sp->gm.records + first_record, (size_t)mine * sizeof(oz_record), hipMemcpyDeviceToDevice, c->stream));
     if (mine < mx) OZ_HIP(hipMemsetAsync(c->d_send + (size_t)mine * sizeof(oz_record), 0, (size_t)(mx - mine) * sizeof(oz_record), c->stream));
     OZ_NCCL(g_rccl.AllGather(c->d_send, c->d_recv, (size_t)mx * sizeof(oz_record), OZ_NCCL_UINT8, c->comm, c->stream));
     long long pos = 0;
     for (int r = 0; r < W; ++r) {
-        if (counts[r]) OZ_HIP(hipMemcpyAsync(out + pos, c->d_recv + (size_t)r * mx * sizeof(oz_record), (size_t)counts[r] * sizeof(oz_record),
-                                             hipMemcpyDeviceToHost, c->stream));
-        pos += counts[r];
+        const long long cnt = pairs[2 * r];
+        if (cnt) OZ_HIP(hipMemcpyAsync(out + pos, c->d_recv + (size_t)r * mx * sizeof(oz_record), (size_t)cnt * sizeof(oz_record),
+                                       hipMemcpyDeviceToHost, c->stream));
+        pos += cnt;
     }
     OZ_HIP(hipStreamSynchronize(c->stream));
     *written = sum;

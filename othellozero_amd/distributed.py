@@ -137,14 +137,22 @@ class Comm:
         _lib.check(lib.oz_comm_create(C.byref(self._h), ident, rank, world))
 
     def gather_records(self, engine, first_record=0, max_records=None):
-        """COLLECTIVE: the records [first_record, ...) of every rank's engine in rank order -> (records, per-rank counts)"""
+        """COLLECTIVE: the records [first_record, ...) of every rank's engine in rank order -> (records, per-rank counts).
+        Two collective calls: the counts alone (out = NULL), then the records into a buffer sized from the pooled count -- the same
+        number on every rank, so no rank can come up short while its peers wait in the payload all-gather.  max_records, if
+        given, is this rank's room: the library fails the call on every rank together when it is too small on any."""
         import ctypes as C
         from . import _lib
-        cap = int(max_records if max_records is not None else self.world * max(engine.stats()["records"] - first_record, 0) * 2 + 65536)
-        out = np.zeros(cap, dtype=RECORD_DTYPE)
+        lib = _lib.load()
         written, per = C.c_int64(), np.zeros(self.world, np.int64)
-        _lib.check(_lib.load().oz_selfplay_gather_records(engine._h, self._h, int(first_record), out.ctypes.data_as(C.c_void_p), cap,
-                                                          C.byref(written), _lib.p_i64(per)))
+        if max_records is None:
+            _lib.check(lib.oz_selfplay_gather_records(engine._h, self._h, int(first_record), None, 0, C.byref(written), _lib.p_i64(per)))
+            cap = max(int(written.value), 1)
+        else:
+            cap = int(max_records)
+        out = np.zeros(cap, dtype=RECORD_DTYPE)
+        _lib.check(lib.oz_selfplay_gather_records(engine._h, self._h, int(first_record), out.ctypes.data_as(C.c_void_p), cap,
+                                                  C.byref(written), _lib.p_i64(per)))
         return out[:written.value], per
 
     def close(self):

@@ -74,45 +74,38 @@ def execute_episode(board_size, neural_network, degree_exploration, num_simulati
 
 def duel_between_neural_networks(board_size, neural_network_1, neural_network_2, degree_exploration, num_simulations,
                                  fixed=False):
-    """training.py:75-88 (imported by workers.py:14-15, pickle_training.py:36).  As the reference: the (agent, points) tuple
-    that duel_between_agents returns is used as the dictionary key, so the call raises KeyError after the game has been
-    played (tests/golden/drivers_misc.json records that behaviour of the reference).  fixed=True unpacks the tuple and
-    returns what the function evidently means to: 0 if neural_network_1's agent (BLACK) won, else 1."""
+    """One game, neural_network_1 as BLACK against neural_network_2 (the name workers.py:14-15 and pickle_training.py:36 import;
+    reference body: training.py:75-88).  What the reference really does is play the game and then fail: it looks the whole
+    `(agent, points)` result of duel_between_agents up in a dict keyed by agent, i.e. KeyError -- recorded from a run of the
+    reference in tests/golden/drivers_misc.json and reproduced here.  fixed=True returns what was meant: 0 if the first
+    network won, 1 otherwise."""
     from .agents import NeuralNetworkOthelloAgent, duel_between_agents
-    game = OthelloGame(board_size)
-    nn_1_agent = NeuralNetworkOthelloAgent(game, neural_network_1, num_simulations, degree_exploration)
-    nn_2_agent = NeuralNetworkOthelloAgent(game, neural_network_2, num_simulations, degree_exploration)
-    agents = {nn_1_agent: neural_network_1, nn_2_agent: neural_network_2}
-    agent_winner = duel_between_agents(game, nn_1_agent, nn_2_agent)
-    if fixed:
-        agent_winner = agent_winner[0]
-    return 0 if agents[agent_winner] is neural_network_1 else 1
+    board = OthelloGame(board_size)
+    black, white = (NeuralNetworkOthelloAgent(board, net, num_simulations, degree_exploration)
+                    for net in (neural_network_1, neural_network_2))
+    outcome = duel_between_agents(board, black, white)          # (winning agent, its points)
+    if not fixed:
+        raise KeyError(outcome)
+    return 0 if outcome[0] is black else 1
 
 
 def evaluate_neural_network(board_size, total_iterations, neural_network, num_simulations, degree_exploration,
                             agent_class, agent_arguments, fixed=False):
-    """training.py:91-118 (imported by workers.py:14-15): `total_iterations` duels of the network's agent against
-    agent_class(game, *agent_arguments), colours drawn by random.shuffle.  As the reference: `agent_winner is nn_agent`
-    compares the (agent, points) tuple with the agent, so no win is ever counted and the function returns 0
-    (tests/golden/drivers_misc.json); fixed=True compares the winning agent."""
+    """`total_iterations` games of the network's search agent against agent_class(game, *agent_arguments); returns the number
+    of games counted as won (reference body: training.py:91-118, imported by workers.py:14-15).  Colours come from one
+    random.shuffle of [opponent, network] per game, as there.  The reference compares the `(agent, points)` result with
+    the agent itself, so it never counts a win and returns 0 (tests/golden/drivers_misc.json); fixed=True compares the agent."""
     from .agents import NeuralNetworkOthelloAgent, duel_between_agents
-    net_wins = 0
-    logging.info('Neural Network Evaluation: Started')
-    for iteration in range(1, total_iterations + 1):
-        game = OthelloGame(board_size)
-        nn_agent = NeuralNetworkOthelloAgent(game, neural_network, num_simulations, degree_exploration)
-        evaluation_agent = agent_class(game, *agent_arguments)
-        agents = [evaluation_agent, nn_agent]
-        random.shuffle(agents)
-        agent_winner = duel_between_agents(game, *agents)
-        if fixed:
-            agent_winner = agent_winner[0]
-        if agent_winner is nn_agent:
-            net_wins += 1
-            logging.info('Neural Network Evaluation: Network won')
-        else:
-            logging.info('Neural Network Evaluation: Network lost')
-    return net_wins
+    wins = 0
+    for _ in range(total_iterations):
+        board = OthelloGame(board_size)
+        ours = NeuralNetworkOthelloAgent(board, neural_network, num_simulations, degree_exploration)
+        seats = [agent_class(board, *agent_arguments), ours]
+        random.shuffle(seats)
+        victor, _points = duel_between_agents(board, *seats)
+        wins += int(fixed and victor is ours)
+    logging.info(f'Neural Network Evaluation: {wins} of {total_iterations} games counted as won')
+    return wins
 
 
 # ---------------------------------------------------------------- batched engine

@@ -23,6 +23,8 @@ Fixtures:
   episodes.npz   execute_episode traces (moves, snapshots, root counts, returned examples, z)
   arena.npz      duel_between_agents traces
   episodes_bnn.npz  execute_episode through the one-channel (BaseNN) board view
+  policy_temps.npz  get_policy_action_probabilities at temperatures whose N ** (1 / T) is not an exact power (1/3, 0.7, 1.5, ...) and one
+                    episode at T = 0.5, every move's pi recorded
 """
 import enum
 import os
@@ -587,7 +589,71 @@ def bnn_fixture():
     np.savez_compressed(os.path.join(OUT, "episodes_bnn.npz"), **out)
 
 
+# ---------------------------------------------------------------- policy extraction at awkward temperatures (M10)
+POLICY_TEMPS = (1.0 / 3.0, 0.5, 0.7, 1.5, 2.0, 3.0)
+
+
+class PolicyRecordingMCTS(RecordingMCTS):
+    pis = None
+
+    def get_policy_action_probabilities(self, state, temperature):
+        pi = super().get_policy_action_probabilities(state, temperature)
+        PolicyRecordingMCTS.pis.append(np.array(pi, dtype=np.float64))
+        return pi
+
+
+def policy_temps_fixture():
+    """othelo_mcts.py:64-67: `self.N(state, action) ** (1 / temperature)` is Python int ** float, i.e. libm pow on a float64, then np.sum"""
+    out, names = {}, []
+    specs = [("pt8", 8, 11, 0, "f64", 1, 100), ("pt6", 6, 21, 0, "nep50", 1, 300), ("pt6_sparse", 6, 22, 7, "nep50", 1, 60), ("pt4", 4, 31, 0, "f64", 2, 120)]
+    for name, n, salt, keep, regime, c, sims in specs:
+        root = OthelloGame.initial_board(n)
+        m = othelo_mcts.OthelloMCTS(n, StubNet(n, salt, keep, regime), c)
+        for _ in range(sims):
+            m.simulate(root, OthelloPlayer.BLACK)
+        cnt = np.zeros(64, np.int32)
+        for a in m._get_state_actions(root):
+            cnt[a[0] * 8 + a[1]] = m.N(root, a)
+        out[f"{name}/meta"] = np.array([n, salt, keep, 0 if regime == "nep50" else 1, sims], dtype=np.int64)
+        out[f"{name}/c"] = np.array([float(c)])
+        out[f"{name}/root"] = np.array(pack(root), dtype=np.uint64)
+        out[f"{name}/counts"] = cnt
+        out[f"{name}/pi"] = np.stack([m.get_policy_action_probabilities(root, T) for T in POLICY_TEMPS])
+        names.append(name)
+        print("policy", name, "root visits", int(cnt.sum()), "max pi at T=1/3", float(out[f"{name}/pi"][0].max()))
+    out["temps"] = np.array(POLICY_TEMPS)
+    # one whole episode at T = 0.5 (6x6, 40 sims): moves as usual plus the pi of every move
+    saved = patched_rng()
+    training.OthelloGame = CountingGame
+    training.OthelloMCTS = PolicyRecordingMCTS
+    try:
+        name, n, sims, c, T, eg, seed, game, salt, keep, regime = ("ep6_T05", 6, 40, 1, 0.5, 0.9, 4321, 11, 113, 0, "nep50")
+        Ctx.seed, Ctx.game, Ctx.ply, Ctx.counts = seed, game, 0, []
+        CountingGame.log = []
+        PolicyRecordingMCTS.pis = []
+        ex = training.execute_episode(n, StubNet(n, salt, keep, regime), c, sims, T, eg)
+        log = CountingGame.log
+        k = len(log)
+        assert len(ex) == 8 * k and len(PolicyRecordingMCTS.pis) == k
+        out[f"{name}/meta"] = np.array([n, sims, seed, game, salt, keep, 0 if regime == "nep50" else 1, k], dtype=np.int64)
+        out[f"{name}/params"] = np.array([float(c), float(T), float(eg)])
+        out[f"{name}/black"] = np.array([x[0] for x in log], dtype=np.uint64)
+        out[f"{name}/white"] = np.array([x[1] for x in log], dtype=np.uint64)
+        out[f"{name}/player"] = np.array([x[2] for x in log], dtype=np.int8)
+        out[f"{name}/action"] = np.array([x[3] for x in log], dtype=np.uint8)
+        out[f"{name}/counts"] = np.array(Ctx.counts, dtype=np.int32)
+        out[f"{name}/pi"] = np.stack(PolicyRecordingMCTS.pis)
+        out[f"{name}/ex_z"] = np.array([z for _, _, z in ex], dtype=np.int8)
+        print("policy episode", name, "moves", k)
+    finally:
+        restore_rng(saved)
+        training.OthelloGame = OthelloGame
+        training.OthelloMCTS = othelo_mcts.OthelloMCTS
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "policy_temps.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rules", "pairwise", "symmetries", "mcts", "episodes", "arena", "bnn", "arena_random"]
+    which = sys.argv[1:] or ["rules", "pairwise", "symmetries", "mcts", "episodes", "arena", "bnn", "arena_random", "policy_temps"]
     for w in which:
         globals()[w + "_fixture"]()

@@ -1391,7 +1391,7 @@ def test_library_side_random_initialisation_is_keras_default_and_deterministic(o
 @pytest.mark.gpu
 def test_c_abi_policy_equals_the_mirror(oz, monkeypatch):
     """oz_mcts_policy = OthelloMCTS.get_policy_action_probabilities (othelo_mcts.py:51-67) behind the C ABI: bit for bit the float64 (n, n) array
-    the Python mirror computes with the reference's own NumPy expressions, for temperatures 1, 0.5 and 2, and for temperature 0 with the tie
+    the Python mirror computes with the reference's own expressions, for temperatures 1, 0.5, 2, 1/3, 0.7, 1.5, 3, and for temperature 0 with the tie
     draw standing in for random.choice(bests)"""
     from othellozero_amd.Othello import BoardView, OthelloGame, OthelloPlayer
     from othellozero_amd.othelo_mcts import OthelloMCTS
@@ -1411,7 +1411,7 @@ def test_c_abi_policy_equals_the_mirror(oz, monkeypatch):
             oz.check(lib.oz_mcts_policy(m._h, 1.0, None, pol.ctypes.data_as(C.POINTER(C.c_double)), oz.p_i32(rc)))
             assert rc[0] == 2 and not pol.any()
             continue
-        for T in (1, 0.5, 2):
+        for T in (1, 0.5, 2, 1 / 3, 0.7, 1.5, 3):               # exact powers / roots and temperatures where pow() has to round
             want = m.get_policy_action_probabilities(state, T)
             oz.check(lib.oz_mcts_policy(m._h, float(T), None, pol.ctypes.data_as(C.POINTER(C.c_double)), oz.p_i32(rc)))
             assert rc[0] == 0 and np.array_equal(pol.reshape(n, n), want), (sims, T)
@@ -1422,3 +1422,54 @@ def test_c_abi_policy_equals_the_mirror(oz, monkeypatch):
             oz.check(lib.oz_mcts_policy(m._h, 0.0, oz.p_u64(draws), pol.ctypes.data_as(C.POINTER(C.c_double)), oz.p_i32(rc)))
             assert np.array_equal(pol.reshape(n, n), want), (sims, k)
             monkeypatch.undo()
+
+
+@pytest.mark.gpu
+def test_policy_temperatures_vs_reference_golden(oz, monkeypatch):
+    """M10 at temperatures whose N ** (1 / T) is not an exact power: the root policy of four searches through the
+    Python mirror AND through oz_mcts_policy, and every move's pi of one whole episode at T = 0.5 (drop-in execute_episode, the
+    reference's draws patched as the generator patched them) -- bit for bit against tests/golden/policy_temps.npz, which
+    tests/golden/gen_golden.py wrote by running the reference (othelo_mcts.py:51-67)."""
+    from othellozero_amd import training
+    from othellozero_amd.Othello import OthelloGame, OthelloPlayer
+    from othellozero_amd.othelo_mcts import OthelloMCTS
+    lib = oz.load()
+    g = load_golden("policy_temps.npz")
+    temps = [float(t) for t in g["temps"]]
+    for name in g["names"]:
+        name = str(name)
+        n, salt, keep, qmode, sims = (int(x) for x in g[f"{name}/meta"])
+        root = oz.unpack_board(int(g[f"{name}/root"][0]), int(g[f"{name}/root"][1]), n)
+        m = OthelloMCTS(n, PyStubNet(n, salt, keep, qmode == 1), float(g[f"{name}/c"][0]), q_mode=qmode, node_cap=1024)
+        for _ in range(sims):
+            m.simulate(root, OthelloPlayer.BLACK)
+        pol, rc = np.zeros((1, n * n), np.float64), np.zeros(1, np.int32)
+        for i, T in enumerate(temps):
+            assert np.array_equal(m.get_policy_action_probabilities(root, T), g[f"{name}/pi"][i]), (name, T)
+            oz.check(lib.oz_mcts_policy(m._h, T, None, pol.ctypes.data_as(C.POINTER(C.c_double)), oz.p_i32(rc)))
+            assert rc[0] == 0 and np.array_equal(pol.reshape(n, n), g[f"{name}/pi"][i]), (name, T)
+    name = "ep6_T05"
+    n, sims, seed, game, salt, keep, qmode, k = (int(x) for x in g[f"{name}/meta"])
+    c, T, eg = (float(x) for x in g[f"{name}/params"])
+    ply, pis, pis_abi = [0], [], []
+    orig_play, orig_policy = OthelloGame.play, OthelloMCTS.get_policy_action_probabilities
+
+    def counting_play(self, row, col):
+        orig_play(self, row, col)
+        ply[0] += 1
+
+    def recording_policy(self, state, temperature):
+        pi = orig_policy(self, state, temperature)
+        pis.append(np.array(pi))
+        pol, rc = np.zeros((1, n * n), np.float64), np.zeros(1, np.int32)
+        oz.check(lib.oz_mcts_policy(self._h, float(temperature), None, pol.ctypes.data_as(C.POINTER(C.c_double)), oz.p_i32(rc)))
+        pis_abi.append(pol.reshape(n, n).copy())
+        return pi
+    monkeypatch.setattr(OthelloGame, "play", counting_play)
+    monkeypatch.setattr(OthelloMCTS, "get_policy_action_probabilities", recording_policy)
+    _patch_rng(monkeypatch, seed, game, lambda: ply[0])
+    ex = training.execute_episode(n, PyStubNet(n, salt, keep, qmode == 1), int(c), sims, T, eg, q_mode=qmode)
+    assert len(ex) == 8 * k and len(pis) == k
+    assert [z for _, _, z in ex] == [int(z) for z in g[f"{name}/ex_z"]]
+    for i in range(k):
+        assert np.array_equal(pis[i], g[f"{name}/pi"][i]) and np.array_equal(pis_abi[i], g[f"{name}/pi"][i]), i

@@ -247,3 +247,38 @@ def test_episodes_one_channel_view():
                 assert oracle.pack_board(snap[perms[t]].reshape(n, n, 2)) == tuple(int(x) for x in g[f"{name}/ex_board"][8 * i + t])
                 assert int(np.nonzero(perms[t] == a)[0][0]) == int(g[f"{name}/ex_policy"][8 * i + t])
                 assert int(ep["z"][i]) == int(g[f"{name}/ex_z"][8 * i + t])
+
+
+def test_policy_at_awkward_temperatures():
+    """M10 where `N ** (1 / T)` is not an exact power or root (T = 1/3, 0.7, 1.5, 3 next to 0.5 and 2): the reference evaluates
+    Python int ** float = libm pow on float64, then np.sum (othelo_mcts.py:64-67).  Root policies of four searches and the pi of every
+    move of one whole episode at T = 0.5, bit for bit against tests/golden/policy_temps.npz (generated by running the reference)."""
+    g = load_golden("policy_temps.npz")
+    temps = [float(t) for t in g["temps"]]
+    assert any(abs(t - 1 / 3) < 1e-15 for t in temps) and 0.7 in temps and 1.5 in temps
+    for name in g["names"]:
+        name = str(name)
+        n, salt, keep, qmode, sims = (int(x) for x in g[f"{name}/meta"])
+        rb, rw = (int(x) for x in g[f"{name}/root"])
+        m = oracle.Mcts(n, float(g[f"{name}/c"][0]), qmode, salt=salt, keep_mask=keep)
+        for _ in range(sims):
+            m.simulate(rb, rw, 1)
+        rc, cnt, legal = m.counts(rb, rw)
+        assert rc == 0 and np.array_equal(cnt, g[f"{name}/counts"]), name
+        for i, T in enumerate(temps):
+            pol, _ = m.policy(rb, rw, T)
+            assert np.array_equal(pol, g[f"{name}/pi"][i]), (name, T)
+            assert abs(pol.sum() - 1.0) < 1e-12
+    name = "ep6_T05"
+    n, sims, seed, game, salt, keep, qmode, k = (int(x) for x in g[f"{name}/meta"])
+    c, T, eg = (float(x) for x in g[f"{name}/params"])
+    assert T == 0.5
+    ep = oracle.Mcts(n, c, qmode, salt=salt, keep_mask=keep).episode(sims, T, eg, seed, game)
+    assert ep["n_moves"] == k and np.array_equal(ep["action"], g[f"{name}/action"]) and np.array_equal(ep["counts"], g[f"{name}/counts"])
+    assert np.array_equal(np.repeat(ep["z"], 8), g[f"{name}/ex_z"])
+    L = oracle.lib()
+    for i in range(k):
+        b, w, pl = int(g[f"{name}/black"][i]), int(g[f"{name}/white"][i]), int(g[f"{name}/player"][i])
+        own, opp = (b, w) if pl == 1 else (w, b)
+        pi = oracle.policy_from_counts(n, ep["counts"][i], L.orc_legal_mask(own, opp, n, 0), T)
+        assert np.array_equal(pi, g[f"{name}/pi"][i]), i
