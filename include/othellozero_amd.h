@@ -80,13 +80,14 @@ int oz_net_get_weight(const oz_net* net, int index, float* data, int64_t nelem);
 int oz_net_init_random(oz_net* net, uint64_t seed);
 /* arithmetic of the 3x3 convolutions and dense layers: 0 = exact fp32 matrix cores (v_mfma_f32_32x32x2_f32);
  * 1 = "f32 via 2 x fp16 split" (fp32-EQUIVALENT, not fp32): x = h1 + h2, products a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_16x16x32_f16 with
- * fp32 accumulation.  An element keeps 22 significant bits while |x| is in [2^-3, 65504] and an ABSOLUTE error of 2^-25 below that, so the
- * class (<= 2^-22 relative per product, i.e. fp32 accumulation error) holds for values in that window -- oz_net_commit puts them there:
- * every activation channel and every weight column gets an exact power-of-two scale (activations from the maxima of |BN output| over a
- * fixed calibration set of positions, landing in [2^8, 2^9); folded into the BN scale / shift and the next layer's weights, the network
- * function is unchanged; oz_net_get_scaling reads the exponents).  Guards, sticky, reported as OZ_ERR_STATE by oz_net_check / predict /
- * selfplay_sync: an activation above 65504 (2^7 above its channel's calibration maximum), or a pixel row whose largest scaled
- * activation is non-zero and below 2^-6 (2^15 below).  Needs channels % 256 == 0.  Takes effect at the next oz_net_commit. */
+ * fp32 accumulation.  An element is carried with an error of max(2^-24 |x|, 2^-25) inside the fp16 range, and oz_net_commit places every
+ * tensor: each activation channel and each weight column gets an exact power-of-two scale -- activations from the maxima of |BN output| over
+ * a fixed calibration set of positions -- so that its maximum lands in [2^-3, 2^-2): every element then has an absolute error <= 2^-23 of
+ * its channel's (column's) calibration maximum, fp32's own relative precision where a dot product's large terms are (the scales are folded
+ * into the BN scale / shift and the next layer's weights: the network function is unchanged; oz_net_get_scaling reads the exponents).
+ * Guards, sticky, reported as OZ_ERR_STATE by oz_net_check / predict / selfplay_sync: an activation above 65504, or a pixel row whose
+ * largest activation is non-zero and 2^15 or more below its channels' calibration maxima.  oz_net_commit also runs the self-check of
+ * OZ_NET_OPT_SELF_CHECK.  Needs channels % 256 == 0.  Takes effect at the next oz_net_commit. */
 int oz_net_set_precision(oz_net* net, int mode);
 int oz_net_get_precision(const oz_net* net);
 int oz_net_check(oz_net* net);
@@ -123,8 +124,9 @@ int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int
  * the 4-phase ping-pong loop.  Same tiles' accumulation order, bit-identical results: the reference form the LDS-DMA race screen
  * (tools/pp_race_check.py, test_pingpong_conv_loop_bit_identical_to_simple_loop) compares the ping-pong schedule against. */
 #define OZ_NET_OPT_SIMPLE_LOOP 1
-/* precision f16x2, both take effect at the next oz_net_commit: the power of two the per-channel calibration maxima are moved below (default 9;
- * test hook for the overflow guard), and log2 of the low-side guard's row threshold (default -6; <= -100 switches the guard off) */
+/* precision f16x2, all take effect at the next oz_net_commit: the powers of two the per-channel calibration maxima (ACT, default -2) and the
+ * per-column weight maxima (W, default -2) are moved below -- the defaults are the measured optimum of tools/target_probe.py, other values
+ * are test hooks and experiments -- and log2 of the low-side guard's row threshold (default -17; <= -100 switches the guard off) */
 #define OZ_NET_OPT_ACT_TARGET_LOG2 2
 #define OZ_NET_OPT_LOW_GUARD_LOG2 3
 /* precision f16x2, default 1: oz_net_commit runs its calibration positions through the f16x2 kernels and through the exact-fp32 kernels and
@@ -132,6 +134,7 @@ int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int
  * within 1e-5: a conditioning problem no range guard can see; healthy networks measure <= 4e-6, of which up to 3e-6 is the fp32 kernels' own
  * rounding); 0 = off, 2 = measure only; oz_net_self_check reads what the last commit measured */
 #define OZ_NET_OPT_SELF_CHECK 4
+#define OZ_NET_OPT_W_TARGET_LOG2 5
 int oz_net_set_option(oz_net* net, int option, int value);
 int oz_net_self_check(oz_net* net, double* max_dpi, double* max_dv, int* positions);
 /* precision f16x2: the exponents chosen at the last commit.  which = 0 .. 4: per-channel activation exponents of the conv1, conv2, conv3,

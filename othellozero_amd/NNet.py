@@ -57,8 +57,8 @@ class NNetWrapper(_NetHandle):
         _lib.check(create(C.byref(self._h), self.board_size_x, self.num_channels, self.max_batch))
         # precision: "f32" = exact fp32 matrix cores; "f16x2" = f32 via 2 x fp16 split on the 16-bit matrix cores
         # (fp32-equivalent: same <= 1e-5 tolerance, ~4x faster; needs channels % 256 == 0; every activation channel / weight column is moved into the
-        #  fp16 window by an exact power of two at commit, and a position whose activations leave it -- above 65504, or a whole pixel row below 2^-6 --
-        #  raises OzError(OZ_ERR_STATE) instead of returning a degraded answer)
+        #  fp16 window by an exact power of two at commit, a commit-time self-check against the exact-fp32 kernels refuses networks that amplify
+        #  rounding, and a position whose activations leave the calibrated range raises OzError(OZ_ERR_STATE) instead of returning a degraded answer)
         self.precision = precision
         _lib.check(lib.oz_net_set_precision(self._h, {"f32": 0, "f16x2": 1}[precision]))
         self.set_weights(weights if weights is not None else
@@ -222,8 +222,8 @@ class NNetWrapper(_NetHandle):
 
     def set_option(self, option, value):
         """switches (_lib.NET_OPT_*): NET_OPT_SIMPLE_LOOP = the one-barrier conv loop the race screen compares against; precision f16x2, effective
-        at the next commit(): NET_OPT_ACT_TARGET_LOG2 (calibration maxima land below 2^value, default 9), NET_OPT_LOW_GUARD_LOG2 (row threshold of the
-        low-side guard, default -6; <= -100 = off)"""
+        at the next commit(): NET_OPT_ACT_TARGET_LOG2 / NET_OPT_W_TARGET_LOG2 (calibration / column maxima land below 2^value, default -2),
+        NET_OPT_LOW_GUARD_LOG2 (row threshold of the low-side guard, default -17; <= -100 = off), NET_OPT_SELF_CHECK (0 off, 1 enforce, 2 measure)"""
         _lib.check(_lib.load().oz_net_set_option(self._h, int(option), int(value)))
 
     def commit(self):

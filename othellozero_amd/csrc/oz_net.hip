@@ -691,8 +691,9 @@ struct OnnNet : oz_net {
     unsigned* d_lowcnt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // low-side guard: per-row counters of tensor t (H2Low)
     unsigned char* d_lut_low = nullptr;                          // conv1 table rows that are low (k_lut_rowlow)
     unsigned fwd_seq = 0;            // forward number of the guard counters (26 bits, never 0)
-    int act_target_log2 = 9;         // OZ_NET_OPT_ACT_TARGET_LOG2: calibration maxima land in [2^(target-1), 2^target)
-    int low_guard_log2 = -6;         // OZ_NET_OPT_LOW_GUARD_LOG2 (<= -100: guard off); committed value below
+    int act_target_log2 = H2_ACT_TOP;   // OZ_NET_OPT_ACT_TARGET_LOG2: calibration maxima land in [2^(target-1), 2^target)
+    int w_target_log2 = H2_W_TOP;    // OZ_NET_OPT_W_TARGET_LOG2: every weight column's largest |w| lands in [2^(target-1), 2^target)
+    int low_guard_log2 = H2_LOW_GUARD;  // OZ_NET_OPT_LOW_GUARD_LOG2 (<= -100: guard off); committed value below
     float low_thr = 0.f;
     H2Low next_low;                  // guard of the NEXT launch_gemm_h2 (consumed by it)
     int next_relu = 1;               // 0: the NEXT launch_gemm_h2 writes the BN output without the ReLU (calibration passes; consumed by it)
@@ -951,10 +952,11 @@ struct OnnNet : oz_net {
         } profile_off(profile);
         float* const act_of[4] = {act2, act3, act4, f1};
         const int P_of[4] = {n * n, (n - 2) * (n - 2), (n - 4) * (n - 4), 1};
-        // Pass 0 calibrates (maxima -> [2^8, 2^9)) and builds every image as it goes.  OZ_NET_OPT_ACT_TARGET_LOG2 != 9 (a test hook) is applied
-        // AFTERWARDS as an exact bump of every exponent, and pass 1 rebuilds the images from the bumped exponents without calibrating:
-        // the calibration passes themselves never run outside the fp16 range, whatever the target.
-        constexpr int TOP = 9;
+        // Pass 0 calibrates (maxima -> [2^(H2_ACT_TOP - 1), 2^H2_ACT_TOP)) and builds every image as it goes.  Another OZ_NET_OPT_ACT_TARGET_LOG2
+        // (a test hook / the window experiments of tools/target_probe.py) is applied AFTERWARDS as an exact bump of every exponent, and pass 1
+        // rebuilds the images from the bumped exponents without calibrating: the calibration passes themselves never run outside the fp16
+        // range, whatever the target.
+        constexpr int TOP = H2_ACT_TOP;
         for (int pass = 0; pass < 2; ++pass) {
             const bool calibrating = pass == 0;
             if (!calibrating) {
@@ -1008,7 +1010,7 @@ struct OnnNet : oz_net {
                     hipLaunchKernelGGL(k_w_colmax, dim3((N + 255) / 256, (K + 63) / 64), dim3(256), 0, 0, d_raw, K, N, d_aexp[i], Cmod, d_colmax);
                     OZ_HIP(hipGetLastError());
                     if (int rc = read_colmax(N, mx, "a weight kernel")) return rc;
-                    pick_exponents(mx, 10, wexp[i]);
+                    pick_exponents(mx, w_target_log2, wexp[i]);
                 }
                 OZ_HIP(hipMemcpy(d_wexp, wexp[i].data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice));
                 if (!d_wh[i]) { if (int rc = alloc(&d_wh[i], (size_t)N * K / 4)) return rc; }
@@ -1127,9 +1129,9 @@ struct OnnNet : oz_net {
             return OZ_ERR_STATE;
         }
         if (f & H2_FLAG_LOW) {
-            oz_set_error("precision mode f16x2: a position's activations fell below the range the 2 x fp16 split carries with fp32 accuracy (a pixel row "
-                         "whose largest scaled activation is non-zero and below 2^%d): results may miss the 1e-5 class; use precision f32 for this network",
-                         low_guard_log2);
+            oz_set_error("precision mode f16x2: a position's activations fell below the range the commit-time calibration covers (a pixel row whose "
+                         "largest activation is non-zero and 2^%d or more below its channels' calibration maxima): results may miss the 1e-5 class; "
+                         "use precision f32 for this network", act_target_log2 - low_guard_log2);
             return OZ_ERR_STATE;
         }
         return OZ_OK;
@@ -1714,14 +1716,17 @@ OZ_API int oz_net_set_option(oz_net* net, int option, int value) {
     OnnNet* o = as_onn(net);
     OZ_REQUIRE(o, "not an OthelloNN network");
     OZ_REQUIRE(option == OZ_NET_OPT_SIMPLE_LOOP || option == OZ_NET_OPT_ACT_TARGET_LOG2 || option == OZ_NET_OPT_LOW_GUARD_LOG2 ||
-               option == OZ_NET_OPT_SELF_CHECK, "unknown network option %d", option);
+               option == OZ_NET_OPT_SELF_CHECK || option == OZ_NET_OPT_W_TARGET_LOG2, "unknown network option %d", option);
     std::lock_guard<std::mutex> lk(o->mu);
     if (option == OZ_NET_OPT_SIMPLE_LOOP) o->simple_loop = value != 0;
-    else if (option == OZ_NET_OPT_SELF_CHECK) {
+    else if (option == OZ_NET_OPT_W_TARGET_LOG2) {
+        OZ_REQUIRE(value >= -12 && value <= 15, "OZ_NET_OPT_W_TARGET_LOG2 must be in [-12, 15] (got %d)", value);
+        if (o->w_target_log2 != value) { o->w_target_log2 = value; o->committed = false; }
+    } else if (option == OZ_NET_OPT_SELF_CHECK) {
         OZ_REQUIRE(value >= 0 && value <= 2, "OZ_NET_OPT_SELF_CHECK must be 0 (off), 1 (enforce) or 2 (measure only); got %d", value);
         if (o->self_check != value) { o->self_check = value; o->committed = false; }
     } else if (option == OZ_NET_OPT_ACT_TARGET_LOG2) {
-        OZ_REQUIRE(value >= 1 && value <= 20, "OZ_NET_OPT_ACT_TARGET_LOG2 must be in [1, 20] (got %d)", value);
+        OZ_REQUIRE(value >= -12 && value <= 20, "OZ_NET_OPT_ACT_TARGET_LOG2 must be in [-12, 20] (got %d)", value);
         if (o->act_target_log2 != value) { o->act_target_log2 = value; o->committed = false; }
     } else {
         OZ_REQUIRE(value <= 15, "OZ_NET_OPT_LOW_GUARD_LOG2 must be <= 15 (got %d)", value);

@@ -4,25 +4,40 @@
 // Every fp32 value x is carried as two fp16 planes  x = h1 + h2,  h1 = fp16(x), h2 = fp16(x - h1), and a product is
 // evaluated as  a1*b1 + a1*b2 + a2*b1  on the fp16 matrix cores with fp32 accumulation.  3 MFMAs at 16x the fp32 rate.
 // What the split keeps (fp16: 11-bit significand, normal down to 2^-14, subnormal step 2^-24):
-//   |x| in [2^-3, 65504]: h1 and h2 are both normal -> 22 significant bits, error <= 2^-24 |x|; the dropped a2*b2 term and the
-//                         residuals are then <= 2^-22 relative per product -- the class of fp32 accumulation error over K = 4608;
+//   |x| in [2^-3, 65504]: h1 and h2 are both normal -> 22 significant bits, error <= 2^-24 |x|;
 //   |x| < 2^-3:           h2 falls into fp16 subnormals -> an ABSOLUTE error floor of 2^-25 per element (at 1e-3 about 15 bits
 //                         survive, below 6e-5 h1 itself is subnormal);   |x| > 65504: not representable.
-// So the class holds where the values that matter in a dot product sit in [2^-3, 65504], and it is the job of the SCALING to put
-// them there (round 4; rounds 1-3 scaled the weights per layer by their single largest |w| and the activations not at all):
+// So the error of an element is max(2^-24 |x|, 2^-25), and it is the job of the SCALING to place every tensor in that window
+// (round 4; rounds 1-3 scaled the weights per layer by their single largest |w| and the activations not at all -- they happened to
+// sit around 2^-6 .. 2^-3 for Keras-initialised networks, and nothing said what happens elsewhere):
 //   activations: every channel c of every h2 tensor (conv1..conv4, fc1 outputs) carries an exact power of two 2^aexp[c], chosen at
-//     oz_net_commit from the channel's maximum over a fixed calibration set of positions (all 3^9 patterns for conv1) so that the
-//     maximum lands in [2^8, 2^9): 2^7 of headroom to 65504 for positions the calibration has not seen, and the floor 2^-25 sits 2^-33
-//     below the channel's maximum.  The power is folded into the producing layer's BN scale and shift (exact) and divided out of the
+//     oz_net_commit from the channel's largest |BN output| (BEFORE the ReLU: the post-ReLU maximum of a channel that hovers around
+//     zero is not a scale) over a fixed calibration set of positions (all 3^9 patterns for conv1), so that this maximum lands in
+//     [2^-3, 2^-2) = H2_ACT_TOP.  The power is folded into the producing layer's BN scale and shift (exact) and divided out of the
 //     consuming layer's weight rows (exact) -- a diagonal rescaling between layers, the network function is unchanged;
-//   weights: after that division every output column c gets its own 2^kexp[c] (its largest |w| -> [2^9, 2^10)), folded into the
-//     column's BN scale: a column of small weights compensated by its BN variance keeps its 22 bits;
+//   weights: after that division every output column c gets its own 2^kexp[c] (its largest |w| -> [2^-3, 2^-2) = H2_W_TOP), folded
+//     into the column's BN scale: a column of small weights compensated by its BN variance is carried like any other.
+//   WHERE in the window, and why at the bottom.  With the maxima just below 2^-2 every element is carried with an ABSOLUTE error of
+//     2^-25 <= 2^-23 of its channel's (column's) calibration maximum -- fp32's own relative precision for the elements near the
+//     maximum, which dominate a dot product, and an error far below theirs for the small ones -- which is what an absolute tolerance
+//     on (pi, v) needs.  And the small elements' residual planes then hold few significant bits: the matrix pipe's power, and
+//     with it the sustained clock, follows the operand bits (round 3: zeroed residual planes ran 11 % faster).  Measured on one device
+//     (tools/target_probe.py: the bench's 3640-position launch, conv3 / whole forward / max error against float64 on 256 rows):
+//       maxima at 2^9 (activations) and 2^10 (weights), everything normal: 1143 us / 2169 us / 4.6e-8
+//       activations at 2^-2:                                            1109      / 2114    / 4.6e-8
+//       activations and weights at 2^-2 (the default):                  1089      / 2082    / 6.0e-8
+//       activations at 2^-4 / 2^-7 (the maxima themselves lose bits):   1094 / 1082 conv3,    1.2e-7 / 1.0e-6
+//     (the unscaled round-3 build: 1098 / 2093 / 9.4e-8 -- its activations sat at 2^-3 and below by accident.)
 //   guards (sticky device flag, OZ_ERR_STATE at the next synchronising call -- never a silent wrong answer): HIGH side, an
-//     activation above 65504; LOW side, a pixel row whose largest scaled activation over ALL channels is non-zero and below
-//     2^-6 (every element of that row is then carried with fewer than ~19 bits relative to the row: 2^-25 / 2^-6), detected per
-//     64-channel slice in the producing epilogue with a per-row counter for the rare low slices (h2_low_report).
+//     activation above 65504 (2^18 above its channel's calibration maximum: non-finite arithmetic upstream, in practice); LOW side, a
+//     pixel row whose largest scaled activation over ALL channels is non-zero and below 2^H2_LOW_GUARD = 2^-17, i.e. a position whose
+//     whole row sits 2^15 or more below the calibration maxima (the calibration does not describe it), detected per 64-channel slice
+//     in the producing epilogue with a per-row counter for the rare low slices (h2_low_report);
+//   self-check (oz_net.hip, run_self_check): at every commit the calibration positions go through these kernels AND the exact-fp32
+//     kernels; a difference above 8e-6 in (pi, v) fails the commit -- the screen for networks that amplify rounding (conditioning),
+//     which no range argument covers.
 // Measured: |d pi|, |d v| <= 1e-5 vs float64 on every tested network incl. small-activation, wide-weight-range and badly scaled BN
-// cases (tests/test_gpu_parity.py::test_f16x2_scaling_*), like the fp32 path.
+// cases (tests/test_gpu_parity.py::test_f16x2_scaling_*), like the fp32 path; 5e-8 on the bench's network.
 //
 // Storage ("h2 layout"): for a row (pixel or output channel) every 8 consecutive k are one 32-byte
 // group  [h1 x 8][h2 x 8]; a row of K values is K/8 groups = 4*K bytes (same footprint as fp32).
@@ -82,6 +97,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define H2_BK 32
 #define H2_F16_MAX 65504.0f
+#define H2_ACT_TOP (-2)                      // per-channel calibration maxima of the h2 tensors land in [2^(H2_ACT_TOP - 1), 2^H2_ACT_TOP)
+#define H2_W_TOP (-2)                        // every weight column's largest |w| lands in [2^(H2_W_TOP - 1), 2^H2_W_TOP)
+#define H2_LOW_GUARD (-17)                   // log2 of the low-side guard's row threshold: 2^15 below the calibration maxima
 #define H2_SELF_CHECK_LIMIT 8.0e-6           // oz_net_commit: largest |d pi|, |d v| between the f16x2 and the exact-fp32 kernels on the calibration positions
 
 // tile configurations: NWM x NWN waves, each wave NTI x NTJ blocks of 32 x 32 (= 2 x 2 MFMA tiles of 16 x 16)
@@ -134,11 +152,11 @@ typedef H2Cfg<2, 2, 1, 2, 3> H2Thin4w;
 struct H2Low {
     unsigned* cnt = nullptr;
     unsigned seq = 0;                     // 26-bit number of the forward (never 0)
-    float thr = 0.f;                      // 2^-6 by default (OZ_NET_OPT_LOW_GUARD_LOG2)
+    float thr = 0.f;                      // 2^H2_LOW_GUARD by default (OZ_NET_OPT_LOW_GUARD_LOG2)
     int* flag = nullptr;
 };
 // one 64-channel slice of row `row` came out low (0 < max < thr): count it; the row is low when all `nslices` of its slices are.
-// Rare by construction (a slice of 64 channels whose maxima all sit 2^15 below their calibration maxima), so a CAS loop is fine;
+// Rare by construction (a slice of 64 channels whose values all sit 2^15 below their calibration maxima), so a CAS loop is fine;
 // the forward number makes stale counts of earlier forwards harmless -- the array is never cleared.
 __device__ __forceinline__ void h2_low_report(const H2Low& lo, long long row, int nslices) {
     unsigned* p = lo.cnt + row;
@@ -316,7 +334,7 @@ __global__ __launch_bounds__(256) void k_w_transpose(const float* __restrict__ s
         if (c0 + r < N && k0 + tx < K) out[(size_t)(c0 + r) * K + k0 + tx] = tile[tx][r];
 }
 // h2 layout [N][K/8][h1 x 8 | h2 x 8] of  w[k][c] * 2^(colexp[c] - inexp[k % Cmod])  in the GEMM's k order k' = (slice * taps + tap) * 32 + c32:
-// colexp[c] moves column c's largest |w| into [2^9, 2^10), inexp[] divides the consumed tensor's per-channel activation scale out
+// colexp[c] moves column c's largest |w| into [2^(H2_W_TOP - 1), 2^H2_W_TOP), inexp[] divides the consumed tensor's per-channel activation scale out
 // (k % Cmod = the input channel of reduction index k: tap * Cin + ci for the 3x3 layers, pixel * C + c for fc1's flattened input).
 // One thread per (output channel c, group of 8 k'); adjacent threads = adjacent c (coalesced reads of the [K][N] source).
 __global__ __launch_bounds__(256) void k_w_to_h2(const float* __restrict__ src, int K, int N, int taps, const int* __restrict__ colexp,

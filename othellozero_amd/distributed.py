@@ -103,10 +103,22 @@ def arena_sharded(net_a, net_b, board_size=8, total_games=512, num_simulations=8
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     first, count = shard_games(total_games, rank, world)
     rows = np.zeros(count, dtype=ARENA_RESULT_DTYPE)
+    failed = None
     if count:
-        res = arena_batch(net_a, net_b, board_size, count, num_simulations, degree_exploration, seed=seed, first_game_id=first, **arena_kwargs)
-        rows["game_id"] = first + np.arange(count)
-        rows["winner"], rows["points"], rows["n_moves"] = res["winner"], res["points"], res["n_moves"]
+        try:
+            res = arena_batch(net_a, net_b, board_size, count, num_simulations, degree_exploration, seed=seed, first_game_id=first, **arena_kwargs)
+            rows["game_id"] = first + np.arange(count)
+            rows["winner"], rows["points"], rows["n_moves"] = res["winner"], res["points"], res["n_moves"]
+        except Exception as e:                                   # still join the collectives below: the peers must not wait for a rank that left
+            failed = e
+    if world > 1:
+        # one status word first (max over ranks): a rank whose games raised ends the match on EVERY rank, before anybody enters the gather
+        status = torch.tensor([1 if failed is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(status, op=dist.ReduceOp.MAX, group=group)
+        if int(status.item()):
+            raise failed if failed is not None else RuntimeError("arena_sharded: another rank's games raised; the match is abandoned on every rank")
+    elif failed is not None:
+        raise failed
     t = torch.from_numpy(rows.view(np.uint8).reshape(-1, ARENA_RESULT_DTYPE.itemsize).copy()).to(device)
     pooled = gather_records(t, group).detach().cpu().contiguous().numpy().reshape(-1).view(ARENA_RESULT_DTYPE)
     pooled = pooled[np.argsort(pooled["game_id"], kind="stable")]
@@ -196,13 +208,18 @@ class GradientAllReduce:
         from .trainer import Trainer
         self.group = group
         self.single_rank_collective = single_rank_collective    # run the all-reduce on a one-rank group too (one-GPU RCCL test)
-        self.flat = torch.zeros(Trainer.arena_size(board_size, channels, in_channels), dtype=torch.float32, device=device)
+        # one element more than the library's arena: the STATUS word of the step (0 = this rank's step is valid, 1 = it failed) rides in the
+        # same all-reduce -- its sum is the number of failed ranks -- instead of overloading a gradient element (a NaN in
+        # element 0 that a genuinely diverged step produced read as "another rank failed")
+        self.size = Trainer.arena_size(board_size, channels, in_channels)
+        self.flat = torch.zeros(self.size + 1, dtype=torch.float32, device=device)
         self.ptr = self.flat.data_ptr()
 
     def __call__(self, trainer, failed=None):
-        """failed: the error this rank's forward / backward raised (None: the step is valid).  A failed rank poisons element 0 of its
-        arena with NaN and still takes part in the all-reduce; after it every rank sees the NaN and raises, so a step that is invalid
-        on one rank (the f16x2 range guard, a diverged tensor) ends the job on ALL ranks instead of leaving the others blocked."""
+        """failed: the exception this rank's forward / backward raised (None: the step is valid).  A failed rank still takes part in the
+        all-reduce, with its status word set; afterwards every rank reads the number of failed ranks and raises if it is not zero, so a
+        step that is invalid on one rank (the f16x2 range guard, a bad batch, an out-of-memory) ends the job on ALL ranks instead of leaving
+        the others blocked in the collective."""
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(self.group) == 1 and not self.single_rank_collective):
             if failed is not None:
                 raise failed
@@ -210,21 +227,24 @@ class GradientAllReduce:
         world = dist.get_world_size(self.group)
         if failed is None:
             trainer.sync()                               # the library's stream wrote the arena
+            self.flat[self.size] = 0.0
         else:
-            self.flat[0] = float("nan")
+            self.flat[: self.size].zero_()               # whatever the failed step left there must not reach the peers' sums as NaN / Inf
+            self.flat[self.size] = 1.0
         if dist.get_backend(self.group) == "gloo" and self.flat.is_cuda:
             host = self.flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.copy_(host / world)
+            self.flat.copy_(host)
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(world)
+        bad = int(round(float(self.flat[self.size].item())))
+        self.flat[: self.size].div_(world)
         if self.flat.is_cuda:
             torch.cuda.synchronize(self.flat.device)     # torch's stream -> before the library's Adam kernel reads it
-        if bool(torch.isnan(self.flat[0]).item()):
+        if bad:
             from ._lib import OZ_ERR_STATE, OzError
-            raise failed if failed is not None else OzError(OZ_ERR_STATE, "another rank's training step was invalid (its forward / backward raised): "
-                                                                          "the averaged gradients are poisoned, the step is not applied on any rank")
+            raise failed if failed is not None else OzError(OZ_ERR_STATE, f"the training step was invalid on {bad} other rank(s) (their forward / backward "
+                                                                          "raised): the step is not applied on any rank")
 
 
 def average_moving_statistics(weights, group=None):

@@ -180,7 +180,7 @@ def fit(trainer, own, opp, pi, z, batch_size=32, epochs=10, shuffle_seed=0, allr
                 failed = None
                 try:
                     losses = trainer.forward_backward(own[idx], opp[idx], pi[idx], z[idx])
-                except _lib.OzError as e:                        # e.g. the f16x2 range guard: this rank's step is invalid
+                except Exception as e:                           # the f16x2 range guard, a bad batch shape, an out-of-memory: this rank's step is invalid
                     if allreduce is None:
                         raise
                     failed, losses = e, np.zeros(3)

@@ -506,8 +506,8 @@ def test_f16x2_range_guards_fail_loudly(oz):
         with pytest.raises(oz.OzError) as ei:
             net.predict_batch(own, opp)
         assert ei.value.code == oz.OZ_ERR_STATE and "fp16 range" in str(ei.value)
-        net.set_option(oz.NET_OPT_ACT_TARGET_LOG2, 9)
-        net.set_option(oz.NET_OPT_LOW_GUARD_LOG2, 12)          # every row's maximum (< 2^9 x headroom) is "low" now
+        net.set_option(oz.NET_OPT_ACT_TARGET_LOG2, -2)
+        net.set_option(oz.NET_OPT_LOW_GUARD_LOG2, 12)          # every row's maximum is "low" now
         with pytest.raises(oz.OzError) as ei:                  # ... already on the calibration positions of the commit's self-check
             net.commit()
         assert ei.value.code == oz.OZ_ERR_STATE and "fell below" in str(ei.value)
@@ -522,7 +522,7 @@ def test_f16x2_range_guards_fail_loudly(oz):
                 net.predict_batch(own, opp)
             assert ei.value.code == oz.OZ_ERR_STATE
         net.set_tables(-1)
-        net.set_option(oz.NET_OPT_LOW_GUARD_LOG2, -6)
+        net.set_option(oz.NET_OPT_LOW_GUARD_LOG2, -17)
         net.set_option(oz.NET_OPT_SELF_CHECK, 1)
         net.commit()                                           # back to the defaults: the same bits as before
         pi2, v2 = net.predict_batch(own, opp)

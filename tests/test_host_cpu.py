@@ -183,9 +183,23 @@ assert float(ar.flat[5]) == 1.5                     # the average of the two are
 err = _lib.OzError(_lib.OZ_ERR_STATE, "range guard") if rank == 1 else None
 try:
     ar(FakeTrainer(), failed=err)
-    raise SystemExit("the poisoned all-reduce did not raise on rank %d" % rank)
+    raise SystemExit("the all-reduce with a failed rank did not raise on rank %d" % rank)
 except _lib.OzError as e:
     assert e.code == _lib.OZ_ERR_STATE and (("range guard" in str(e)) == (rank == 1))
+# ... any exception, not only the library's (ADVICE r3): a bad batch shape on rank 0
+try:
+    ar(FakeTrainer(), failed=ValueError("bad batch") if rank == 0 else None)
+    raise SystemExit("a ValueError on one rank did not end the step on rank %d" % rank)
+except ValueError:
+    assert rank == 0
+except _lib.OzError as e:
+    assert rank == 1 and "other rank" in str(e)
+# the status word is its own element: a genuinely diverged gradient (NaN in element 0) is NOT reported as a peer's failure
+ar.flat.fill_(1.0)
+if rank == 0:
+    ar.flat[0] = float("nan")
+ar(FakeTrainer())
+assert bool(torch.isnan(ar.flat[0])) and float(ar.flat[1]) == 1.0
 # arena games sharded over the ranks: ONE all-gather of 16-byte results, every rank ends with the whole match sorted by game id
 import othellozero_amd.agents as agents
 from othellozero_amd.distributed import arena_sharded
@@ -198,6 +212,17 @@ assert np.array_equal(res["game_id"], np.arange(7)) and np.array_equal(res["winn
 assert np.array_equal(res["points"], 30 + np.arange(7)) and np.array_equal(res["n_moves"], 50 + np.arange(7))
 res1 = arena_sharded(None, None, 6, 1, 10)           # fewer games than ranks: rank 1 plays none
 assert np.array_equal(res1["game_id"], [0]) and res1["points"][0] == 30
+# a rank whose games raise ends the match on EVERY rank instead of leaving the others in the gather (ADVICE r3)
+def failing_arena(*a, first_game_id=0, **kw):
+    if first_game_id > 0:
+        raise RuntimeError("rank-local failure")
+    return fake_arena(*a, first_game_id=first_game_id, **kw)
+agents.arena_batch = failing_arena
+try:
+    arena_sharded(None, None, 6, 7, 10)
+    raise SystemExit("arena_sharded did not raise on rank %d" % rank)
+except RuntimeError as e:
+    assert ("rank-local failure" in str(e)) == (rank == 1) and ("another rank" in str(e)) == (rank == 0)
 dist.barrier()
 print("RANK_OK", rank)
 """

@@ -126,15 +126,15 @@ rank = int(os.environ["RANK"])
 dist.init_process_group("gloo", rank=rank, world_size=2)
 n, C = 6, 128
 ar = GradientAllReduce(n, C, 2, device="cpu")
-assert ar.flat.numel() == Trainer.arena_size(n, C, 2) and ar.flat.numel() % 4 == 0
+assert ar.flat.numel() == Trainer.arena_size(n, C, 2) + 1 and ar.size % 4 == 0          # the arena + the step's status word
 class FakeTrainer:
     synced = 0
     def sync(self): self.synced += 1
 ft = FakeTrainer()
-ar.flat.copy_(torch.arange(ar.flat.numel(), dtype=torch.float32) % 97 + rank * 10)
+ar.flat[:ar.size].copy_(torch.arange(ar.size, dtype=torch.float32) % 97 + rank * 10)
 ar(ft)
-want = torch.arange(ar.flat.numel(), dtype=torch.float32) % 97 + 5.0
-assert ft.synced == 1 and torch.equal(ar.flat, want), "arena not averaged"
+want = torch.arange(ar.size, dtype=torch.float32) % 97 + 5.0
+assert ft.synced == 1 and torch.equal(ar.flat[:ar.size], want) and float(ar.flat[ar.size]) == 0.0, "arena not averaged"
 w = init_weights(n, seed=rank, channels=C, randomize_all=True)
 avg = average_moving_statistics(w)
 w0, w1 = init_weights(n, seed=0, channels=C, randomize_all=True), init_weights(n, seed=1, channels=C, randomize_all=True)
