@@ -42,7 +42,7 @@ extern "C" {
 #define OZ_LEAF_WAIT 3       /* free-running driver with a batch cap: the leaf is chosen and waits for a slot of a later batch */
 
 const char* oz_last_error(void);
-int oz_version(void);
+int oz_version(void);                 /* 200 */
 int oz_device_count(void);
 int oz_set_device(int device);       /* device used by objects created afterwards on this thread */
 
@@ -149,9 +149,9 @@ int oz_net_get_info(oz_net* net, int what, int* value);
  * OthelloMCTS / MCTS (othelo_mcts.py:9-88, MCTS/__init__.py:19-187): num_games independent
  * instances, one wavefront per instance, tables resident in HBM. */
 typedef struct oz_mcts oz_mcts;
-/* node_cap: states per instance (each a fixed-stride record: header + one 24-byte edge per legal move, 1024 B on 8x8);
- * edge_cap: kept for ABI stability, unused since the edges live inside the node records (round 2) */
-int oz_mcts_create(oz_mcts** out, int n, int num_games, int node_cap, int edge_cap, double c, int q_mode);
+/* node_cap: states per instance (each a fixed-stride record: header + one 24-byte edge per legal move, 1024 B on 8x8).
+ * (oz_version 200: the `edge_cap` arguments / field of version 100 are gone -- the edges live inside the node records since round 2) */
+int oz_mcts_create(oz_mcts** out, int n, int num_games, int node_cap, double c, int q_mode);
 int oz_mcts_destroy(oz_mcts* m);
 int oz_mcts_reset(oz_mcts* m, int game /* -1 = all */);                 /* fresh OthelloMCTS() */
 /* cross-game leaf de-duplication of oz_mcts_simulate's batches (default on; results are identical either way) */
@@ -198,7 +198,7 @@ typedef struct {
     uint64_t game_id_stride;/* id step when a slot is refilled (world_size*num_games) */
     int32_t refill;         /* 1: a finished slot immediately starts a new game */
     int32_t node_cap;       /* per-game node table capacity (0 = sims*61+64) */
-    int32_t edge_cap;       /* unused (edges live inside the node records); kept for ABI stability */
+    int32_t reserved0;      /* 0 */
     int32_t record_cap;     /* move records kept for export (0 = num_games*64*4) */
     int32_t dedup;          /* OZ_DEDUP_*: cross-game leaf de-duplication -- a board that several games reach in the same batch is evaluated
                              * once and every one of them reads the same (pi, v) row; changes no record, count or statistic, only leaves_evaluated */
@@ -299,7 +299,7 @@ int oz_selfplay_gather_records(oz_selfplay* sp, oz_comm* comm, int64_t first_rec
  * main.py:163-233), its random.choice drawn from the RNG_TIE stream at that ply. */
 typedef struct oz_arena oz_arena;
 int oz_arena_create(oz_arena** out, int n, int num_games, int sims, double c, int q_mode, uint64_t seed,
-                    uint64_t first_game_id, oz_net* net_a, oz_net* net_b, int node_cap, int edge_cap);
+                    uint64_t first_game_id, oz_net* net_a, oz_net* net_b, int node_cap);
 int oz_arena_destroy(oz_arena* a);
 int oz_arena_run(oz_arena* a);       /* plays all games to the end (synchronous) */
 /* the same, stopping after `max_rounds` further rounds (0 = to the end): a round = one searched ply in every live game.  Synchronous; may

@@ -38,7 +38,7 @@ class SelfplayConfig(C.Structure):
         ("n", C.c_int32), ("num_games", C.c_int32), ("sims", C.c_int32), ("q_mode", C.c_int32),
         ("c", C.c_double), ("temperature", C.c_double), ("e_greedy", C.c_double),
         ("seed", C.c_uint64), ("first_game_id", C.c_uint64), ("game_id_stride", C.c_uint64),
-        ("refill", C.c_int32), ("node_cap", C.c_int32), ("edge_cap", C.c_int32), ("record_cap", C.c_int32),
+        ("refill", C.c_int32), ("node_cap", C.c_int32), ("reserved0", C.c_int32), ("record_cap", C.c_int32),
         ("dedup", C.c_int32), ("batch_cap", C.c_int32), ("eval_cache", C.c_int32), ("reserved", C.c_int32),
     ]
 
@@ -90,7 +90,7 @@ SIGNATURES = {
     "oz_net_set_option": [_vp, C.c_int, C.c_int], "oz_net_get_info": [_vp, C.c_int, C.POINTER(C.c_int)],
     "oz_net_get_scaling": [_vp, C.c_int, _i32p, C.c_int64],
     "oz_net_self_check": [_vp, _f64p, _f64p, C.POINTER(C.c_int)],
-    "oz_mcts_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int],
+    "oz_mcts_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int],
     "oz_mcts_destroy": [_vp], "oz_mcts_reset": [_vp, C.c_int], "oz_mcts_set_dedup": [_vp, C.c_int],
     "oz_mcts_set_roots": [_vp, _u64p, _u64p, _u8p],
     "oz_mcts_simulate": [_vp, _vp, C.c_int], "oz_mcts_select": [_vp],
@@ -114,7 +114,7 @@ SIGNATURES = {
     "oz_selfplay_eval_time": [_vp, _f64p, _i64p, _i64p],
     "oz_comm_unique_id": [_u8p], "oz_comm_create": [C.POINTER(_vp), _u8p, C.c_int, C.c_int], "oz_comm_destroy": [_vp],
     "oz_selfplay_gather_records": [_vp, _vp, C.c_int64, _vp, C.c_int64, _i64p, _i64p],
-    "oz_arena_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_uint64, _vp, _vp, C.c_int, C.c_int],
+    "oz_arena_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_uint64, _vp, _vp, C.c_int],
     "oz_arena_destroy": [_vp], "oz_arena_run": [_vp], "oz_arena_run_rounds": [_vp, C.c_int], "oz_arena_stats": [_vp, _i64p, _i64p],
     "oz_arena_set_dedup": [_vp, C.c_int], "oz_arena_leaves_evaluated": [_vp, _i64p, _i64p],
     "oz_arena_results": [_vp, _i8p, _i32p, _i32p, _u8p, _i8p, _u64p, _u64p],

@@ -74,7 +74,7 @@ def duel_between_agents(game, agent_1, agent_2):
 
 
 def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, degree_exploration=1.0, seed=0,
-                first_game_id=0, q_mode=_lib.QMODE_F64, node_cap=0, edge_cap=0, max_rounds=0, dedup=True):
+                first_game_id=0, q_mode=_lib.QMODE_F64, node_cap=0, max_rounds=0, dedup=True):
     """num_games games of net_a (BLACK) vs net_b (WHITE), temperature 0, max-visit ties broken by the RNG_TIE
     stream keyed (seed, game id, ply).  One of the two may be None: RandomOthelloAgent plays that colour.
     max_rounds > 0 stops after that many plies per game (unfinished boards: winner / points then describe the position reached).
@@ -85,7 +85,7 @@ def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, 
     h = C.c_void_p()
     _lib.check(lib.oz_arena_create(C.byref(h), board_size, num_games, num_simulations, float(degree_exploration), q_mode,
                                    seed, first_game_id, net_a._h if net_a is not None else None,
-                                   net_b._h if net_b is not None else None, node_cap, edge_cap))
+                                   net_b._h if net_b is not None else None, node_cap))
     try:
         if not dedup:                                        # every expansion evaluated by itself (identical results; bench.py's config5 headline)
             _lib.check(lib.oz_arena_set_dedup(h, 0))

@@ -17,7 +17,7 @@ void oz_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 OZ_API const char* oz_last_error(void) { return g_err; }
-OZ_API int oz_version(void) { return 100; }
+OZ_API int oz_version(void) { return 200; }     // 200 (round 4): edge_cap left oz_mcts_create / oz_arena_create / oz_selfplay_config
 OZ_API int oz_device_count(void) {
     int c = 0;
     if (hipGetDeviceCount(&c) != hipSuccess) return 0;

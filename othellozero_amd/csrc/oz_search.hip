@@ -594,12 +594,11 @@ static int mcts_reset_locked(oz_mcts* m, int game) {
 // Othello positions).  A position with more legal moves raises OZ_ERR_CAPACITY, never a silent truncation.
 static int row_cap_for(int n) { const int e = n * n - 4; return e < 41 ? e : 41; }
 
-static int mcts_create(oz_mcts** out, int n, int G, int node_cap, int edge_cap, double c, int q_mode) {
+static int mcts_create(oz_mcts** out, int n, int G, int node_cap, double c, int q_mode) {
     OZ_REQUIRE(n == 4 || n == 6 || n == 8, "board size must be 4, 6 or 8 (got %d)", n);
     OZ_REQUIRE(G > 0 && node_cap > 0, "num_games and node_cap must be positive");
     OZ_REQUIRE(node_cap < (int)OZ_HT_IDX_MASK, "node_cap %d too large (max %u)", node_cap, OZ_HT_IDX_MASK - 1);
     OZ_REQUIRE(q_mode == OZ_QMODE_NEP50 || q_mode == OZ_QMODE_F64, "unknown q_mode %d", q_mode);
-    (void)edge_cap;      // kept in the ABI: edges live inside the fixed-stride node records now, there is no separate edge pool
     oz_mcts* m = new oz_mcts();
     m->device = oz_current_device();
     MctsDev& d = m->d;
@@ -752,9 +751,9 @@ static int mcts_steps_async(oz_mcts* m, oz_net* net, int nsims, bool time_eval) 
     return OZ_OK;
 }
 
-OZ_API int oz_mcts_create(oz_mcts** out, int n, int num_games, int node_cap, int edge_cap, double c, int q_mode) {
+OZ_API int oz_mcts_create(oz_mcts** out, int n, int num_games, int node_cap, double c, int q_mode) {
     OZ_REQUIRE(out, "null out pointer");
-    return mcts_create(out, n, num_games, node_cap, edge_cap, c, q_mode);
+    return mcts_create(out, n, num_games, node_cap, c, q_mode);
 }
 OZ_API int oz_mcts_destroy(oz_mcts* m) { mcts_destroy(m); return OZ_OK; }
 
@@ -1277,9 +1276,8 @@ OZ_API int oz_selfplay_create(oz_selfplay** out, const oz_selfplay_config* cfg, 
     sp->cfg = *cfg; sp->net = net;
     const int max_plies = cfg->n * cfg->n - 4;
     const int node_cap = cfg->node_cap > 0 ? cfg->node_cap : cfg->sims * (max_plies + 1) + 64;
-    const int edge_cap = cfg->edge_cap > 0 ? cfg->edge_cap : node_cap * 14;
     const long long rcap = cfg->record_cap > 0 ? cfg->record_cap : (long long)cfg->num_games * 64 * 4;
-    int rc = mcts_create(&sp->m, cfg->n, cfg->num_games, node_cap, edge_cap, cfg->c, cfg->q_mode);
+    int rc = mcts_create(&sp->m, cfg->n, cfg->num_games, node_cap, cfg->c, cfg->q_mode);
     if (!rc) rc = games_alloc(sp, cfg->num_games, cfg->n, rcap);
     if (!rc) sp->m->d.dedup = cfg->dedup == OZ_DEDUP_OFF ? 0 : 1;
     if (!rc) sp->batch_cap = cfg->batch_cap;
@@ -1585,7 +1583,7 @@ __global__ void k_arena_collect(GamesDev gm, uint8_t* actions, int8_t* players, 
 }
 
 OZ_API int oz_arena_create(oz_arena** out, int n, int num_games, int sims, double c, int q_mode, uint64_t seed,
-                           uint64_t first_game_id, oz_net* net_a, oz_net* net_b, int node_cap, int edge_cap) {
+                           uint64_t first_game_id, oz_net* net_a, oz_net* net_b, int node_cap) {
     OZ_REQUIRE(out && (net_a || net_b), "null argument (at most one of the two networks may be NULL = RandomOthelloAgent)");
     OZ_REQUIRE(sims >= 2, "num_simulations must be >= 2");
     OZ_REQUIRE((!net_a || net_a->n == n) && (!net_b || net_b->n == n), "network board size mismatch");
@@ -1595,12 +1593,11 @@ OZ_API int oz_arena_create(oz_arena** out, int n, int num_games, int sims, doubl
     const int max_plies = n * n - 4;
     // each agent searches only on its own turns: about half the plies
     const int ncap = node_cap > 0 ? node_cap : sims * (max_plies / 2 + 2) + 64;
-    const int ecap = edge_cap > 0 ? edge_cap : ncap * 14;
     oz_selfplay* sp = &a->games;
     memset(&sp->cfg, 0, sizeof sp->cfg);
     sp->cfg.n = n; sp->cfg.num_games = num_games; sp->cfg.sims = sims; sp->cfg.c = c; sp->cfg.q_mode = q_mode; sp->cfg.seed = seed;
-    int rc = mcts_create(&sp->m, n, num_games, ncap, ecap, c, q_mode);
-    if (!rc) rc = mcts_create(&a->mb, n, num_games, ncap, ecap, c, q_mode);
+    int rc = mcts_create(&sp->m, n, num_games, ncap, c, q_mode);
+    if (!rc) rc = mcts_create(&a->mb, n, num_games, ncap, c, q_mode);
     if (!rc) rc = games_alloc(sp, num_games, n, (long long)num_games * 64);
     if (!rc) {
         sp->gm.seed = seed; sp->gm.id_stride = 0; sp->gm.temperature = 0; sp->gm.e_greedy = 1.0; sp->gm.refill = 0;

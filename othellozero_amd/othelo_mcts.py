@@ -18,7 +18,7 @@ from .Othello import OthelloGame, OthelloPlayer
 
 class OthelloMCTS:
     def __init__(self, board_size, neural_network, degree_exploration, q_mode=_lib.QMODE_F64,
-                 node_cap=8192, edge_cap=None):
+                 node_cap=8192):
         """q_mode: OZ_QMODE_F64 = the NumPy 1.18.5 promotion the reference pins (requirements.txt:19),
         OZ_QMODE_NEP50 = what NumPy >= 2 computes (SURVEY.md R-FP)."""
         self._board_size = board_size
@@ -30,8 +30,7 @@ class OthelloMCTS:
         self._node_cap = node_cap
         self._h = C.c_void_p()
         lib = _lib.require_gpu()
-        _lib.check(lib.oz_mcts_create(C.byref(self._h), board_size, 1, node_cap, edge_cap or node_cap * 16,
-                                      float(degree_exploration), q_mode))
+        _lib.check(lib.oz_mcts_create(C.byref(self._h), board_size, 1, node_cap, float(degree_exploration), q_mode))
         self._native = getattr(neural_network, "_h", None) is not None
         self._root = None
 

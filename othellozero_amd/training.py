@@ -114,7 +114,7 @@ class SelfPlayEngine:
 
     def __init__(self, neural_network, board_size=8, num_games=4096, num_simulations=100, degree_exploration=1.0,
                  policy_temperature=1.0, e_greedy=0.9, seed=1234, first_game_id=0, game_id_stride=0,
-                 q_mode=_lib.QMODE_F64, refill=False, node_cap=0, edge_cap=0, record_cap=0, dedup=True, batch_cap=0, eval_cache=False):
+                 q_mode=_lib.QMODE_F64, refill=False, node_cap=0, record_cap=0, dedup=True, batch_cap=0, eval_cache=False):
         """dedup: cross-game leaf de-duplication (a board several games reach in one batch is evaluated once; no record changes);
         batch_cap: leaves per network batch of the free-running driver (0 = none; see preferred_batch_cap);
         eval_cache: take (pi, v) of boards the network has evaluated before from its persistent cache (NNetWrapper.set_eval_cache) --
@@ -125,7 +125,7 @@ class SelfPlayEngine:
         self.cfg = _lib.SelfplayConfig(
             n=board_size, num_games=num_games, sims=num_simulations, q_mode=q_mode, c=float(degree_exploration),
             temperature=float(policy_temperature), e_greedy=float(e_greedy), seed=seed, first_game_id=first_game_id,
-            game_id_stride=game_id_stride, refill=1 if refill else 0, node_cap=node_cap, edge_cap=edge_cap,
+            game_id_stride=game_id_stride, refill=1 if refill else 0, node_cap=node_cap,
             record_cap=record_cap, dedup=_lib.DEDUP_ON if dedup else _lib.DEDUP_OFF, batch_cap=int(batch_cap),
             eval_cache=1 if eval_cache else 0)
         self._h = C.c_void_p()

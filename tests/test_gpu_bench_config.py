@@ -143,23 +143,27 @@ def test_network_at_the_timed_shape_vs_float64_oracle(oz, precision):
     assert tail <= TOL
 
 
-def test_config5_real_networks_bounded_plies_vs_oracle(oz):
+def test_config5_real_networks_whole_games_vs_oracle(oz):
     """bench.py's config5 leg (BASELINE configs[4] with REAL networks): 512 arena games x 800 sims per move and agent on two 512-filter
-    networks (seeds 0 / 1), bounded to 3 plies; two sampled games replayed by the oracle's arena (agents.py:44-84 restated) fed with
-    the GPU networks' own (pi, v): actions, movers and boards bit-exact"""
+    networks (seeds 0 / 1), every game played TO THE END; two sampled WHOLE games are replayed by the oracle's arena (agents.py:44-84
+    restated) fed with the GPU networks' own (pi, v): actions, movers, boards, winner and points bit-exact"""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("oz_bench", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    out = bench.config5_arena(C, "f16x2", plies=3)
-    assert out["sample_mismatches"] == 0 and out["sample_games_replayed_by_oracle"] == 2
-    assert out["moves"] == 512 * 3 and out["simulations"] == 512 * 3 * 800 and out["expansions"] > 0.8 * out["simulations"]
+    out = bench.config5_arena(C, "f16x2")
+    assert "plies_per_game" not in out and out["games_finished"] == 512 and out["games_per_s"] > 0
+    assert out["sample_mismatches"] == 0 and out["sample_games_replayed_by_oracle"] == 2 and out["sample_plies_replayed"] >= 2 * 50
+    assert 512 * 50 <= out["moves"] <= 512 * 62 and out["simulations"] == out["moves"] * 800 and out["expansions"] > 0.7 * out["simulations"]
     assert out["sims_per_s"] > 0 and out["value"] > 0
-    # the leg's headline evaluates every expansion by itself; the library default shares boards between the games of a step -- same games
+    # the leg's headline evaluates every expansion by itself; the library default shares boards between the games of a step -- same moves
     assert out["leaves_evaluated"] == out["expansions"]
-    assert out["with_cross_game_dedup"]["identical_games"] and out["with_cross_game_dedup"]["leaves_evaluated"] < out["expansions"]
+    assert out["with_cross_game_dedup"]["identical_moves_on_those_plies"]
+    # the bounded form (quick looks) still says that it is bounded
+    short = bench.config5_arena(C, "f16x2", plies=3, sample=1)
+    assert short["plies_per_game"] == 3 and short["moves"] == 512 * 3 and short["sample_mismatches"] == 0 and "games_per_s" not in short
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "f32"])

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     bound = set(_lib.SIGNATURES) | {"oz_last_error"}
     assert declared == bound, (declared ^ bound)
-    assert lib.oz_version() >= 100
+    assert lib.oz_version() >= 200                  # 200: the dead edge_cap arguments left the ABI
 
 
 def test_missing_library_fails_loudly(tmp_path):
@@ -238,6 +238,58 @@ def test_gloo_world_size_2_record_pooling(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=180)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {rank}" in out, out
+
+
+GLOO8_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from othellozero_amd._lib import RECORD_DTYPE
+from othellozero_amd.distributed import gather_records, records_to_tensor, tensor_to_records, shard_games
+rank, world = int(os.environ["RANK"]), 8
+dist.init_process_group("gloo", rank=rank, world_size=world)
+# ragged and empty ranks: rank r contributes COUNTS[r] records; ranks 2 and 5 none, rank 7 far more than the others
+COUNTS = [3, 40, 0, 7, 1, 0, 12, 200]
+def records_of(r):
+    rec = np.zeros(COUNTS[r], dtype=RECORD_DTYPE)
+    rec["game_id"] = 1000 * r + np.arange(COUNTS[r]) // 5
+    rec["ply"] = np.arange(COUNTS[r]) % 5
+    rec["black"] = 7 * r + np.arange(COUNTS[r])
+    rec["z"] = 1 - 2 * (np.arange(COUNTS[r]) & 1)
+    return rec
+pooled = tensor_to_records(gather_records(records_to_tensor(records_of(rank))))
+want = np.concatenate([records_of(r) for r in range(world)])             # rank order, every rank's own order kept
+assert pooled.size == sum(COUNTS) and pooled.tobytes() == want.tobytes(), (rank, pooled.size)
+# every rank empty: still a collective, still fine
+none = tensor_to_records(gather_records(records_to_tensor(records_of(2))))
+assert none.size == 0
+# only the LAST rank has records
+last = tensor_to_records(gather_records(records_to_tensor(records_of(7) if rank == 7 else records_of(2))))
+assert last.tobytes() == records_of(7).tobytes()
+# the 8-way split of a job's game ids: contiguous blocks that cover [0, total) exactly once, ragged and with fewer games than ranks
+for total in (32768, 4096, 13, 5, 0):
+    blocks = [shard_games(total, r, world) for r in range(world)]
+    assert blocks[0][0] == 0 and sum(c for _, c in blocks) == total
+    assert all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+    assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+dist.barrier()
+print("RANK_OK", rank)
+"""
+
+
+def test_gloo_world_size_8_ragged_and_empty_ranks(tmp_path):
+    """the exchange step 8 ways (BASELINE configs[2]'s rank count; workers.py:180-184 replaced by one all-gather): ragged contributions,
+    empty ranks in the middle, everybody empty, only the last rank non-empty -- pooled == concatenation in rank order on every rank"""
+    script = tmp_path / "gloo8_worker.py"
+    script.write_text(GLOO8_WORKER)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(8):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {rank}" in out, out
 
