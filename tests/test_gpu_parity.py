@@ -531,6 +531,28 @@ def test_f16x2_range_guards_fail_loudly(oz):
         NNetWrapper((8, 8), num_channels_1=128, precision="f16x2")       # needs channels % 256 == 0
 
 
+def test_precision_can_be_switched_on_a_live_network(oz):
+    """oz_net_set_precision + oz_net_commit on ONE network object, f32 -> f16x2 -> f32 -> f16x2: every commit rebuilds that precision's
+    images (scales, tables, the self-check's fp32 copies) and the outputs are bit for bit those of a fresh network of the same precision"""
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.weights import init_weights
+    n, C_ = 6, 256
+    w = init_weights(n, seed=8, channels=C_, randomize_all=True)
+    own, opp = _boards(n, 20, seed=2)
+    fresh = {p: NNetWrapper((n, n), num_channels_1=C_, max_batch=32, weights=w, precision=p).predict_batch(own, opp) for p in ("f32", "f16x2")}
+    net = NNetWrapper((n, n), num_channels_1=C_, max_batch=32, weights=w, precision="f32")
+    lib = oz.load()
+    assert net.self_check()[2] == 0                            # no self-check in exact fp32
+    for p in ("f32", "f16x2", "f32", "f16x2"):
+        oz.check(lib.oz_net_set_precision(net._h, {"f32": 0, "f16x2": 1}[p]))
+        net.precision = p
+        net.commit()
+        pi, v = net.predict_batch(own, opp)
+        assert np.array_equal(pi, fresh[p][0]) and np.array_equal(v, fresh[p][1]), p
+    dpi, dv, npos = net.self_check()
+    assert 0 <= dpi <= 8e-6 and 0 <= dv <= 8e-6 and npos == 64
+
+
 def _rescaled(w, case, C_):
     """badly scaled but EQUIVALENT (or at least well-posed) parameterisations of the network `w`"""
     w = [a.copy() for a in w]
