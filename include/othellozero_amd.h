@@ -117,7 +117,10 @@ int oz_net_set_tables(oz_net* net, int mode);
  * power of two of 4-way buckets; n*n + 6 words per entry; 0 frees it).  The generalisation of the reference's per-search
  * `_predict_cache` (othelo_mcts.py:13,82-88: one dict per OthelloMCTS instance) to every self-play engine that is created with
  * oz_selfplay_config.eval_cache = 1 on this network -- across batches, games and refilled slots.  A hit changes no bit of any result
- * (a position's (pi, v) is independent of the batch it is evaluated in); the cache is emptied by oz_net_commit (new weights). */
+ * (a position's (pi, v) is independent of the batch it is evaluated in); the cache is emptied by oz_net_commit (new weights) and by an
+ * oz_net_set_tables that changes the form of conv1 / conv2 (the table form adds conv2's products in another order than the GEMM forms).
+ * Engines that share a cached network may run one after the other (a second engine starts warm) but NOT concurrently: their enqueues are
+ * serialised by the network's mutex, their streams are not, and an entry one engine replaces could be read half-written by the other. */
 int oz_net_set_eval_cache(oz_net* net, int64_t entries);
 int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int64_t* hits, int64_t* inserts);
 /* diagnostics switch, per network (default 0): the 3x3 convolutions of precision f16x2 on the one-barrier-per-k-tile main loop instead of

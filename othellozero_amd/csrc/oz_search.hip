@@ -328,9 +328,15 @@ __global__ __launch_bounds__(256) void k_cache_insert(MctsDev t) {
         mine = __shfl(mine, 0, 64);
     }
     if (!mine) return;
+    // the key goes LAST, behind a fence: a lookup of another stream that sees the key sees the whole (pi, v) of THIS insert.  (That covers an
+    // entry being filled; an entry being REPLACED while another engine's k_cache_copy reads it is not covered -- engines that share a cached
+    // network must not run concurrently, see oz_net_set_eval_cache in the header.)
+    if (lane == 0) { t.ec.keys[entry * 2] = 0; t.ec.keys[entry * 2 + 1] = 0; }
+    __threadfence();
     if (lane < t.n2) t.ec.pi[entry * t.n2 + lane] = t.pi[(size_t)slot * t.n2 + lane];
+    if (lane == 0) t.ec.v[entry] = t.v[slot];
+    __threadfence();
     if (lane == 0) {
-        t.ec.v[entry] = t.v[slot];
         t.ec.keys[entry * 2] = own; t.ec.keys[entry * 2 + 1] = opp;
         atomicAdd(&t.ec.counters[2], 1ULL);
     }

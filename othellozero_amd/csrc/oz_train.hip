@@ -563,6 +563,12 @@ __global__ __launch_bounds__(256) void k_t_dgrad_operand(const float* __restrict
 // inverse powers ride in the GEMM's per-column scale, so scaling itself changes no bit.  Small elements of a gradient tensor
 // (below 2^-11 of its maximum) lose relative precision in the second plane -- an absolute error of 2^-37 of the tensor's
 // maximum, far below the fp32 rounding of the sums they enter.  Activations are post-ReLU values < 65504 (sticky flag otherwise).
+// Where in the fp16 window the per-step scales put a tensor's maximum: 2^9 .. 2^10 for the weights, 2^13 for the data gradients.  The inference path
+// moved its maxima to 2^-2 in round 4 (fewer residual bits for small elements = a higher sustained clock, tools/target_probe.py); that is NOT copied here:
+// these scales are per TENSOR, and a gradient tensor's elements lie many binary orders below its maximum -- at a maximum of 2^-2 an element 2^-10 of it
+// would keep 13 bits, at 2^13 it keeps all 22.
+#define T_W_TARGET 1000.0f
+#define T_DZ_TARGET 8192.0f
 typedef _Float16 t_f16x8 __attribute__((ext_vector_type(8)));
 struct AbsMaxArgs { const float* p[3]; long long n[3]; };
 // out[l] = bits of max |p[l][i]| (non-negative floats order like their bit patterns); out is zeroed by the caller
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(256) void k_t_w_to_h2(const float* __restrict__ W, 
     if (DGRAD) { grp = (int)(idx % ng); nrow = (int)(idx / ng); }
     else { nrow = (int)(idx % N); grp = (int)(idx / N); }
     if (idx >= (long long)N * ng) return;
-    const int kexp = t_exp_for(*wmax, 1000.0f);
+    const int kexp = t_exp_for(*wmax, T_W_TARGET);
     if (idx == 0 && t_bad_max(*wmax)) atomicOr(flag, 2);
     const int kp = grp * 8, tile = kp >> 5, c32 = kp & 31, slice = tile / 9, tap = tile - slice * 9, ch = slice * 32 + c32;
     float v[8];
@@ -646,9 +652,9 @@ __global__ __launch_bounds__(256) void k_t_dz_to_h2(const float* __restrict__ dz
                                                     uint4* __restrict__ out, float* __restrict__ dscale, int ncols, int* __restrict__ flag) {
     const int cg = C >> 3, P = Hout * Hout;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, m = idx / cg;
-    const int ez = t_exp_for(*dzmax, 8192.0f);
+    const int ez = t_exp_for(*dzmax, T_DZ_TARGET);
     if (idx == 0 && (t_bad_max(*dzmax) || t_bad_max(*wmax))) atomicOr(flag, 2);
-    if (idx < ncols) dscale[idx] = ldexpf(1.0f, -(ez + t_exp_for(*wmax, 1000.0f)));
+    if (idx < ncols) dscale[idx] = ldexpf(1.0f, -(ez + t_exp_for(*wmax, T_W_TARGET)));
     if (m >= (long long)(*d_count) * P) return;
     const int g8 = (int)(idx % cg), b = (int)(m / P), pix = (int)(m % P);
     const size_t row = ((size_t)b * Hz + pix / Hout + zoff) * Hz + pix % Hout + zoff;
@@ -722,7 +728,7 @@ __global__ __launch_bounds__(256) void k_t_z_octets(const float* __restrict__ dz
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0 && t_bad_max(*dzmax)) atomicOr(flag, 2);
     if (idx >= (long long)noct * Hout * WH_ZW * C4) return;
-    const int ez = t_exp_for(*dzmax, 8192.0f);
+    const int ez = t_exp_for(*dzmax, T_DZ_TARGET);
     const int ch = (int)(idx % C4) * 4;
     const long long cell = idx / C4;
     const int c = (int)(cell % WH_ZW), r = (int)((cell / WH_ZW) % Hout), oct = (int)(cell / ((long long)WH_ZW * Hout));
@@ -815,7 +821,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_h2(const uint4* __restrict__ X
         }
     }
     // C/D layout of the 16 x 16 MFMA: col = lane & 15 (co), row = (lane >> 4) * 4 + reg (ci)
-    const float sc = ldexpf(1.0f, -t_exp_for(*dzmax, 8192.0f));
+    const float sc = ldexpf(1.0f, -t_exp_for(*dzmax, T_DZ_TARGET));
     float* __restrict__ outp = msplit > 1 ? partial + (size_t)blockIdx.y * slab : dW;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
