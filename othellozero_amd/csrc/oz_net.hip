@@ -184,20 +184,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
         if (kt + 1 < nk) gload(kt + 1);
         const float* At = &lds[buf][0][(wm * 64 + r32) * GM_LDS_STRIDE + half * 4];
         const float* Bt = &lds[buf][1][(wn * 64 + r32) * GM_LDS_STRIDE + half * 4];
+        // fragments double-buffered in registers: the four ds_read_b128 of step s + 1 are issued BEFORE the 16 MFMAs of step s (the block has
+        // registers to spare at 2 blocks per CU), so their LDS latency hides under 1024 cycles of matrix work instead of sitting between the
+        // steps (round 4: the compiler issued them after 30 of a pair's 32 MFMAs and waited)
+        f32x4 fa0[2], fa1[2], fb0[2], fb1[2];
+        auto ldfrag = [&](int s, int w) {
+            fa0[w] = *reinterpret_cast<const f32x4*>(At + s * 8);
+            fa1[w] = *reinterpret_cast<const f32x4*>(At + 32 * GM_LDS_STRIDE + s * 8);
+            fb0[w] = *reinterpret_cast<const f32x4*>(Bt + s * 8);
+            fb1[w] = *reinterpret_cast<const f32x4*>(Bt + 32 * GM_LDS_STRIDE + s * 8);
+        };
+        ldfrag(0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             // lane (r, half) holds k = 8s + 4*half + {0..3}: MFMA j pairs k = 8s+j (half 0) with 8s+4+j (half 1)
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(At + s * 8);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(At + 32 * GM_LDS_STRIDE + s * 8);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bt + s * 8);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bt + 32 * GM_LDS_STRIDE + s * 8);
+            const int w = s & 1;
+            if (s < 3) ldfrag(s + 1, w ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b1[q], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b0[q], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b1[q], acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[w][q], fb0[w][q], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[w][q], fb1[w][q], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[w][q], fb0[w][q], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[w][q], fb1[w][q], acc[1][1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
@@ -648,7 +659,8 @@ struct OnnNet : oz_net {
     float *d_scale[6] = {}, *d_shift[6] = {};
     float *d_wpi = nullptr, *d_bpi = nullptr, *d_wv = nullptr, *d_bv = nullptr;
     float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *act4 = nullptr, *f1 = nullptr, *f2 = nullptr;
-    // precision 1 ("f32 via 2 x fp16 split", oz_net_h2.h): conv2..4 weights in the h2 layout, pre-scaled by 2^kexp
+    // precision 1 ("f32 via 2 x fp16 split", oz_net_h2.h): conv2..4, fc1, fc2 weights in the h2 layout, column c scaled by 2^wexp[c] and row k by
+    // 2^-aexp[channel of k] (commit_h2); d_scale_h2 / d_shift_h2 carry the inverse powers and the output tensor's exponents
     int precision = 0;
     uint4* d_wh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // conv2..4, fc1, fc2
     float* d_scale_h2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -836,7 +848,7 @@ struct OnnNet : oz_net {
         return lo;
     }
 
-    // T2[t] = table . W_t^T (raw k-sums, scaled 2^kexp like the convolution's): nine GEMMs M = OZ_LUT_PATTERNS, K = N = C
+    // T2[t] = table . W_t^T (raw k-sums, column c scaled 2^wexp[0][c] like the convolution's): nine GEMMs M = OZ_LUT_PATTERNS, K = N = C
     int build_t2() {
         // d_wtap (conv2's kernel as nine [C][C] matrices in the h2 layout, same power-of-two scale as d_wh[0]) was written by oz_net_commit
         if (!d_one) {
