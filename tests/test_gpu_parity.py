@@ -531,6 +531,43 @@ def test_f16x2_range_guards_fail_loudly(oz):
         NNetWrapper((8, 8), num_channels_1=128, precision="f16x2")       # needs channels % 256 == 0
 
 
+@pytest.mark.parametrize("n,C_", [(8, 256), (6, 512)])
+def test_network_vs_the_vendor_libraries(oz, n, C_):
+    """a FOURTH opinion on the OthelloNN arithmetic (the NN oracle cannot be pinned by TensorFlow, which is absent everywhere): the same graph
+    (Net/OthelloNN.py:42-56) through PyTorch-ROCm on this card, i.e. MIOpen convolutions, MIOpen / native batch norm and rocBLAS GEMMs in
+    float32 -- code that shares nothing with this library, the NumPy oracle, the C oracle or torch-CPU's oneDNN path.  All five agree
+    within 1e-5 on (pi, v): vendor fp32 vs the float64 oracle, this library in both precisions vs the vendor result."""
+    import torch
+    import torch.nn.functional as F
+    from othellozero_amd.NNet import NNetWrapper
+    from othellozero_amd.weights import init_weights
+    w = init_weights(n, seed=17, channels=C_, randomize_all=True)
+    for i in (36, 38):
+        w[i] = w[i] * 4.0
+    B = 40
+    own, opp = _boards(n, B, seed=9)
+    pi64, v64 = nn_numpy.forward(w, own, opp, n)
+    dev = torch.device("cuda", 0)
+    tw = [torch.from_numpy(np.asarray(a, dtype=np.float32)).to(dev) for a in w]
+    with torch.no_grad():
+        x = torch.from_numpy(nn_numpy.planes(own, opp, n, dtype=np.float32)).to(dev).permute(0, 3, 1, 2).contiguous()      # NCHW
+        for layer, pad in enumerate((1, 1, 0, 0)):
+            k, bias, g, b, mu, var = tw[6 * layer:6 * layer + 6]
+            x = F.conv2d(x, k.permute(3, 2, 0, 1).contiguous(), bias, padding=pad)
+            x = F.batch_norm(x, mu, var, g, b, training=False, eps=1e-3).relu()
+        x = x.permute(0, 2, 3, 1).reshape(B, -1)                                                                              # keras Flatten of NHWC
+        for layer in (4, 5):
+            k, bias, g, b, mu, var = tw[6 * layer:6 * layer + 6]
+            x = F.batch_norm(x @ k + bias, mu, var, g, b, training=False, eps=1e-3).relu()
+        pit = torch.softmax(x @ tw[36] + tw[37], dim=1).cpu().numpy().astype(np.float64)
+        vt = torch.tanh(x @ tw[38] + tw[39])[:, 0].cpu().numpy().astype(np.float64)
+    assert np.abs(pit - pi64).max() <= 1e-5 and np.abs(vt - v64).max() <= 1e-5
+    for precision in ("f32", "f16x2"):
+        net = NNetWrapper((n, n), num_channels_1=C_, max_batch=64, weights=w, precision=precision)
+        pi, v = net.predict_batch(own, opp)
+        assert np.abs(pi.reshape(B, -1) - pit).max() <= 1e-5 and np.abs(v - vt).max() <= 1e-5, precision
+
+
 def test_precision_can_be_switched_on_a_live_network(oz):
     """oz_net_set_precision + oz_net_commit on ONE network object, f32 -> f16x2 -> f32 -> f16x2: every commit rebuilds that precision's
     images (scales, tables, the self-check's fp32 copies) and the outputs are bit for bit those of a fresh network of the same precision"""
