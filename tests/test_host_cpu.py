@@ -55,6 +55,25 @@ def test_product_never_imports_oracle():
                 assert "liboz_oracle" not in src, f
 
 
+def test_bench_uses_the_oracle_only_as_checker_and_cpu_baseline():
+    """bench.py (launcher + timed region) never imports the oracle; bench_legs.py imports it only inside the legs that ARE the checker or the
+    CPU baseline (cpu_baseline*, parity_sample, config5_arena's replay, dropin_config0's CPU port) -- never at module level, never in run_secondary"""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert not re.search(r"^\s*(import|from)\s+oracle", src, flags=re.M)
+    tree = ast.parse(open(os.path.join(ROOT, "bench_legs.py")).read())
+    allowed = {"cpu_baseline", "cpu_baseline_config", "parity_sample", "config5_arena", "dropin_config0", "host_threads"}
+    for node in tree.body:
+        names = []
+        for sub in ast.walk(node):
+            if isinstance(sub, ast.Import):
+                names += [a.name.split(".")[0] for a in sub.names]
+            elif isinstance(sub, ast.ImportFrom) and sub.module:
+                names.append(sub.module.split(".")[0])
+        if "oracle" in names:
+            assert isinstance(node, ast.FunctionDef) and node.name in allowed, getattr(node, "name", type(node).__name__)
+
+
 def test_record_dtype_and_pack_roundtrip():
     from othellozero_amd import _lib
     assert _lib.RECORD_DTYPE.itemsize == 48
