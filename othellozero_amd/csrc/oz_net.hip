@@ -200,6 +200,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
             // lane (r, half) holds k = 8s + 4*half + {0..3}: MFMA j pairs k = 8s+j (half 0) with 8s+4+j (half 1)
             const int w = s & 1;
             if (s < 3) ldfrag(s + 1, w ^ 1);
+            // the next tile's registers go to LDS in the MIDDLE of this tile's matrix work (the loads were issued 2000 cycles ago; the other buffer
+            // has not been read since the last barrier): at the closing barrier nothing is left to wait for but the other waves
+            if (s == 2 && kt + 1 < nk) lstore(buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -210,7 +213,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
