@@ -77,48 +77,68 @@ __device__ float g_gm_zero_line[32];          // 128 B of zeros: the source of t
 
 
 // out[M][N] = act((A[M][K] . Wt[N][K]^T) * scale + shift), M = *d_count * Hout^2, rows (b, oy, ox)
-__global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ in, const float* __restrict__ Wt,
-                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                     float* __restrict__ out, const int* __restrict__ d_count,
-                                                     GemmGeom g, int num_mt, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][GM_BM * GM_LDS_STRIDE];   // [buf][A|B][row][k]
-    // XCD-aware tile order: the N/128 column tiles of one row tile run on the same XCD (ids b, b+8 share an L2)
-    const int nnt = g.N / GM_BN;
+// Tile configurations (round 4): waves in NWM x NWN, every wave TI x TJ MFMA tiles of 32 x 32.
+//   GmStd  2 x 2 waves of 64 x 64   -> block 128 x 128, 256 threads, 64 KB of LDS, two blocks per CU: every layer, every mode (pixel-major
+//          tiles, split-K, the trainer's gradients)
+//   GmBig  2 x 4 waves of 128 x 64  -> block 256 x 256, 512 threads, 128 KB of LDS, one block per CU: the 3x3 convolutions of large batches --
+//          half the operand bytes per MFMA (the ablations put 13 % of a launch on the operand loads themselves), same sums in the same order
+template <int NWM_, int NWN_, int TI_, int TJ_, int OCC_> struct GmCfg {
+    static constexpr int NWM = NWM_, NWN = NWN_, TI = TI_, TJ = TJ_, OCC = OCC_;
+    static constexpr int BM = NWM * TI * 32, BN = NWN * TJ * 32, NT = NWM * NWN * 64, RPP = NT / 8;      // RPP: rows staged per pass of the block
+    static constexpr int IA = BM / RPP, IB = BN / RPP;
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * GM_LDS_STRIDE * 4;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile shape");
+};
+typedef GmCfg<2, 2, 2, 2, 2> GmStd;
+typedef GmCfg<2, 4, 4, 2, 1> GmBig;
+static_assert(GmStd::BM == GM_BM && GmStd::BN == GM_BN, "GM_BM / GM_BN describe the standard tile");
+
+template <typename CF>
+__global__ __launch_bounds__(CF::NT, CF::OCC) void k_gemm_f32(const float* __restrict__ in, const float* __restrict__ Wt,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float* __restrict__ out, const int* __restrict__ d_count,
+                                                              GemmGeom g, int num_mt, float* __restrict__ partial) {
+    constexpr int BM = CF::BM, BN = CF::BN, IA = CF::IA, IB = CF::IB, RPP = CF::RPP, TI = CF::TI, TJ = CF::TJ;
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];                       // [buf][A rows | B rows][32 floats]
+    auto tileA = [&](int buf) -> float* { return lds_dyn + (size_t)buf * (BM + BN) * GM_LDS_STRIDE; };
+    auto tileB = [&](int buf) -> float* { return lds_dyn + ((size_t)buf * (BM + BN) + BM) * GM_LDS_STRIDE; };
+    // XCD-aware tile order: the N/BN column tiles of one row tile run on the same XCD (ids b, b+8 share an L2)
+    const int nnt = g.N / BN;
     const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
     const int mt = (j / nnt) * 8 + xcd, nt = j % nnt;
     const int P = g.Hout * g.Hout;
     const int count = *d_count;
     const long long M = (long long)count * P;
-    // row r of tile mt -> (board, output pixel): board-major (b, oy, ox) rows, or one pixel of 128 consecutive boards
+    // row r of tile mt -> (board, output pixel): board-major (b, oy, ox) rows, or one pixel of BM consecutive boards
     int tile_pix = 0, tile_b0 = 0;
     if (g.pixmajor) {
         // tile mt = (pixel, board group) with the GROUP minor: workgroup ids go round-robin over the 8 XCDs, so an XCD sees every
         // pixel of its board groups -- border pixels (few taps) and interior pixels (all nine) in the same mix on every XCD
         // (pixel-minor order put one board COLUMN on each XCD: the two border columns idled while six XCDs did the work)
-        const int ngrp = (count + GM_BM - 1) / GM_BM;
+        const int ngrp = (count + BM - 1) / BM;
         if (mt >= ngrp * P) return;
-        tile_pix = mt / ngrp; tile_b0 = (mt % ngrp) * GM_BM;
-    } else if (mt >= num_mt || (long long)mt * GM_BM >= M) return;
+        tile_pix = mt / ngrp; tile_b0 = (mt % ngrp) * BM;
+    } else if (mt >= num_mt || (long long)mt * BM >= M) return;
     auto row_bp = [&](int r, int& b, int& pix) -> bool {
         if (g.pixmajor) { b = tile_b0 + r; pix = tile_pix; return b < count; }
-        const long long m = (long long)mt * GM_BM + r;
+        const long long m = (long long)mt * BM + r;
         b = (int)(m / P); pix = (int)(m % P);
         return m < M;
     };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int chunk = tid & 7, srow = tid >> 3;          // staging: row srow + 32*i, k offset chunk*4
+    const int wm = wave / CF::NWN, wn = wave % CF::NWN;
+    const int chunk = tid & 7, srow = tid >> 3;          // staging: row srow + RPP * i, k offset chunk * 4
 
     // per staged A row: base offset of input pixel (oy-pad, ox-pad) and the 9-bit tap validity mask
-    long long abase[4];
-    unsigned amask[4];
+    long long abase[IA];
+    unsigned amask[IA];
     const int chi = g.core_hi < 0 ? g.Hin : g.core_hi;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < IA; ++i) {
         int b, pix;
         abase[i] = 0; amask[i] = 0;
-        if (row_bp(srow + 32 * i, b, pix)) {
+        if (row_bp(srow + RPP * i, b, pix)) {
             const int oy = pix / g.Hout, ox = pix % g.Hout;
             abase[i] = (((long long)b * g.Hin + (oy - g.pad)) * g.Hin + (ox - g.pad)) * g.Cin;
             unsigned mk = 0;
@@ -147,37 +167,43 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
         return __builtin_ctz(m);
     };
     // Staging (round 4): global -> LDS by 16-byte LDS-DMA, no staging registers, no ds_write pass.  Thread (srow, chunk) owns LDS rows
-    // srow + 32 i, physical chunk `chunk`: a wave's instruction i fills the 8 rows 8 w + 32 i .. + 7 = 1 KB contiguous.  Physical chunk p of row r
+    // srow + RPP i, physical chunk `chunk`: a wave's instruction i fills the 8 rows 8 w + RPP i .. + 7 = 1 KB contiguous.  Physical chunk p of row r
     // holds LOGICAL chunk p ^ ((r >> 1) & 7).  A ds_read_b128 is served in 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... over
     // 64 banks = 256 B (MI355X_MICROARCH.md): with the 32x32x2 operand map (lane: row r32, k-half) a group holds 8 even and 8 odd rows, rows of one
     // parity share the 128-byte half of the bank window, and (r >> 1) & 7 is a bijection on each parity's eight rows in every group -- conflict-free
     // without padding (SQ_LDS_BANK_CONFLICT 0; the first key tried, r & 7, measured 50 % conflict cycles).  Rounds 1-3 staged through registers
     // into rows padded to 144 B.  What the change bought (tools/f32_forward_probe.py, 3640 positions): fc1 707 -> 573 us, fc2 103 -> 88 us,
-    // conv3 / conv4 -0.4 / -1 % only: the ablations put 13 % of a convolution launch on the operand loads THEMSELVES (conv3 5063 us whole, 4401
-    // without the loads, 4903 with every load a cache hit, 5082 without the fragment reads, 5242 without the barrier), not on how they are staged.
-    const int swz = chunk ^ ((srow >> 1) & 7);           // the logical chunk this thread fetches (rows srow + 32 i share the key)
+    // conv3 5063 -> 4901 us with the conflict-free key: the ablations put 13 % of a convolution launch on the operand loads THEMSELVES (conv3
+    // 5063 us whole, 4401 without the loads, 4903 with every load a cache hit, 5082 without the fragment reads, 5242 without the barrier),
+    // not on how they are staged -- hence the 256 x 256 tile for the large convolutions (half the operand bytes per MFMA).
+    const int swz = chunk ^ ((srow >> 1) & 7);           // the logical chunk this thread fetches (rows srow + RPP i share the key: RPP / 2 % 8 == 0)
+    static_assert((RPP / 2) % 8 == 0, "rows of one thread must share the swizzle key");
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const float* brow[4];
+    const float* brow[IB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) brow[i] = Wt + (size_t)(nt * GM_BN + srow + 32 * i) * g.K + swz * 4;
+    for (int i = 0; i < IB; ++i) brow[i] = Wt + (size_t)(nt * BN + srow + RPP * i) * g.K + swz * 4;
     const float* zsrc = g_gm_zero_line + swz * 4;
 
     auto stage = [&](int kt, int buf) {
         const int tap = tap_of(kt), ci0 = (kt % kpt) * GM_BK, k0 = tap * g.Cin + ci0;
         const long long toff = ((long long)(tap / 3) * g.Hin + (tap % 3)) * g.Cin + ci0 + swz * 4;
+        float* la = tileA(buf);
+        float* lb = tileB(buf);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < IA; ++i) {
             const float* ga = ((amask[i] >> tap) & 1) ? in + abase[i] + toff : zsrc;
-            __builtin_amdgcn_global_load_lds((gm_gptr)ga, (gm_lptr)&lds[buf][0][(wave_u * 8 + 32 * i) * GM_LDS_STRIDE], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gm_gptr)(brow[i] + k0), (gm_lptr)&lds[buf][1][(wave_u * 8 + 32 * i) * GM_LDS_STRIDE], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gm_gptr)ga, (gm_lptr)(la + (wave_u * 8 + RPP * i) * GM_LDS_STRIDE), 16, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < IB; ++i)
+            __builtin_amdgcn_global_load_lds((gm_gptr)(brow[i] + k0), (gm_lptr)(lb + (wave_u * 8 + RPP * i) * GM_LDS_STRIDE), 16, 0, 0);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < TJ; ++jj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
@@ -185,37 +211,37 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
     const int nk_all = g.pixmajor ? __builtin_popcount(tmask) * kpt : g.K / GM_BK, nk_s = (nk_all + g.ksplit - 1) / g.ksplit;
     const int kt0 = blockIdx.y * nk_s, nk = min(nk_all, kt0 + nk_s);
     const int r32 = lane & 31, half = lane >> 5;
-    const int key = (r32 >> 1) & 7;                      // rows r32 and r32 + 32 of a wave tile share it
+    const int key = (r32 >> 1) & 7;                      // rows r32 + 32 t of a wave tile share it
     if (kt0 < nk) stage(kt0, kt0 & 1);
     __syncthreads();                                     // drains the DMA (vmcnt(0)) and publishes the tile
     for (int kt = kt0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);         // the other buffer: every wave finished reading it before the last barrier
-        const float* At = &lds[buf][0][(wm * 64 + r32) * GM_LDS_STRIDE];
-        const float* Bt = &lds[buf][1][(wn * 64 + r32) * GM_LDS_STRIDE];
-        // fragments double-buffered in registers: the four ds_read_b128 of step s + 1 are issued BEFORE the 16 MFMAs of step s
-        f32x4 fa0[2], fa1[2], fb0[2], fb1[2];
+        const float* At = tileA(buf) + (wm * TI * 32 + r32) * GM_LDS_STRIDE;
+        const float* Bt = tileB(buf) + (wn * TJ * 32 + r32) * GM_LDS_STRIDE;
+        // fragments double-buffered in registers: the ds_read_b128 of step s + 1 are issued BEFORE the MFMAs of step s
+        f32x4 fa[2][TI], fb[2][TJ];
         auto ldfrag = [&](int s, int w) {
             const int off = ((2 * s + half) ^ key) * 4;  // lane (r, half) holds k = 8s + 4*half + {0..3}: logical chunk 2s + half of its row
-            fa0[w] = *reinterpret_cast<const f32x4*>(At + off);
-            fa1[w] = *reinterpret_cast<const f32x4*>(At + 32 * GM_LDS_STRIDE + off);
-            fb0[w] = *reinterpret_cast<const f32x4*>(Bt + off);
-            fb1[w] = *reinterpret_cast<const f32x4*>(Bt + 32 * GM_LDS_STRIDE + off);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa[w][i] = *reinterpret_cast<const f32x4*>(At + i * 32 * GM_LDS_STRIDE + off);
+#pragma unroll
+            for (int jj = 0; jj < TJ; ++jj) fb[w][jj] = *reinterpret_cast<const f32x4*>(Bt + jj * 32 * GM_LDS_STRIDE + off);
         };
         ldfrag(0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            // MFMA j pairs k = 8s+j (half 0) with 8s+4+j (half 1)
+            // MFMA q pairs k = 8s+q (half 0) with 8s+4+q (half 1)
             const int w = s & 1;
             if (s < 3) ldfrag(s + 1, w ^ 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[w][q], fb0[w][q], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[w][q], fb1[w][q], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[w][q], fb0[w][q], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[w][q], fb1[w][q], acc[1][1], 0, 0, 0);
-            }
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TJ; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[w][i][q], fb[w][jj][q], acc[i][jj], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                 // vmcnt(0): the next tile has landed; barrier: everybody is done with this one
@@ -223,15 +249,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float* __restrict__ i
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int col = nt * GM_BN + wn * 64 + jj * 32 + r32;
+    for (int jj = 0; jj < TJ; ++jj) {
+        const int col = nt * BN + wn * TJ * 32 + jj * 32 + r32;
         const float sc = scale[col], sh = shift[col];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int b, pix;
-                if (row_bp(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, b, pix)) {
+                if (row_bp(wm * TI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, b, pix)) {
                     const long long m = (long long)b * P + pix;
                     if (g.ksplit > 1) { partial[(size_t)blockIdx.y * g.slab + (size_t)m * g.N + col] = acc[i][jj][r]; continue; }
                     float v = fmaf(acc[i][jj][r], sc, sh);
@@ -379,7 +405,27 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
         while (ksplit < 16 && grid_s * ksplit < split_blocks && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * (Ms > Mmax ? Ms : Mmax) * N <= partial_floats) ksplit *= 2;
     }
     g.ksplit = ksplit; g.slab = Mmax * N;
-    hipLaunchKernelGGL(k_gemm_f32, dim3(grid, ksplit), dim3(256), 0, s, in, Wt, scale, shift, out, d_count, g, num_mt, partial);
+    {   // the dynamic-LDS limits of the two instantiations, once per device
+        static bool attr_done[64] = {};
+        int dev_now = 0;
+        OZ_HIP(hipGetDevice(&dev_now));
+        if (!attr_done[dev_now & 63]) {
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_f32<GmStd>, hipFuncAttributeMaxDynamicSharedMemorySize, GmStd::LDS_BYTES));
+            OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_f32<GmBig>, hipFuncAttributeMaxDynamicSharedMemorySize, GmBig::LDS_BYTES));
+            attr_done[dev_now & 63] = true;
+        }
+    }
+    // 3x3 convolutions that fill the chip with 256 x 256 tiles (no pixel-major skipping, no k split): the big tile -- every output element's
+    // products are added in the same order as on the standard tile (bit-identical), keyed on the call's capacity like the other choices
+    const long long big_blocks = ((Mmax + GmBig::BM - 1) / GmBig::BM) * (N / GmBig::BN);
+    if (taps == 9 && !g.pixmajor && ksplit == 1 && N % GmBig::BN == 0 && big_blocks >= 192) {
+        const int num_mt_big = (int)((Mmax + GmBig::BM - 1) / GmBig::BM);
+        const int grid_big = ((num_mt_big + 7) / 8) * 8 * (N / GmBig::BN);
+        hipLaunchKernelGGL(k_gemm_f32<GmBig>, dim3(grid_big, 1), dim3(GmBig::NT), GmBig::LDS_BYTES, s, in, Wt, scale, shift, out, d_count, g, num_mt_big, partial);
+        OZ_HIP(hipGetLastError());
+        return OZ_OK;
+    }
+    hipLaunchKernelGGL(k_gemm_f32<GmStd>, dim3(grid, ksplit), dim3(GmStd::NT), GmStd::LDS_BYTES, s, in, Wt, scale, shift, out, d_count, g, num_mt, partial);
     OZ_HIP(hipGetLastError());
     if (ksplit > 1) {
         const long long quads = (Mmax * N + 3) / 4;
