@@ -1,6 +1,6 @@
 """A/B of two builds of the library on ONE device in ONE gpurun call: per-kernel time of the f16x2 forward at the bench's launch size (3640
 positions on the max_batch = 4096 network), the same positions for both.  Each build runs in its own child process with its own package.
-    python tools/ab_forward.py <repo root A> <repo root B> [rounds]"""
+    python tools/ab_forward.py <repo root A> <repo root B> [more roots ...] [rounds]"""
 import json
 import os
 import subprocess
@@ -29,8 +29,8 @@ print("RESULT " + json.dumps({name: ms / c * 1e3 for name, (ms, c) in k.items() 
 
 
 def main():
-    roots = sys.argv[1:3]
-    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+    roots = [a for a in sys.argv[1:] if not a.isdigit()]
+    rounds = next((int(a) for a in sys.argv[1:] if a.isdigit()), 200)
     res = {}
     for rep in range(2):                      # A B A B: drift of the box shows up as a difference between the repeats
         for r in roots:
