@@ -1111,6 +1111,16 @@ def test_c_abi_exchange_step_over_rccl_on_one_rank(oz):
     more = eng.stats()["records"]
     tail, per = comm.gather_records(eng, first_record=own.size)   # only what completed since
     assert per.tolist() == [more - own.size] and tail.size == more - own.size
+    # the counts-only form (out = NULL, room 0) and the room check, which is decided from the gathered (count, room) pairs -- on every rank alike
+    lib = oz.load()
+    written, cnt = C.c_int64(), np.zeros(1, np.int64)
+    oz.check(lib.oz_selfplay_gather_records(eng._h, comm._h, 0, None, 0, C.byref(written), oz.p_i64(cnt)))
+    assert written.value == more and cnt.tolist() == [more]
+    small = np.zeros(more - 1, dtype=oz.RECORD_DTYPE)
+    rc = lib.oz_selfplay_gather_records(eng._h, comm._h, 0, small.ctypes.data_as(C.c_void_p), small.size, C.byref(written), oz.p_i64(cnt))
+    assert rc == oz.OZ_ERR_ARG and "room" in lib.oz_last_error().decode() and written.value == 0 and cnt.tolist() == [more]
+    exact, per = comm.gather_records(eng, max_records=more)       # exactly enough room
+    assert exact.size == more
     comm.close()
 
 

@@ -429,6 +429,21 @@ def test_c_host_example_plays_and_pools_records(tmp_path):
     assert r.returncode == 0 and "SELFPLAY_HOST_OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_elf_reader_sees_the_library_s_hip_dependency():
+    """_lib._elf_dynamic_strings (no external tools): the built library needs libamdhip64.so.<major>, and a HIP runtime file's SONAME has the same
+    form -- the two strings _one_hip_runtime compares before it preloads PyTorch's bundled runtime"""
+    from othellozero_amd import _lib
+    soname, needed = _lib._elf_dynamic_strings(_lib.LIB_PATH)
+    hip = [x for x in needed if x.startswith("libamdhip64.so")]
+    assert len(hip) == 1 and re.fullmatch(r"libamdhip64\.so\.\d+", hip[0]), needed
+    sys_rt = "/opt/rocm/lib/libamdhip64.so"
+    if os.path.exists(sys_rt):
+        so, _ = _lib._elf_dynamic_strings(os.path.realpath(sys_rt))
+        assert so == hip[0]                                      # the runtime it was linked against
+    with pytest.raises(ValueError):
+        _lib._elf_dynamic_strings(os.path.join(ROOT, "README.md"))
+
+
 def test_library_and_pytorch_share_one_hip_runtime():
     """PyTorch wheels bundle their own libamdhip64.so (same SONAME as the system one) and load it by path: with the library loaded first a process
     used to hold TWO HIP runtimes, whose streams / device pointers are invalid in each other (torch tensors handed to the library; RCCL's
