@@ -87,7 +87,7 @@ int oz_net_init_random(oz_net* net, uint64_t seed);
  * into the BN scale / shift and the next layer's weights: the network function is unchanged; oz_net_get_scaling reads the exponents).
  * Guards, sticky, reported as OZ_ERR_STATE by oz_net_check / predict / selfplay_sync: an activation above 65504, or a pixel row whose
  * largest activation is non-zero and 2^15 or more below its channels' calibration maxima.  oz_net_commit also runs the self-check of
- * OZ_NET_OPT_SELF_CHECK.  Needs channels % 256 == 0.  Takes effect at the next oz_net_commit. */
+ * OZ_NET_OPT_SELF_CHECK.  Needs channels % 256 == 0 and channels <= 2048.  Takes effect at the next oz_net_commit. */
 int oz_net_set_precision(oz_net* net, int mode);
 int oz_net_get_precision(const oz_net* net);
 int oz_net_check(oz_net* net);
@@ -138,14 +138,25 @@ int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int
  * rounding); 0 = off, 2 = measure only; oz_net_self_check reads what the last commit measured */
 #define OZ_NET_OPT_SELF_CHECK 4
 #define OZ_NET_OPT_W_TARGET_LOG2 5
+/* diagnostics switch, per network (default 0), precision f32: the 3x3 convolutions of large batches never take the 256 x 256 tile (GmBig) and run
+ * on the 128 x 128 one (GmStd) like every other layer.  Both tiles add every output element's products in the same order: bit-identical
+ * results -- the screen test_f32_big_tile_bit_identical_to_the_standard_tile compares them.  Takes effect at the next forward. */
+#define OZ_NET_OPT_F32_STD_TILE 6
 int oz_net_set_option(oz_net* net, int option, int value);
 int oz_net_self_check(oz_net* net, double* max_dpi, double* max_dv, int* positions);
 /* precision f16x2: the exponents chosen at the last commit.  which = 0 .. 4: per-channel activation exponents of the conv1, conv2, conv3,
  * conv4 (channels each) and fc1 (1024) outputs; which = 5 .. 9: per-column weight exponents of conv2, conv3, conv4 (channels), fc1 (1024), fc2 (512) */
 int oz_net_get_scaling(oz_net* net, int which, int32_t* out, int64_t nelem);
-/* launch facts of the last forward: OZ_NET_INFO_CONV3_TILE_ROWS = the row-tile height conv3 ran on (f16x2: 256 / 192, chosen per call from
- * the capacity the caller launches with -- 256 at bench.py's batch cap of 3640 leaves; 128 for the latency path and precision f32) */
+/* launch facts of the last forward: OZ_NET_INFO_CONV3_TILE_ROWS = the row-tile height conv3 ran on.  Precision f16x2: 256 / 192, chosen per call
+ * from the capacity the caller launches with (256 at bench.py's batch cap of 3640 leaves), 128 on the latency path (max_batch <= 32).
+ * Precision f32: what oz_gemm_f32_launch really launched -- 256 (GmBig: a 3x3 convolution whose 256 x 256 tiles fill the chip, e.g. every call
+ * of a max_batch = 4096 network), 128 (GmStd: smaller networks, or OZ_NET_OPT_F32_STD_TILE), 64 (the weight-stream kernel of layers with at
+ * most 64 rows: one-position networks). */
 #define OZ_NET_INFO_CONV3_TILE_ROWS 1
+/* precision f16x2: the guard bits (1 = an activation above the fp16 range, 4 = a low row) raised ON THE CALIBRATION POSITIONS by the self-check of the
+ * last oz_net_commit -- 0 for a healthy network.  With OZ_NET_OPT_SELF_CHECK = 1 such a commit fails; with 2 (measure only) it succeeds and this
+ * says what happened.  The device flag is cleared by the commit that reported it. */
+#define OZ_NET_INFO_SELF_CHECK_GUARD 2
 int oz_net_get_info(oz_net* net, int what, int* value);
 
 /* ------------------------------------------------------------------ search
@@ -375,6 +386,12 @@ int oz_trainer_step_count(oz_trainer* t, int64_t* step);
  * comparison with the host: sqrt(a), a/b in float64; a/b and (a*b+a)/b in float32 (no FMA contraction). */
 int oz_selftest_arith(const double* a, const double* b, int count, double* sqrt_a, double* div_ab, float* fdiv_ab,
                       float* fchain);
+/* what the matrix pipe of the current device sustains right now: a pure-MFMA loop (no LDS, no loads, no barriers, one wave per SIMD) for
+ * about target_ms milliseconds.  kind 0 = v_mfma_f32_32x32x2_f32 (precision f32's instruction), 1 = v_mfma_f32_16x16x32_f16 on operands with
+ * busy mantissas (precision f16x2's).  tflops = issued FLOP / HIP-event time; clock_ghz (optional) = the clock at which back-to-back issue
+ * gives that rate; ms_measured (optional).  bench.py reports both kinds as `device_calibration`: the number that separates a slow or
+ * power-capped box from a regression of the kernels. */
+int oz_selftest_mfma_rate(int kind, double target_ms, double* tflops, double* clock_ghz, double* ms_measured);
 
 #ifdef __cplusplus
 }

@@ -65,7 +65,12 @@ class NNetWrapper(_NetHandle):
                          init_weights(self.board_size_x, seed, self.num_channels, in_channels=self.in_channels))
 
     # ---- weights (model.get_weights / set_weights, Net/NNet.py:98-101)
-    def set_weights(self, weights):
+    def set_weights(self, weights, on_refusal="raise"):
+        """model.set_weights + oz_net_commit.  Precision f16x2 may REFUSE a network at commit (OZ_ERR_STATE: a guard fired on the calibration
+        positions, or the self-check against the exact-fp32 kernels measured more than 8e-6).  on_refusal="raise" (default): the OzError
+        propagates -- callers that load arbitrary weights decide themselves.  on_refusal="f32": the wrapper warns, switches THIS network to
+        precision f32 (exact fp32 kernels on the GPU, always valid) and commits again -- what train() uses, so that a long f16x2 run is not
+        ended by the weights of one iteration."""
         lib = _lib.load()
         shapes = onn_shapes(self.board_size_x, self.num_channels, self.in_channels)
         assert len(weights) == len(shapes), f"expected {len(shapes)} arrays"
@@ -73,7 +78,16 @@ class NNetWrapper(_NetHandle):
             a = np.ascontiguousarray(w, dtype=np.float32)
             assert a.shape == tuple(shp), f"weight {i}: shape {a.shape} != {shp}"
             _lib.check(lib.oz_net_set_weight(self._h, i, _lib.p_f32(a), a.size))
-        _lib.check(lib.oz_net_commit(self._h))
+        try:
+            _lib.check(lib.oz_net_commit(self._h))
+        except _lib.OzError as e:
+            if not (on_refusal == "f32" and e.code == _lib.OZ_ERR_STATE and self.precision == "f16x2"):
+                raise
+            import warnings
+            warnings.warn(f"othellozero_amd: precision f16x2 refused these weights at commit ({e}); this network continues in precision f32")
+            _lib.check(lib.oz_net_set_precision(self._h, 0))
+            self.precision = "f32"
+            _lib.check(lib.oz_net_commit(self._h))
 
     def init_random(self, seed):
         """a fresh network as Keras initialises it (glorot_uniform kernels, zero biases, identity BatchNormalization) from the LIBRARY's own
@@ -145,7 +159,7 @@ class NNetWrapper(_NetHandle):
         if allreduce is not None:                       # BN moving statistics are per replica: average them
             from .distributed import average_moving_statistics
             weights = average_moving_statistics(weights, getattr(allreduce, "group", None))
-        self.set_weights(weights)
+        self.set_weights(weights, on_refusal="f32")
         return hist
 
     # ---- checkpoints (Net/NNet.py:90-96): Keras HDF5 weight files, read and written by keras_h5.py (no h5py needed);
@@ -223,7 +237,8 @@ class NNetWrapper(_NetHandle):
     def set_option(self, option, value):
         """switches (_lib.NET_OPT_*): NET_OPT_SIMPLE_LOOP = the one-barrier conv loop the race screen compares against; precision f16x2, effective
         at the next commit(): NET_OPT_ACT_TARGET_LOG2 / NET_OPT_W_TARGET_LOG2 (calibration / column maxima land below 2^value, default -2),
-        NET_OPT_LOW_GUARD_LOG2 (row threshold of the low-side guard, default -17; <= -100 = off), NET_OPT_SELF_CHECK (0 off, 1 enforce, 2 measure)"""
+        NET_OPT_LOW_GUARD_LOG2 (row threshold of the low-side guard, default -17; <= -100 = off), NET_OPT_SELF_CHECK (0 off, 1 enforce, 2 measure);
+        precision f32: NET_OPT_F32_STD_TILE = the 3x3 convolutions on the 128 x 128 tile even where the 256 x 256 one would be picked (bit-identical)"""
         _lib.check(_lib.load().oz_net_set_option(self._h, int(option), int(value)))
 
     def commit(self):
@@ -246,8 +261,16 @@ class NNetWrapper(_NetHandle):
         _lib.check(_lib.load().oz_net_self_check(self._h, C.byref(a), C.byref(b), C.byref(k)))
         return a.value, b.value, k.value
 
+    def self_check_guard(self):
+        """precision f16x2: the guard bits (1 = above the fp16 range, 4 = a low row) the last commit's self-check saw on the calibration positions
+        (0 = none; with NET_OPT_SELF_CHECK = 2 the commit succeeds and this is how a caller learns of them)"""
+        v = C.c_int()
+        _lib.check(_lib.load().oz_net_get_info(self._h, _lib.NET_INFO_SELF_CHECK_GUARD, C.byref(v)))
+        return v.value
+
     def conv3_tile_rows(self):
-        """row-tile height the LAST forward ran conv3 on (f16x2: 256 at bench.py's batch cap, 192 for full 4096-leaf launches)"""
+        """row-tile height the LAST forward ran conv3 on (f16x2: 256 at bench.py's batch cap, 192 for full 4096-leaf launches, 128 on the latency path;
+        f32: 256 = the 256 x 256 tile of large batches, 128 = the standard tile, 64 = the weight-stream kernel of one-position networks)"""
         v = C.c_int()
         _lib.check(_lib.load().oz_net_get_info(self._h, _lib.NET_INFO_CONV3_TILE_ROWS, C.byref(v)))
         return v.value

@@ -15,8 +15,8 @@ LIB_PATH = os.environ.get("OZ_LIB_PATH") or os.path.join(_HERE, "lib", "libothel
 OZ_OK, OZ_ERR_HIP, OZ_ERR_ARG, OZ_ERR_CAPACITY, OZ_ERR_KEY, OZ_ERR_STATE = range(6)
 QMODE_NEP50, QMODE_F64 = 0, 1
 DEDUP_DEFAULT, DEDUP_ON, DEDUP_OFF = 0, 1, 2                                          # oz_selfplay_config.dedup
-NET_OPT_SIMPLE_LOOP, NET_OPT_ACT_TARGET_LOG2, NET_OPT_LOW_GUARD_LOG2, NET_OPT_SELF_CHECK, NET_OPT_W_TARGET_LOG2 = 1, 2, 3, 4, 5      # oz_net_set_option
-NET_INFO_CONV3_TILE_ROWS = 1                                                          # oz_net_get_info
+NET_OPT_SIMPLE_LOOP, NET_OPT_ACT_TARGET_LOG2, NET_OPT_LOW_GUARD_LOG2, NET_OPT_SELF_CHECK, NET_OPT_W_TARGET_LOG2, NET_OPT_F32_STD_TILE = 1, 2, 3, 4, 5, 6      # oz_net_set_option
+NET_INFO_CONV3_TILE_ROWS, NET_INFO_SELF_CHECK_GUARD = 1, 2                                                          # oz_net_get_info
 LEAF_IDLE, LEAF_TERMINAL, LEAF_EVAL = 0, 1, 2
 VT_INT, VT_F32, VT_F64 = 0, 1, 2
 NET_KERNELS = ("input", "conv2", "conv3", "conv4", "fc1", "fc2", "heads")           # OZ_NET_KERNELS slots
@@ -121,6 +121,7 @@ SIGNATURES = {
     "oz_examples_expand": [_vp, C.c_int64, C.c_int, C.c_int, _u8p, _i32p, _i8p],
     "oz_symmetry_table": [C.c_int, _i32p],
     "oz_selftest_arith": [_f64p, _f64p, C.c_int, _f64p, _f64p, _f32p, _f32p],
+    "oz_selftest_mfma_rate": [C.c_int, C.c_double, _f64p, _f64p, _f64p],
     "oz_trainer_arena_size": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)],
     "oz_trainer_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                           C.c_uint64, _vp],
@@ -266,6 +267,13 @@ def require_gpu():
     if lib.oz_device_count() <= 0:
         raise OzLibraryError("no HIP device visible: othellozero_amd computes on an MI355X only (no CPU fallback)")
     return lib
+
+
+def mfma_rate(kind, target_ms=50.0):
+    """oz_selftest_mfma_rate: {"tflops", "clock_ghz", "ms"} of a pure-MFMA loop on the current device; kind "f32" / "f16" """
+    t, g, m = C.c_double(), C.c_double(), C.c_double()
+    check(require_gpu().oz_selftest_mfma_rate({"f32": 0, "f16": 1}[kind], float(target_ms), C.byref(t), C.byref(g), C.byref(m)))
+    return {"tflops": t.value, "clock_ghz": g.value, "ms": m.value}
 
 
 # numpy -> pointer helpers

@@ -141,7 +141,8 @@ struct GemmGeom {
 };
 int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
                        const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
-                       hipStream_t s, float* partial, long long partial_floats, int sizing_count = 0, int core_lo = 0, int core_hi = -1);
+                       hipStream_t s, float* partial, long long partial_floats, int sizing_count = 0, int core_lo = 0, int core_hi = -1,
+                       int* tile_rows_out = nullptr, int force_std_tile = 0);
 // the f16x2 GEMM (k_gemm_h2, oz_net_h2.h) on h2-layout operands, fp32 rows out; zero_line = >= 256 B of zeros, flag = sticky range flag
 int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, const float* shift, float* out, const int* d_count, int max_count,
                       int Hin, int Hout, int pad, int Cin, int taps, int N, hipStream_t s, float* partial, long long partial_floats,

@@ -213,7 +213,11 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void k_gemm_f32(const float* __res
     const int r32 = lane & 31, half = lane >> 5;
     const int key = (r32 >> 1) & 7;                      // rows r32 + 32 t of a wave tile share it
     if (kt0 < nk) stage(kt0, kt0 & 1);
-    __syncthreads();                                     // drains the DMA (vmcnt(0)) and publishes the tile
+    // LDS-DMA rows written on behalf of OTHER waves become visible to a reader only after the ISSUING wave's vmcnt wait and a barrier
+    // the reader has passed.  The wait is explicit, as in the h2 kernels: __syncthreads()'s workgroup-scope fence does not promise a
+    // vmcnt wait on gfx9 and gfx950 has no automatic wait before s_barrier (this LLVM emits one today, a later one may not).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                     // publishes the tile
     for (int kt = kt0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);         // the other buffer: every wave finished reading it before the last barrier
@@ -244,7 +248,8 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void k_gemm_f32(const float* __res
                         acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[w][i][q], fb[w][jj][q], acc[i][jj], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                                 // vmcnt(0): the next tile has landed; barrier: everybody is done with this one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's pieces of THIS wave have landed (explicit: see the prologue) ...
+        __syncthreads();                                 // ... and the barrier publishes them; everybody is done with this tile
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -360,7 +365,12 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_f32(const float* __restri
 // in a fixed order by k_splitk_reduce_f32 -- same result for every batch position, different rounding than ksplit = 1.
 int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
                        const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
-                       hipStream_t s, float* partial, long long partial_floats, int sizing_count, int core_lo, int core_hi) {
+                       hipStream_t s, float* partial, long long partial_floats, int sizing_count, int core_lo, int core_hi,
+                       int* tile_rows_out, int force_std_tile) {
+    // tile_rows_out (optional): the row-tile height this launch ran on -- 64 = the weight-stream kernel, 128 = GmStd, 256 = GmBig;
+    // force_std_tile: never the 256 x 256 tile (OZ_NET_OPT_F32_STD_TILE: the bit-identity screen of the two tiles)
+    int tile_rows_dummy = 0;
+    int& tile_rows = tile_rows_out ? *tile_rows_out : tile_rows_dummy;
     OZ_REQUIRE(N % GM_BN == 0 && Cin % GM_BK == 0, "gemm_f32: N %% 128 and Cin %% 32 must be 0 (N=%d Cin=%d)", N, Cin);
     GemmGeom g;
     g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.relu = relu;
@@ -385,6 +395,7 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
         if ((long long)ks * max_count * Pout * N <= partial_floats) {
             const long long slab = (long long)max_count * Pout * N;
             g.ksplit = ks; g.slab = slab; g.pixmajor = 0;
+            tile_rows = 64;
             hipLaunchKernelGGL(k_gemm_f32_skinny, dim3(N / SK_COLS, ks), dim3(256), 0, s, in, Wt, d_count, g.K, N, kb, partial, slab, g);
             const long long quads = (slab + 3) / 4;
             hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, partial, slab, ks, N, Pout, d_count, scale,
@@ -418,13 +429,15 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
     // 3x3 convolutions that fill the chip with 256 x 256 tiles (no pixel-major skipping, no k split): the big tile -- every output element's
     // products are added in the same order as on the standard tile (bit-identical), keyed on the call's capacity like the other choices
     const long long big_blocks = ((Mmax + GmBig::BM - 1) / GmBig::BM) * (N / GmBig::BN);
-    if (taps == 9 && !g.pixmajor && ksplit == 1 && N % GmBig::BN == 0 && big_blocks >= 192) {
+    if (taps == 9 && !g.pixmajor && ksplit == 1 && N % GmBig::BN == 0 && big_blocks >= 192 && !force_std_tile) {
+        tile_rows = GmBig::BM;
         const int num_mt_big = (int)((Mmax + GmBig::BM - 1) / GmBig::BM);
         const int grid_big = ((num_mt_big + 7) / 8) * 8 * (N / GmBig::BN);
         hipLaunchKernelGGL(k_gemm_f32<GmBig>, dim3(grid_big, 1), dim3(GmBig::NT), GmBig::LDS_BYTES, s, in, Wt, scale, shift, out, d_count, g, num_mt_big, partial);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
     }
+    tile_rows = GmStd::BM;
     hipLaunchKernelGGL(k_gemm_f32<GmStd>, dim3(grid, ksplit), dim3(GmStd::NT), GmStd::LDS_BYTES, s, in, Wt, scale, shift, out, d_count, g, num_mt, partial);
     OZ_HIP(hipGetLastError());
     if (ksplit > 1) {
@@ -477,7 +490,8 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
         while (ksplit < 16 && blocks * ksplit < 256 && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * Mmax * N <= partial_floats) ksplit *= 2;
     }
     g.ksplit = ksplit;
-    const int grid = ((num_mt + 7) / 8) * 8 * (N / BN) * ksplit;
+    const int per_mt = (N / BN) * ksplit;
+    const int grid = num_mt < 8 ? ((per_mt + 7) / 8) * 8 * num_mt : ((num_mt + 7) / 8) * 8 * per_mt;       // (the kernel's two block mappings)
     void* dst = ksplit > 1 ? (void*)partial : (void*)out;
     if (mid)
         hipLaunchKernelGGL(k_gemm_h2<H2MidPP>, dim3(grid), dim3(H2MidPP::NT), H2MidPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
@@ -501,106 +515,64 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
 }
 
 // ---------------------------------------------------------------- heads
-// one 256-thread block per HEADS_P positions: wave w accumulates k in [128w, 128w+128) of logits[a] = f2 . Wpi[:,a]
-// (one policy column per lane, every coalesced Wpi row load feeds HEADS_P positions) and of v = f2 . Wv; the four
-// partial sums are combined in a fixed order through LDS, then wave w finishes positions 2w, 2w+1 (softmax, tanh).
-#define HEADS_P 8
-__global__ __launch_bounds__(256) void k_heads(const float* __restrict__ f2 /*[B][512]*/, const int* __restrict__ d_count,
-                                               int A, const float* __restrict__ Wpi /*[512][A]*/, const float* __restrict__ bpi,
-                                               const float* __restrict__ Wv /*[512]*/, const float* __restrict__ bv,
-                                               float* __restrict__ pi, float* __restrict__ v) {
-    __shared__ float part[4][HEADS_P][64];
-    __shared__ float vpart_s[4][HEADS_P];
-    const int b0 = blockIdx.x * HEADS_P, lane = threadIdx.x & 63, w = threadIdx.x >> 6, count = *d_count;
+// one 256-thread block per LP positions whose f2 rows (2 KB each) are staged in LDS once: wave w accumulates k in [128w, 128w+128) of
+// logits[a] = f2 . Wpi[:,a] (one policy column per lane, every coalesced Wpi row load feeds LP positions through LDS broadcasts) and of
+// v = f2 . Wv; the four partial sums are combined in a fixed order through LDS, then wave w finishes positions w LP/4 .. (softmax, tanh).
+// LP = 16 for batches, 8 for the few positions of the latency path: the same sums in the same order either way.
+// The policy weights of a wave's 128 reduction indices are fetched 32 rows at a time: the loop is a chain of L2 round trips (~0.6 us each),
+// so the depth of a batch IS the launch time -- with 4-8 rows in flight the launch took 20 us for ONE position, as long as conv3's 9.4 MB
+// weight stream, and 21 us at 512 positions (round 5: rocprofv3 of the arena and of predict(); 32 in flight: see DESIGN.md).
+template <int LP>
+__global__ __launch_bounds__(256) void k_heads_t(const float* __restrict__ f2 /*[B][512]*/, const int* __restrict__ d_count,
+                                                 int A, const float* __restrict__ Wpi /*[512][A]*/, const float* __restrict__ bpi,
+                                                 const float* __restrict__ Wv /*[512]*/, const float* __restrict__ bv,
+                                                 float* __restrict__ pi, float* __restrict__ v) {
+    __shared__ __attribute__((aligned(16))) float xs[LP][512];
+    __shared__ float part[4][LP][64];
+    __shared__ float vpart_s[4][LP];
+    const int b0 = blockIdx.x * LP, lane = threadIdx.x & 63, w = threadIdx.x >> 6, count = *d_count;
     if (b0 >= count) return;
     const bool act = lane < A;
-    const float* x[HEADS_P];
+    // this wave's first batch of weight rows is requested before the f2 rows are staged: the two round trips overlap
+    float wgt[32];
 #pragma unroll
-    for (int p = 0; p < HEADS_P; ++p) x[p] = f2 + (size_t)(b0 + p < count ? b0 + p : count - 1) * 512 + w * 128;
-    float logit[HEADS_P], vp[HEADS_P];
-#pragma unroll
-    for (int p = 0; p < HEADS_P; ++p) { logit[p] = 0.f; vp[p] = 0.f; }
-#pragma unroll 8
-    for (int i = 0; i < 128; ++i) {
-        const float wgt = act ? Wpi[(size_t)(w * 128 + i) * A + lane] : 0.f;
-#pragma unroll
-        for (int p = 0; p < HEADS_P; ++p) logit[p] = fmaf(x[p][i], wgt, logit[p]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float wv = Wv[w * 128 + lane * 2 + i];
-#pragma unroll
-        for (int p = 0; p < HEADS_P; ++p) vp[p] = fmaf(x[p][lane * 2 + i], wv, vp[p]);
-    }
-#pragma unroll
-    for (int p = 0; p < HEADS_P; ++p) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) vp[p] += __shfl_xor(vp[p], off, 64);
-        part[w][p][lane] = logit[p];
-        if (lane == 0) vpart_s[w][p] = vp[p];
-    }
-    __syncthreads();
-    const float bl = act ? bpi[lane] : 0.f, bvv = bv[0];
-#pragma unroll
-    for (int q = 0; q < HEADS_P / 4; ++q) {
-        const int p = w * (HEADS_P / 4) + q;
-        const float sum = ((part[0][p][lane] + part[1][p][lane]) + part[2][p][lane]) + part[3][p][lane];
-        const float lg = act ? sum + bl : -INFINITY;
-        float mx = lg;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-        const float e = act ? expf(lg - mx) : 0.f;
-        float s = e;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (b0 + p < count) {
-            if (act) pi[(size_t)(b0 + p) * A + lane] = e / s;
-            if (lane == 0) v[b0 + p] = tanhf(((vpart_s[0][p] + vpart_s[1][p]) + vpart_s[2][p]) + vpart_s[3][p] + bvv);
-        }
-    }
-}
-
-// the same sums in the same order with the f2 rows of HEADS_LP positions staged in LDS once (the loop above issues 8 broadcast global loads
-// per weight row; here they are LDS broadcasts and only the weight rows come from global memory)
-#define HEADS_LP 16
-__global__ __launch_bounds__(256) void k_heads_lds(const float* __restrict__ f2 /*[B][512]*/, const int* __restrict__ d_count,
-                                                   int A, const float* __restrict__ Wpi /*[512][A]*/, const float* __restrict__ bpi,
-                                                   const float* __restrict__ Wv /*[512]*/, const float* __restrict__ bv,
-                                                   float* __restrict__ pi, float* __restrict__ v) {
-    __shared__ __attribute__((aligned(16))) float xs[HEADS_LP][512];
-    __shared__ float part[4][HEADS_LP][64];
-    __shared__ float vpart_s[4][HEADS_LP];
-    const int b0 = blockIdx.x * HEADS_LP, lane = threadIdx.x & 63, w = threadIdx.x >> 6, count = *d_count;
-    if (b0 >= count) return;
-    for (int q = threadIdx.x; q < HEADS_LP * 128; q += 256) {                 // 16-byte pieces; rows beyond the batch repeat the last one (never stored)
+    for (int j = 0; j < 32; ++j) wgt[j] = act ? Wpi[(size_t)(w * 128 + j) * A + lane] : 0.f;
+    for (int q = threadIdx.x; q < LP * 128; q += 256) {                 // 16-byte pieces; rows beyond the batch repeat the last one (never stored)
         const int p = q >> 7, c4 = (q & 127) * 4;
         *reinterpret_cast<f32x4*>(&xs[p][c4]) = *reinterpret_cast<const f32x4*>(f2 + (size_t)(b0 + p < count ? b0 + p : count - 1) * 512 + c4);
     }
     __syncthreads();
-    const bool act = lane < A;
-    float logit[HEADS_LP], vp[HEADS_LP];
+    float logit[LP], vp[LP];
 #pragma unroll
-    for (int p = 0; p < HEADS_LP; ++p) { logit[p] = 0.f; vp[p] = 0.f; }
-#pragma unroll 4
-    for (int i4 = 0; i4 < 128; i4 += 4) {
-        float wgt[4];
+    for (int p = 0; p < LP; ++p) { logit[p] = 0.f; vp[p] = 0.f; }
+#pragma unroll 1
+    for (int i0 = 0; i0 < 128; i0 += 32) {                   // (rolled, with scheduling fences per position: fully unrolled the compiler hoisted every
+        float nxt[32];                                       //  LDS read of the loop to the top -- 512 VGPRs and 6 KB of scratch per thread, 64 us per launch)
+        const bool more = i0 + 32 < 128;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wgt[j] = act ? Wpi[(size_t)(w * 128 + i4 + j) * A + lane] : 0.f;
+        for (int j = 0; j < 32; ++j) nxt[j] = (act && more) ? Wpi[(size_t)(w * 128 + (more ? i0 + 32 : 0) + j) * A + lane] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < HEADS_LP; ++p) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[p][w * 128 + i4]);
+        for (int p = 0; p < LP; ++p) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) logit[p] = fmaf(x[j], wgt[j], logit[p]);
+            for (int j4 = 0; j4 < 32; j4 += 4) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[p][w * 128 + i0 + j4]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) logit[p] = fmaf(x[j], wgt[j4 + j], logit[p]);
+            }
+            if ((p & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wgt[j] = nxt[j];
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const float wv = Wv[w * 128 + lane * 2 + i];
 #pragma unroll
-        for (int p = 0; p < HEADS_LP; ++p) vp[p] = fmaf(xs[p][w * 128 + lane * 2 + i], wv, vp[p]);
+        for (int p = 0; p < LP; ++p) vp[p] = fmaf(xs[p][w * 128 + lane * 2 + i], wv, vp[p]);
     }
 #pragma unroll
-    for (int p = 0; p < HEADS_LP; ++p) {
+    for (int p = 0; p < LP; ++p) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vp[p] += __shfl_xor(vp[p], off, 64);
         part[w][p][lane] = logit[p];
@@ -609,8 +581,8 @@ __global__ __launch_bounds__(256) void k_heads_lds(const float* __restrict__ f2 
     __syncthreads();
     const float bl = act ? bpi[lane] : 0.f, bvv = bv[0];
 #pragma unroll
-    for (int q = 0; q < HEADS_LP / 4; ++q) {
-        const int p = w * (HEADS_LP / 4) + q;
+    for (int q = 0; q < LP / 4; ++q) {
+        const int p = w * (LP / 4) + q;
         const float sum = ((part[0][p][lane] + part[1][p][lane]) + part[2][p][lane]) + part[3][p][lane];
         const float lg = act ? sum + bl : -INFINITY;
         float mx = lg;
@@ -626,6 +598,8 @@ __global__ __launch_bounds__(256) void k_heads_lds(const float* __restrict__ f2 
         }
     }
 }
+#define HEADS_P 8
+#define HEADS_LP 16
 
 // ---------------------------------------------------------------- stub evaluator (test nets)
 __global__ __launch_bounds__(64) void k_stub(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
@@ -740,6 +714,9 @@ struct OnnNet : oz_net {
     int profile = 0;
     OzTimer timer{OZ_NET_KERNELS};
     int tables_mode = -1;            // oz_net_set_tables: -1 = default (2), 0 / 1 / 2 see forward_h2
+    int sizing() const { return max_batch; }     // the batch size the k-splits of the medium path are chosen for: the capacity, a per-network constant
+    size_t partial_cap = 0;          // floats d_partial holds
+    bool f32_std_tile = false;       // oz_net_set_option(OZ_NET_OPT_F32_STD_TILE): precision f32 never takes the 256 x 256 tile (bit-identity screen)
     bool simple_loop = false;        // oz_net_set_option(OZ_NET_OPT_SIMPLE_LOOP): one-barrier-per-k-tile loop for the 3x3 layers (race screen)
     float* d_t2rows = nullptr;       // commit staging: one tap's T2 rows [OZ_LUT_PATTERNS][C] before the slice-major re-layout
     int last_conv3_rows = 0;         // row-tile height the last forward ran conv3 on (oz_net_get_info)
@@ -765,6 +742,7 @@ struct OnnNet : oz_net {
     int self_check = 1;              // OZ_NET_OPT_SELF_CHECK: compare with the exact-fp32 kernels on the calibration positions at commit
     double sc_dpi = -1.0, sc_dv = -1.0;                          // what the last commit's self-check measured (oz_net_self_check)
     int sc_positions = 0;
+    int sc_guard = 0;                // H2_FLAG_* bits a guard raised on the calibration positions during the last self-check (OZ_NET_INFO_SELF_CHECK_GUARD)
     float *d_sc_out = nullptr;       // self-check outputs: [2][cal_total][A + 1]
     uint64_t *d_cal_own = nullptr, *d_cal_opp = nullptr;          // calibration positions (calib_positions), resident
     int* d_cal_count = nullptr;
@@ -794,7 +772,8 @@ struct OnnNet : oz_net {
                     int Hout, int pad, int Cin, int taps, int N, hipStream_t s) {
         // small and medium networks (max_batch <= 512) split K over the idle CUs: latency, not throughput
         return oz_gemm_f32_launch(in, Wt, d_scale[layer], d_shift[layer], out, d_count, max_count, Hin, Hout, pad, Cin, taps, N, 1, s,
-                                  d_part32, d_part32 ? (long long)part32_floats() : 0, max_batch);
+                                  d_part32, d_part32 ? (long long)part32_floats() : 0, sizing(), 0, -1,
+                                  layer == 2 ? &last_conv3_rows : nullptr, f32_std_tile ? 1 : 0);       // layer 2 = conv3: what oz_net_get_info reports
     }
 
     // precision f32: split-K slabs per position-row budget (small networks 16 slices, medium ones fewer; none for large batches)
@@ -807,14 +786,14 @@ struct OnnNet : oz_net {
     // k-split of a 3x3 convolution on BM-row tiles (N = C, 256-column tiles): the smallest power of two <= 8 that brings
     // the grid to >= 192 blocks, from max_batch (a per-network constant, so results do not depend on the size of a call)
     int conv_ksplit(int pixels, int BM) const {
-        const long long blocks = (((long long)max_batch * pixels + BM - 1) / BM) * (C / 256);
+        const long long blocks = (((long long)sizing() * pixels + BM - 1) / BM) * (C / 256);
         int k = 1;
         while (k < 8 && blocks * k < 192) k *= 2;
         return k;
     }
     size_t partial_floats() const {
         if (max_batch <= 32) return (size_t)16 * max_batch * 64 * 1024;
-        size_t need = (size_t)4 * max_batch * 1024;                                  // fc1
+        size_t need = (size_t)(sizing() >= 1024 ? 4 : 8) * max_batch * 1024;         // fc1 (forward_h2: kfc1)
         const int px[3] = {n * n, (n - 2) * (n - 2), (n - 4) * (n - 4)}, bm[3] = {256, 192, 256};
         for (int i = 0; i < 3; ++i) {
             int k = conv_ksplit(px[i], bm[i]);
@@ -839,7 +818,8 @@ struct OnnNet : oz_net {
         if (out_h2 && ksplit == 1) g.low = low;
         const long long Mmax = (long long)max_count * Hout * Hout;
         const int num_mt = (int)((Mmax + CF::BM - 1) / CF::BM);
-        const int grid = ((num_mt + 7) / 8) * 8 * (N / CF::BN) * ksplit;
+        const int per_mt = (N / CF::BN) * ksplit;
+        const int grid = num_mt < 8 ? ((per_mt + 7) / 8) * 8 * num_mt : ((num_mt + 7) / 8) * 8 * per_mt;   // (the kernel's two block mappings)
         void* out_final = out;
         if (ksplit > 1) out = d_partial;          // raw k-slice sums; k_splitk_reduce_h2 below writes out_final (h2 layout)
         {   // the dynamic-LDS limit of THIS instantiation, once per device
@@ -876,8 +856,8 @@ struct OnnNet : oz_net {
     // policy / value heads: batches stage the f2 rows of 16 positions in LDS; few positions (the latency path) keep the 8-position kernel
     // (same sums in the same order either way)
     void launch_heads(int max_count, const int* d_count, float* d_pi, float* d_v, hipStream_t s) {
-        if (max_count >= 64) hipLaunchKernelGGL(k_heads_lds, dim3((max_count + HEADS_LP - 1) / HEADS_LP), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
-        else hipLaunchKernelGGL(k_heads, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        if (max_count >= 64) hipLaunchKernelGGL(k_heads_t<HEADS_LP>, dim3((max_count + HEADS_LP - 1) / HEADS_LP), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        else hipLaunchKernelGGL(k_heads_t<HEADS_P>, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
     }
 
     // conv1 + conv2 as the table gather-sum: one table slice per XCD at 512 filters, the thread-per-(pixel, 8 channels) kernel otherwise
@@ -990,7 +970,11 @@ struct OnnNet : oz_net {
         if (!d_flag) { if (int rc = alloc(&d_flag, 1)) return rc; }
         OZ_HIP(hipMemset(d_flag, 0, sizeof(int)));
         // split-K slabs: fc1 (4 x max_batch x 1024); small networks also split the convolutions 16 ways (latency path)
-        if (!d_partial) { if (int rc = alloc(&d_partial, partial_floats())) return rc; }
+        if (!d_partial || partial_floats() > partial_cap) {
+            d_partial = nullptr;
+            if (int rc = alloc(&d_partial, partial_floats())) return rc;
+            partial_cap = partial_floats();
+        }
         if (!d_zero) { if (int rc = alloc(&d_zero, 16)) return rc; }
         OZ_HIP(hipMemset(d_zero, 0, 256));
         if (!d_colmax) { if (int rc = alloc(&d_colmax, (size_t)wide)) return rc; }
@@ -1121,7 +1105,7 @@ struct OnnNet : oz_net {
             }
         }
         OZ_HIP(hipMemset(d_flag, 0, sizeof(int)));
-        sc_dpi = sc_dv = -1.0; sc_positions = 0;
+        sc_dpi = sc_dv = -1.0; sc_positions = 0; sc_guard = 0;
         if (self_check && act_target_log2 == TOP) { if (int rc = run_self_check()) return rc; }
         return OZ_OK;
     }
@@ -1164,7 +1148,14 @@ struct OnnNet : oz_net {
         OZ_HIP(hipMemcpy(out.data(), d_sc_out, sizeof(float) * out.size(), hipMemcpyDeviceToHost));
         int flag = 0;
         OZ_HIP(hipMemcpy(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost));
-        if (flag) return check();                            // a guard fired on the calibration positions themselves
+        // a guard fired on the calibration positions themselves: mode 1 fails the commit with the guard's own message, mode 2 (measure only)
+        // records it (OZ_NET_INFO_SELF_CHECK_GUARD) and goes on; either way the flag does not stay sticky beyond the commit that reported it
+        int guard_rc = OZ_OK;
+        if (flag) {
+            guard_rc = check();
+            OZ_HIP(hipMemset(d_flag, 0, sizeof(int)));
+        }
+        sc_guard = flag;
         double dpi = 0.0, dv = 0.0;
         const float *a = out.data(), *b = out.data() + (size_t)cal_total * per;
         bool finite = true;
@@ -1174,6 +1165,7 @@ struct OnnNet : oz_net {
             if (i < (size_t)cal_total * A) dpi = std::max(dpi, d); else dv = std::max(dv, d);
         }
         sc_dpi = dpi; sc_dv = dv; sc_positions = cal_total;
+        if (self_check == 1 && flag) return guard_rc;
         if (self_check == 1 && (!finite || dpi > H2_SELF_CHECK_LIMIT || dv > H2_SELF_CHECK_LIMIT)) {
             oz_set_error("oz_net_commit (precision f16x2): self-check failed -- on %d calibration positions the f16x2 kernels and the exact-fp32 kernels differ by "
                          "max |d pi| = %.3g, max |d v| = %.3g (limit %.1g): this network amplifies rounding beyond what the 2 x fp16 split (22 of fp32's 24 "
@@ -1305,16 +1297,19 @@ struct OnnNet : oz_net {
         //  the 128 x 128 tile because the k-slices and the order inside them are the same -- tools/pp_race_check.py)
         next_low = low_of(4, guard);
         next_relu = h2o4;
+        // (medium networks, max_batch < 1024: 8 k-slices -- fc1 at 512 rows is 32 output tiles of 128 x 128; 4 slices = 128 blocks of 64 k-tiles
+        //  took 58 us + its reduce in the arena's 512-leaf batches, round 5; the split is keyed on max_batch, a per-network constant)
+        const int kfc1 = sizing() >= 1024 ? 4 : 8;
         if (int rc = small ? launch_small<H2Small, H2Small2>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)
-                     : (pp && max_count >= 1024) ? launch_gemm_h2<H2BigPP, 5>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
-                                                          : launch_small<H2Small, H2Small2>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)) return rc;
+                     : (pp && sizing() >= 1024 && max_count >= 1024) ? launch_gemm_h2<H2BigPP, 5>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
+                                                          : launch_small<H2Small, H2Small2>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, kfc1)) return rc;
         mark(4, false);
         if (calib == 4) { OZ_HIP(hipGetLastError()); return OZ_OK; }
         mark(5, true);
         // fc2: one position has 4 blocks of 32 k-tiles -> small networks split k 8 ways too, medium ones 4 ways (from max_batch)
         // (large networks: one k-slice on the four-wave form of the thin tile, bit-identical to the two-wave one)
-        if (int rc = max_batch > 512 ? launch_gemm_h2<H2Thin4w, 6>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, 1)
-                                    : launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, small ? 8 : max_batch <= 512 ? 4 : 1)) return rc;
+        if (int rc = sizing() > 512 ? launch_gemm_h2<H2Thin4w, 6>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, 1)
+                                   : launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, small ? 8 : 4)) return rc;
         mark(5, false);
         mark(6, true);
         launch_heads(max_count, d_count, d_pi, d_v, s);
@@ -1337,7 +1332,7 @@ struct OnnNet : oz_net {
         const int P = n * n;
         // precision f32: conv1 + conv2 from the fp32 pattern tables (default), or conv1 kernel + conv2 GEMM (oz_net_set_tables 0 / 1)
         const bool use_t2f = (tables_mode < 0 || tables_mode >= 2) && t2f_ok;
-        last_conv3_rows = GM_BM;
+        last_conv3_rows = 0;             // set by conv3's launch below (launch_gemm, layer 2): 64 weight stream / 128 GmStd / 256 GmBig
         profiled_layer = use_t2f ? 3 : 2;
         if (profile && timer.backlog() > 4096) timer.drain();          // no host stall inside an enqueue loop: only pairs that have completed
         long long tidx = -1;
@@ -1735,6 +1730,8 @@ OZ_API int oz_net_set_precision(oz_net* net, int mode) {
     OZ_REQUIRE(o, "not an OthelloNN network");
     OZ_REQUIRE(mode == 0 || mode == 1, "precision must be 0 (f32) or 1 (f16x2)");
     OZ_REQUIRE(mode == 0 || o->C % 256 == 0, "precision f16x2 needs channels %% 256 == 0 (got %d)", o->C);
+    // the low-side guard counts a row's low 64-channel slices in 6 bits (h2_low_report): 64 slices or more would switch it off silently
+    OZ_REQUIRE(mode == 0 || o->C <= 2048, "precision f16x2 supports at most 2048 channels (got %d): use precision f32", o->C);
     std::lock_guard<std::mutex> lk(o->mu);
     if (o->precision != mode) { o->precision = mode; o->committed = false; }
     return OZ_OK;
@@ -1781,9 +1778,11 @@ OZ_API int oz_net_set_option(oz_net* net, int option, int value) {
     OnnNet* o = as_onn(net);
     OZ_REQUIRE(o, "not an OthelloNN network");
     OZ_REQUIRE(option == OZ_NET_OPT_SIMPLE_LOOP || option == OZ_NET_OPT_ACT_TARGET_LOG2 || option == OZ_NET_OPT_LOW_GUARD_LOG2 ||
-               option == OZ_NET_OPT_SELF_CHECK || option == OZ_NET_OPT_W_TARGET_LOG2, "unknown network option %d", option);
+               option == OZ_NET_OPT_SELF_CHECK || option == OZ_NET_OPT_W_TARGET_LOG2 || option == OZ_NET_OPT_F32_STD_TILE,
+               "unknown network option %d", option);
     std::lock_guard<std::mutex> lk(o->mu);
     if (option == OZ_NET_OPT_SIMPLE_LOOP) o->simple_loop = value != 0;
+    else if (option == OZ_NET_OPT_F32_STD_TILE) o->f32_std_tile = value != 0;
     else if (option == OZ_NET_OPT_W_TARGET_LOG2) {
         OZ_REQUIRE(value >= -12 && value <= 15, "OZ_NET_OPT_W_TARGET_LOG2 must be in [-12, 15] (got %d)", value);
         if (o->w_target_log2 != value) { o->w_target_log2 = value; o->committed = false; }
@@ -1828,9 +1827,9 @@ OZ_API int oz_net_get_scaling(oz_net* net, int which, int32_t* out, int64_t nele
 OZ_API int oz_net_get_info(oz_net* net, int what, int* value) {
     OnnNet* o = as_onn(net);
     OZ_REQUIRE(o && value, "not an OthelloNN network / null argument");
-    OZ_REQUIRE(what == OZ_NET_INFO_CONV3_TILE_ROWS, "unknown network info %d", what);
+    OZ_REQUIRE(what == OZ_NET_INFO_CONV3_TILE_ROWS || what == OZ_NET_INFO_SELF_CHECK_GUARD, "unknown network info %d", what);
     std::lock_guard<std::mutex> lk(o->mu);
-    *value = o->last_conv3_rows;
+    *value = what == OZ_NET_INFO_CONV3_TILE_ROWS ? o->last_conv3_rows : o->sc_guard;
     return OZ_OK;
 }
 

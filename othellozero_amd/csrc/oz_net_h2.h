@@ -735,9 +735,23 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     constexpr int RI = CF::TI * 2, RJ = CF::TJ * 2;           // 16-row / 16-column MFMA tiles per wave
     // XCD-aware tile order: the N/BN column tiles of one row tile run on the same XCD (ids b, b+8 share an L2)
     // split-K (g.ksplit > 1): the ksplit slices of one output tile are consecutive block ids of the same XCD
+    // FEW row tiles (num_mt < 8: dense layers of batches up to ~1000 rows, every layer of the latency path): the mapping above would leave
+    // XCDs num_mt .. 7 idle and make every working XCD stream the WHOLE weight matrix through its own L2 (one position: all blocks of a layer
+    // on XCD 0 -- 32 of 256 CUs; fc1 at 512 rows: 4 XCDs, 134 MB of HBM reads for a 33.5 MB matrix).  There the WEIGHT slices q = (column
+    // tile, k-slice) go round-robin over the XCDs and the row tiles of one slice share its XCD: every weight byte leaves HBM once, every XCD
+    // works.  Same blocks, same sums -- only where they run changes.
     const int nnt = g.N / BN, per_mt = nnt * g.ksplit;
     const int id = blockIdx.x, xcd = id & 7, jb = id >> 3;
-    const int mt = (jb / per_mt) * 8 + xcd, rem = jb % per_mt, nt = rem / g.ksplit, ks = rem - nt * g.ksplit;
+    int mt, nt, ks;
+    if (num_mt < 8) {
+        mt = jb % num_mt;
+        const int q = (jb / num_mt) * 8 + xcd;
+        if (q >= per_mt) return;
+        nt = q / g.ksplit; ks = q - nt * g.ksplit;
+    } else {
+        const int rem = jb % per_mt;
+        mt = (jb / per_mt) * 8 + xcd; nt = rem / g.ksplit; ks = rem - nt * g.ksplit;
+    }
     const int P = g.Hout * g.Hout;
     const long long M = (long long)(*d_count) * P;
     if (mt >= num_mt || (long long)mt * BM >= M) return;

@@ -731,30 +731,39 @@ static int mcts_collect_eval_time(oz_mcts* m) {
 // `nsims` lock-step simulations: descent | compaction | evaluator, then per further simulation the previous one's expand + backup
 // fused with the next descent (k_backup_select), and one closing expand + backup: nsims + 1 tree launches instead of 2 nsims
 // (results are identical to the unfused sequence, which a single step still uses).
+// mcts_step_k enqueues simulation k of such a sequence, mcts_steps_close the closing expand + backup: the arena interleaves the steps of
+// its two searches on two streams.  max_leaves = an upper bound of the leaves a batch can hold (<= G: the active games), the size the
+// evaluator's launches are made for.
+static int mcts_step_k(oz_mcts* m, oz_net* net, int k, int max_leaves, bool time_eval) {
+    MctsDev& d = m->d;
+    hipStream_t s = m->stream;
+    const bool all = m->profile;
+    long long i = all ? m->timer.begin(TS_SELECT, s) : -1;
+    if (k == 0) hipLaunchKernelGGL(k_select, dim3(d.G), dim3(64), 0, s, d);
+    else hipLaunchKernelGGL(k_backup_select, dim3(d.G), dim3(64), 0, s, d);
+    m->timer.end(i, s);
+    i = all ? m->timer.begin(TS_COMPACT, s) : -1;
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, d);
+    m->timer.end(i, s);
+    return eval_batch_async(m, net, max_leaves, time_eval || all);
+}
+static int mcts_steps_close(oz_mcts* m) {
+    const bool all = m->profile;
+    const long long i = all ? m->timer.begin(TS_BACKUP, m->stream) : -1;
+    hipLaunchKernelGGL(k_expand_backup, dim3(m->d.G), dim3(64), 0, m->stream, m->d, 0);
+    m->timer.end(i, m->stream);
+    OZ_HIP(hipGetLastError());
+    return OZ_OK;
+}
 static int mcts_steps_async(oz_mcts* m, oz_net* net, int nsims, bool time_eval) {
     if (nsims < 2) {
         for (int i = 0; i < nsims; ++i)
             if (int rc = mcts_step_async(m, net, time_eval)) return rc;
         return OZ_OK;
     }
-    MctsDev& d = m->d;
-    hipStream_t s = m->stream;
-    const bool all = m->profile;
-    for (int k = 0; k < nsims; ++k) {
-        long long i = all ? m->timer.begin(TS_SELECT, s) : -1;
-        if (k == 0) hipLaunchKernelGGL(k_select, dim3(d.G), dim3(64), 0, s, d);
-        else hipLaunchKernelGGL(k_backup_select, dim3(d.G), dim3(64), 0, s, d);
-        m->timer.end(i, s);
-        i = all ? m->timer.begin(TS_COMPACT, s) : -1;
-        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, d);
-        m->timer.end(i, s);
-        if (int rc = eval_batch_async(m, net, d.G, time_eval || all)) return rc;
-    }
-    const long long i = all ? m->timer.begin(TS_BACKUP, s) : -1;
-    hipLaunchKernelGGL(k_expand_backup, dim3(d.G), dim3(64), 0, s, d, 0);
-    m->timer.end(i, s);
-    OZ_HIP(hipGetLastError());
-    return OZ_OK;
+    for (int k = 0; k < nsims; ++k)
+        if (int rc = mcts_step_k(m, net, k, m->d.G, time_eval)) return rc;
+    return mcts_steps_close(m);
 }
 
 OZ_API int oz_mcts_create(oz_mcts** out, int n, int num_games, int node_cap, double c, int q_mode) {
@@ -1695,7 +1704,10 @@ OZ_API int oz_arena_run_rounds(oz_arena* a, int max_rounds_arg) {
         if (!a->na) hipLaunchKernelGGL(k_arena_random_move, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, 1);
         if (!a->nb) hipLaunchKernelGGL(k_arena_random_move, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, -1);
         // who has to move?  Without passes every game of a round has the same mover, so one of the two agents has nothing to search: its
-        // a->sims steps (11 launches each over zero leaves) are skipped -- one 8-byte read-back per round buys ~10 % at 800 sims per move
+        // a->sims steps (11 launches each over zero leaves) are skipped -- one 8-byte read-back per round buys ~10 % at 800 sims per move.
+        // (Round 5, measured and removed: BOTH agents in every round -- the odd slots held back one ply, agent A's and agent B's chains on two
+        //  streams, k-splits sized for half batches -- 350.6 against 348.7 ms per ply of 512 games in an A/B on one device: the second chain's
+        //  kernels run beside the first one's and slow them by what they gain, the chip is power limited)
         int movers[2] = {0, 0};
         hipMemsetAsync(a->d_movers, 0, sizeof movers, s);
         hipLaunchKernelGGL(k_arena_movers, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, a->d_movers);
@@ -1705,13 +1717,16 @@ OZ_API int oz_arena_run_rounds(oz_arena* a, int max_rounds_arg) {
         const bool run_a = a->na && movers[0] > 0, run_b = a->nb && movers[1] > 0;
         if (run_a) hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, ma->d, 1);
         if (run_b) hipLaunchKernelGGL(k_sp_roots, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, mb->d, -1);
+        // the evaluator's launches are made for the movers of the round (an upper bound of the leaves a batch can hold), not for all G slots
         if (run_a) {
             std::lock_guard<std::mutex> la(a->na->mu);
-            rc = mcts_steps_async(ma, a->na, a->sims, false);
+            for (int k = 0; k < a->sims && !rc; ++k) rc = mcts_step_k(ma, a->na, k, movers[0], false);
+            if (!rc) rc = mcts_steps_close(ma);
         }
         if (!rc && run_b) {
             std::lock_guard<std::mutex> lb(a->nb->mu);
-            rc = mcts_steps_async(mb, a->nb, a->sims, false);
+            for (int k = 0; k < a->sims && !rc; ++k) rc = mcts_step_k(mb, a->nb, k, movers[1], false);
+            if (!rc) rc = mcts_steps_close(mb);
         }
         if (rc) break;
         if (run_a) hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, ma->d, 1);
@@ -1727,7 +1742,6 @@ OZ_API int oz_arena_run_rounds(oz_arena* a, int max_rounds_arg) {
         }
     }
     if (!rc) rc = check_error_flag(ma);
-    mb->stream = s;                                          // (check_error_flag reads through the object's stream)
     if (!rc) rc = check_error_flag(mb);
     mb->stream = sb_saved;
     if (rc) return rc;
@@ -1857,31 +1871,45 @@ OZ_API int oz_comm_destroy(oz_comm* c) {
 // COLLECTIVE: every rank of `comm` calls it with its own engine.  The records [first_record, records completed so far) of every rank's
 // engine, concatenated in rank order, into `out` (host, caller-owned, max_records long; per_rank[world] gets every rank's count).
 // A (count, room) pair all-gather (16 bytes per rank) + ONE padded all-gather of 48-byte records, device to device out of the engines' HBM
-// buffers.  Every decision that could end the call between the two collectives is taken from the GATHERED pairs, i.e. identically on every
-// rank (a rank-local capacity check let one rank leave while its peers entered the payload all-gather): too little room on ANY
-// rank fails the call on EVERY rank, before the payload moves; a failed buffer allocation is agreed on by one more 8-byte all-gather.
+// buffers.  Every decision that could end the call on one rank is taken from the GATHERED pairs, i.e. identically on every rank (a
+// rank-local capacity check let one rank leave while its peers entered the payload all-gather; ADVICE r4: so did a rank-local argument or HIP
+// error BEFORE the first all-gather): a rank whose own arguments are bad (first_record < 0, a null buffer with room, the communicator on
+// another device) or whose record counter cannot be read joins the pair all-gather with room = -2, "cannot take part", and EVERY rank fails
+// together -- that rank with its own message, the others naming it; too little room on ANY rank fails the call on EVERY rank before the payload
+// moves; a failed buffer allocation is agreed on by one more 8-byte all-gather.  What stays rank-local: null sp / comm / written (there is no
+// communicator to say so with) and an RCCL / HIP failure of the collectives themselves (the communicator is then broken for everybody).
 // out == NULL with max_records == 0 on every rank = the counts only (*written = the pooled number, per_rank filled): size the buffer, call again.
 OZ_API int oz_selfplay_gather_records(oz_selfplay* sp, oz_comm* c, int64_t first_record, oz_record* out, int64_t max_records, int64_t* written,
                                       int64_t* per_rank) {
     OZ_REQUIRE(sp && c && written, "null argument");
-    OZ_REQUIRE(first_record >= 0, "first_record %lld", (long long)first_record);
-    OZ_REQUIRE(out || max_records == 0, "oz_selfplay_gather_records: null output buffer with room for %lld records", (long long)max_records);
     std::lock_guard<std::mutex> lk(sp->mu);
     std::lock_guard<std::mutex> lkc(c->mu);
-    hipSetDevice(sp->m->device);
-    OZ_REQUIRE(c->device == sp->m->device, "the communicator lives on device %d, the engine on device %d", c->device, sp->m->device);
-    OZ_HIP(hipStreamSynchronize(sp->m->stream));
+    hipSetDevice(c->device);
+    char local_bad[256] = "";
+    if (first_record < 0) snprintf(local_bad, sizeof local_bad, "first_record %lld", (long long)first_record);
+    else if (!out && max_records != 0) snprintf(local_bad, sizeof local_bad, "null output buffer with room for %lld records", (long long)max_records);
+    else if (c->device != sp->m->device) snprintf(local_bad, sizeof local_bad, "the communicator lives on device %d, the engine on device %d", c->device, sp->m->device);
     unsigned long long total = 0;
-    OZ_HIP(hipMemcpy(&total, sp->gm.counters, 8, hipMemcpyDeviceToHost));
+    if (!local_bad[0]) {
+        hipError_t e = hipStreamSynchronize(sp->m->stream);
+        if (e == hipSuccess) e = hipMemcpy(&total, sp->gm.counters, 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { snprintf(local_bad, sizeof local_bad, "reading the engine's record counter failed: %s", hipGetErrorString(e)); (void)hipGetLastError(); }
+    }
     long long have = (long long)total < sp->gm.record_cap ? (long long)total : sp->gm.record_cap;
     const int W = c->world;
-    long long pair[2] = {have > first_record ? have - first_record : 0, out ? (long long)max_records : -1};      // room -1 = "counts only"
+    // room: >= 0 = records `out` holds, -1 = "counts only", -2 = "this rank cannot take part"
+    long long pair[2] = {have > first_record ? have - first_record : 0, out ? (long long)max_records : -1};
+    if (local_bad[0]) { pair[0] = 0; pair[1] = -2; }
     const long long mine = pair[0];
     OZ_HIP(hipMemcpyAsync(c->d_counts, pair, sizeof pair, hipMemcpyHostToDevice, c->stream));
     OZ_NCCL(g_rccl.AllGather(c->d_counts, c->d_counts + 2, 2, OZ_NCCL_INT64, c->comm, c->stream));
     std::vector<long long> pairs((size_t)2 * W);
     OZ_HIP(hipMemcpyAsync(pairs.data(), c->d_counts + 2, sizeof(long long) * 2 * W, hipMemcpyDeviceToHost, c->stream));
     OZ_HIP(hipStreamSynchronize(c->stream));
+    *written = 0;
+    if (local_bad[0]) { oz_set_error("oz_selfplay_gather_records: %s (every rank fails together)", local_bad); return OZ_ERR_ARG; }
+    for (int r = 0; r < W; ++r)
+        if (pairs[2 * r + 1] == -2) { oz_set_error("oz_selfplay_gather_records: rank %d could not take part (bad arguments or a local error there): every rank fails together", r); return OZ_ERR_STATE; }
     long long mx = 0, sum = 0;
     int counts_only = 0, short_rank = -1;
     for (int r = 0; r < W; ++r) {
@@ -1891,7 +1919,6 @@ OZ_API int oz_selfplay_gather_records(oz_selfplay* sp, oz_comm* c, int64_t first
         if (pairs[2 * r + 1] < 0) ++counts_only;
     }
     for (int r = 0; r < W && short_rank < 0; ++r) if (pairs[2 * r + 1] >= 0 && pairs[2 * r + 1] < sum) short_rank = r;
-    *written = 0;
     if (counts_only == W) { *written = sum; return OZ_OK; }
     OZ_REQUIRE(counts_only == 0, "oz_selfplay_gather_records: %d of %d ranks asked for the counts only (out == NULL), the others for the records", counts_only, W);
     OZ_REQUIRE(short_rank < 0, "oz_selfplay_gather_records: %lld pooled records, rank %d has room for %lld (every rank fails together)", sum, short_rank,
@@ -1955,5 +1982,94 @@ OZ_API int oz_selftest_arith(const double* a, const double* b, int count, double
     hipMemcpy(fdiv_ab, df, 4ull * count, hipMemcpyDeviceToHost); hipMemcpy(fchain, dq, 4ull * count, hipMemcpyDeviceToHost);
     hipFree(da); hipFree(db); hipFree(ds); hipFree(dd); hipFree(df); hipFree(dq);
     OZ_HIP(e);
+    return OZ_OK;
+}
+
+// Sustained matrix-pipe rate of THIS device, right now: a pure-MFMA loop (no LDS, no loads, no barriers; one block per CU, one wave per SIMD,
+// four independent accumulators back to back -- the issue pattern of the GEMM kernels' clusters) for about `target_ms`.  kind 0 =
+// v_mfma_f32_32x32x2_f32 (what k_gemm_f32 runs on), kind 1 = v_mfma_f32_16x16x32_f16 on operands with every mantissa bit busy (what k_gemm_h2
+// runs on; the sustained clock of that pipe follows the operand bits).  bench.py puts both numbers into its line as
+// `device_calibration`, so that a reader can tell a slow box (or a power-capped one) from a regression: the GEMM kernels' own rate moves
+// with this one.  tflops = FLOP of the issued MFMAs / HIP-event time; clock_ghz = the clock at which back-to-back issue (64 / 16 cycles per
+// MFMA and SIMD) gives that rate.
+typedef float dg_f32x16 __attribute__((ext_vector_type(16)));
+typedef float dg_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 dg_f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_diag_mfma_f32(float* out, int iters, float a0, float b0) {
+    dg_f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const float a = a0 + threadIdx.x * 1.0009765625e-3f, b = b0 + threadIdx.x * 2.001953125e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_diag_mfma_f16(float* out, int iters, unsigned seed) {
+    dg_f32x4 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    dg_f16x8 a, b;
+    uint64_t r = oz_sm64(seed + 977u * (blockIdx.x * blockDim.x + threadIdx.x));
+    for (int j = 0; j < 8; ++j) {                            // values in [2^-3, 2^-2) with random mantissas and signs: the window the network's tensors sit in
+        r = oz_sm64(r);
+        const unsigned short ha = (unsigned short)(0x3000u | (r & 0x3FFu) | ((r >> 10) & 1u) << 15);
+        const unsigned short hb = (unsigned short)(0x3000u | ((r >> 16) & 0x3FFu) | ((r >> 26) & 1u) << 15);
+        a[j] = __builtin_bit_cast(_Float16, ha); b[j] = __builtin_bit_cast(_Float16, hb);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int r2 = 0; r2 < 4; ++r2) s += acc[i][r2];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+OZ_API int oz_selftest_mfma_rate(int kind, double target_ms, double* tflops, double* clock_ghz, double* ms_measured) {
+    OZ_REQUIRE((kind == 0 || kind == 1) && tflops, "oz_selftest_mfma_rate: kind must be 0 (f32) or 1 (f16), tflops non-null");
+    OZ_REQUIRE(target_ms > 0 && target_ms <= 2000, "oz_selftest_mfma_rate: target_ms %.1f outside (0, 2000]", target_ms);
+    const int dev = oz_current_device();
+    hipDeviceProp_t prop;
+    OZ_HIP(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount;
+    float* out = nullptr;
+    OZ_HIP(hipMalloc((void**)&out, sizeof(float) * 256 * (size_t)cus));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const double flop_per_mfma = kind == 0 ? 32.0 * 32 * 2 * 2 : 16.0 * 16 * 32 * 2;
+    const double cycles_per_mfma = kind == 0 ? 64.0 : 16.0;  // back-to-back issue on one SIMD
+    auto launch = [&](int iters) {
+        if (kind == 0) hipLaunchKernelGGL(k_diag_mfma_f32, dim3(cus), dim3(256), 0, 0, out, iters, 0.5f, 0.25f);
+        else hipLaunchKernelGGL(k_diag_mfma_f16, dim3(cus), dim3(256), 0, 0, out, iters, 12345u);
+    };
+    // a short run sizes the long one (and warms the clocks up)
+    int iters = kind == 0 ? 400 : 1600;
+    float ms = 0.f;
+    hipError_t err = hipSuccess;
+    for (int pass = 0; pass < 2 && err == hipSuccess; ++pass) {
+        hipEventRecord(e0, 0);
+        launch(iters);
+        hipEventRecord(e1, 0);
+        err = hipEventSynchronize(e1);
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+        if (pass == 0 && err == hipSuccess) {
+            const double scale = target_ms / (ms > 1e-3f ? ms : 1e-3f);
+            const double want = iters * scale;
+            iters = (int)(want < 1 ? 1 : want > 2.0e8 ? 2.0e8 : want);
+        }
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(out);
+    OZ_HIP(err);
+    const double mfmas = (double)cus * 4 /* waves = SIMDs */ * iters * 64.0;
+    const double rate = mfmas * flop_per_mfma / (ms * 1e-3);
+    *tflops = rate / 1e12;
+    if (clock_ghz) *clock_ghz = mfmas / ((double)cus * 4) * cycles_per_mfma / (ms * 1e-3) / 1e9;
+    if (ms_measured) *ms_measured = ms;
     return OZ_OK;
 }

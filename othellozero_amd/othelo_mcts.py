@@ -136,41 +136,58 @@ class OthelloMCTS:
             probabilities[row, col] = int(cnt[row * 8 + col]) ** (1 / temperature)
         return probabilities / (np.sum(probabilities) or 1)
 
-    # ---- the MCTS template hooks of the reference (othelo_mcts.py:28-49,69-88).  The search itself runs in the library
-    # (k_select / k_expand_backup restate these per wavefront); the methods are kept for callers that use them directly.
+    # ---- the game hooks MCTS/__init__.py:86-166 declares abstract and othelo_mcts.py:28-49,69-88 fills in.  The search never calls
+    # them here (the kernels carry the rules); callers that use them directly get the LIBRARY's rules kernels through the C ABI
+    # (oz_rules_status / oz_rules_apply_moves / oz_rules_legal_moves on the packed board), i.e. the same bit-parallel code the search runs.
+    def _rules_status(self, state):
+        c0, c1 = (np.array([x], np.uint64) for x in _lib.pack_board(state))
+        fin, p0, p1, win = np.zeros(1, np.uint8), np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.int8)
+        _lib.check(_lib.load().oz_rules_status(_lib.p_u64(c0), _lib.p_u64(c1), self._board_size, 1, _lib.p_u8(fin), _lib.p_i32(p0),
+                                               _lib.p_i32(p1), _lib.p_i8(win)))
+        return bool(fin[0]), int(win[0])
+
+    def _legal_mask(self, own, opp):
+        legal = np.zeros(1, np.uint64)
+        _lib.check(_lib.load().oz_rules_legal_moves(_lib.p_u64(np.array([own], np.uint64)), _lib.p_u64(np.array([opp], np.uint64)),
+                                                    self._board_size, 1, _lib.p_u64(legal)))
+        return int(legal[0])
+
     def is_terminal_state(self, state):
-        return OthelloGame.has_board_finished(state)
+        return self._rules_status(state)[0]
 
     def get_state_reward(self, state):
-        return OthelloGame.get_board_winning_player(state)[0].value
+        return self._rules_status(state)[1]                    # +1: channel 0 holds at least as many discs (a draw counts for it), else -1
 
     def get_next_state(self, state, action):
-        board = np.copy(state)
-        OthelloGame.flip_board_squares(board, OthelloPlayer.BLACK, *action)
-        if OthelloGame.has_player_actions_on_board(board, OthelloPlayer.WHITE):
-            board = OthelloGame.invert_board(board)            # keep the mover in channel 0
-        return board
+        own, opp = _lib.pack_board(state)
+        sq = np.array([int(action[0]) * 8 + int(action[1])], np.uint8)
+        o2, p2 = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        _lib.check(_lib.load().oz_rules_apply_moves(_lib.p_u64(np.array([own], np.uint64)), _lib.p_u64(np.array([opp], np.uint64)), _lib.p_u8(sq),
+                                                    self._board_size, 1, _lib.p_u64(o2), _lib.p_u64(p2)))
+        own, opp = int(o2[0]), int(p2[0])
+        if self._legal_mask(opp, own):                         # the opponent can answer: it becomes the mover (channel 0); a pass keeps the orientation
+            own, opp = opp, own
+        return _lib.unpack_board(own, opp, self._board_size)
 
     def _neural_network_predict(self, state):
-        key = _lib.pack_board(state)                           # exact board equality, what hash(sha1(bytes)) stands for
-        cache = self.__dict__.setdefault("_predict_cache", {})
-        if key not in cache:
-            if self._one_channel:
-                state = OthelloGame.convert_to_one_channel_board(state)
-            cache[key] = self._neural_network.predict(state)
-        return cache[key]
+        """one evaluation per distinct board of this search (the reference's per-instance dict, keyed by the exact board)"""
+        seen = self.__dict__.setdefault("_predict_cache", {})
+        key = _lib.pack_board(state)
+        hit = seen.get(key)
+        if hit is None:
+            hit = seen[key] = self._neural_network.predict(OthelloGame.convert_to_one_channel_board(state) if self._one_channel else state)
+        return hit
 
     def get_state_value(self, state):
         return self._neural_network_predict(state)[1]
 
-    def get_state_actions_propabilities(self, state):
+    def get_state_actions_propabilities(self, state):          # (sic: the reference's spelling)
         return self._neural_network_predict(state)[0]
 
     def _mask_valid_moves(self, state):
-        board_mask = np.zeros((self._board_size, self._board_size))
-        for row, col in self.get_state_actions(state):
-            board_mask[row, col] = 1
-        return board_mask
+        n = self._board_size
+        legal = self._legal_mask(*_lib.pack_board(state))
+        return np.array([[(legal >> (r * 8 + c)) & 1 for c in range(n)] for r in range(n)], dtype=np.float64)
 
     def moves_scaled_by_valid_moves(self, state):
         return self.get_state_actions_propabilities(state) * self._mask_valid_moves(state)

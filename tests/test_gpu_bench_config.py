@@ -137,10 +137,40 @@ def test_network_at_the_timed_shape_vs_float64_oracle(oz, precision):
     rows_full = net.conv3_tile_rows()
     if precision == "f16x2":
         assert (rows_cap, rows_full) == (256, 192)                       # the capped call IS the timed kernel; the full call is the other tile
+    else:
+        # exact fp32: the library reports what oz_gemm_f32_launch really launched -- k_gemm_f32<GmBig>, the 256 x 256 tile, for every
+        # call of a max_batch = 4096 network (the tile is keyed on the capacity, not on the size of a call)
+        assert (rows_cap, rows_full) == (256, 256)
     assert np.array_equal(p4.reshape(B, -1)[:cap], pi) and np.array_equal(v4[:cap], v)
     # the last rows of the call sit in the partly filled last row tile (3640 * 36 = 511.9 tiles of 256 rows)
     tail = np.abs(pi[-8:] - pi64[cap - 8:cap]).max()
     assert tail <= TOL
+
+
+def test_f32_big_tile_bit_identical_to_the_standard_tile(oz):
+    """precision f32: the 256 x 256 tile of large batches (k_gemm_f32<GmBig>, the kernel behind value_exact_fp32) against the 128 x 128 tile
+    every other layer and mode runs on (OZ_NET_OPT_F32_STD_TILE forces it): both add every output element's products in the same order, so
+    (pi, v) must be BIT-identical -- at the timed shape (3640 positions) and on a full 4096-position call, 8x8 and 6x6.  Also the screen for
+    the LDS-DMA publication of both instantiations (a visibility race in one of them would show up as a mismatch)."""
+    from othellozero_amd.NNet import NNetWrapper
+    for n in (8, 6):
+        w, own, opp, pi64, v64 = _case(n)
+        net = NNetWrapper((n, n), num_channels_1=C, max_batch=B, weights=w, precision="f32")
+        for count in (3640, B):
+            net.set_option(oz.NET_OPT_F32_STD_TILE, 0)
+            pb, vb = net.predict_batch(own[:count], opp[:count])
+            assert net.conv3_tile_rows() == 256
+            net.set_option(oz.NET_OPT_F32_STD_TILE, 1)
+            ps, vs = net.predict_batch(own[:count], opp[:count])
+            assert net.conv3_tile_rows() == 128
+            assert np.array_equal(pb, ps) and np.array_equal(vb, vs), (n, count)
+            assert np.abs(pb.reshape(count, -1) - pi64[:count]).max() <= TOL and np.abs(vb - v64[:count]).max() <= TOL
+        net.set_option(oz.NET_OPT_F32_STD_TILE, 0)
+        # a one-position network reports the weight-stream kernel
+        one = NNetWrapper((n, n), num_channels_1=C, max_batch=1, weights=w, precision="f32")
+        one.predict_batch(own[:1], opp[:1])
+        assert one.conv3_tile_rows() == 64
+        del net, one
 
 
 def test_config5_real_networks_whole_games_vs_oracle(oz):

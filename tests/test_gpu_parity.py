@@ -511,8 +511,14 @@ def test_f16x2_range_guards_fail_loudly(oz):
         with pytest.raises(oz.OzError) as ei:                  # ... already on the calibration positions of the commit's self-check
             net.commit()
         assert ei.value.code == oz.OZ_ERR_STATE and "fell below" in str(ei.value)
+        assert net.self_check_guard() & 4 and net.self_check()[2] > 0      # the refusal left its measurement behind ...
+        net.set_option(oz.NET_OPT_SELF_CHECK, 2)               # "measure only" (ADVICE r4): the same commit succeeds, says what it saw,
+        net.commit()
+        assert net.self_check_guard() & 4 and net.self_check()[2] > 0 and net.self_check()[0] >= 0
+        assert oz.load().oz_net_check(net._h) == oz.OZ_OK       # ... and does not leave the device flag sticky
         net.set_option(oz.NET_OPT_SELF_CHECK, 0)               # without it the commit succeeds and the guard fires where positions are evaluated
         net.commit()
+        assert net.self_check_guard() == 0
         with pytest.raises(oz.OzError) as ei:
             net.predict_batch(own, opp)
         assert ei.value.code == oz.OZ_ERR_STATE and "fell below" in str(ei.value)
@@ -529,6 +535,17 @@ def test_f16x2_range_guards_fail_loudly(oz):
         assert np.array_equal(pi2, pi) and np.array_equal(v2, v)
     with pytest.raises(oz.OzError):
         NNetWrapper((8, 8), num_channels_1=128, precision="f16x2")       # needs channels % 256 == 0
+    # a refusal at commit on the path trained weights take (NNetWrapper.train -> set_weights(on_refusal="f32")): the wrapper warns and the
+    # network carries on in exact fp32 on the GPU instead of ending a long run
+    net = NNetWrapper((8, 8), num_channels_1=256, max_batch=4, weights=w, precision="f16x2")
+    net.set_option(oz.NET_OPT_LOW_GUARD_LOG2, 12)
+    with pytest.raises(oz.OzError):
+        net.set_weights(w)                                       # default: the caller decides
+    with pytest.warns(UserWarning, match="continues in precision f32"):
+        net.set_weights(w, on_refusal="f32")
+    assert net.precision == "f32" and oz.load().oz_net_get_precision(net._h) == 0
+    pi, v = net.predict_batch(own, opp)
+    assert np.abs(pi.reshape(4, -1) - pi64).max() <= 1e-5 and np.abs(v - v64).max() <= 1e-5
 
 
 @pytest.mark.parametrize("n,C_", [(8, 256), (6, 512)])
@@ -1121,6 +1138,14 @@ def test_c_abi_exchange_step_over_rccl_on_one_rank(oz):
     assert rc == oz.OZ_ERR_ARG and "room" in lib.oz_last_error().decode() and written.value == 0 and cnt.tolist() == [more]
     exact, per = comm.gather_records(eng, max_records=more)       # exactly enough room
     assert exact.size == more
+    # a rank whose own arguments are bad still JOINS the pair all-gather (room = -2, "cannot take part") and fails afterwards, so that its
+    # peers fail with it instead of blocking in the collective; the communicator stays usable
+    rc = lib.oz_selfplay_gather_records(eng._h, comm._h, -1, small.ctypes.data_as(C.c_void_p), small.size, C.byref(written), oz.p_i64(cnt))
+    assert rc == oz.OZ_ERR_ARG and "first_record" in lib.oz_last_error().decode() and written.value == 0
+    rc = lib.oz_selfplay_gather_records(eng._h, comm._h, 0, None, 5, C.byref(written), oz.p_i64(cnt))
+    assert rc == oz.OZ_ERR_ARG and "null output buffer" in lib.oz_last_error().decode()
+    again, per = comm.gather_records(eng, max_records=more)
+    assert again.tobytes() == exact.tobytes()
     comm.close()
 
 

@@ -1,5 +1,5 @@
 import sys, os, time, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from othellozero_amd.NNet import NNetWrapper
 for prec in ("f16x2", "f32"):
     net = NNetWrapper((8, 8), num_channels_1=512, max_batch=1, seed=0, precision=prec)
