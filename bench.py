@@ -349,14 +349,22 @@ def run_rank(args, rank, world, local_rank, t_proc):
     vec = torch.tensor([d["expansions"], d["simulations"], d["games_completed"], d["moves"], d["node_visits"]],
                        dtype=torch.float64, device=dev)
     tmax = torch.tensor([dt, gather_ms], dtype=torch.float64, device=dev)
-    per_rank = torch.zeros(world, dtype=torch.float64, device=dev)           # records every rank contributed to the pool
-    per_rank[rank] = float(local_records.shape[0])
+    # per rank: records contributed to the pool, its OWN time of the timed steps (before the gather: t_g - t0), its own gather time, its own
+    # expansions -- so that the first real multi-GPU run shows skew between the ranks, not just a sum and a maximum
+    per_rank = torch.zeros((4, world), dtype=torch.float64, device=dev)
+    per_rank[0, rank] = float(local_records.shape[0])
+    per_rank[1, rank] = (t_g - t0) * 1e3 / args.steps
+    per_rank[2, rank] = gather_ms
+    per_rank[3, rank] = float(d["expansions"])
     if world > 1:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
     dt, gather_ms = (float(x) for x in tmax.tolist())
-    per_rank_records = [int(x) for x in per_rank.tolist()]
+    per_rank_records = [int(x) for x in per_rank[0].tolist()]
+    per_rank_step_ms = [float(x) for x in per_rank[1].tolist()]
+    per_rank_gather_ms = [float(x) for x in per_rank[2].tolist()]
+    per_rank_expansions = [int(x) for x in per_rank[3].tolist()]
     if sum(per_rank_records) != int(pooled.shape[0]):                        # the all-gather lost or duplicated records: not a result
         print(f"bench.py: rank {rank}: pooled {int(pooled.shape[0])} records, the ranks contributed {per_rank_records} (sum {sum(per_rank_records)})",
               file=sys.stderr, flush=True)
@@ -402,6 +410,10 @@ def run_rank(args, rank, world, local_rank, t_proc):
             "games_completed": int(games_all), "expansions": int(exp_all), "simulations": int(sims_all),
             "expansions_per_sim": exp_all / max(sims_all, 1), "node_visits_per_sim": visits_all / max(sims_all, 1),
             "pooled_records": int(pooled.shape[0]), "per_rank_records": per_rank_records, "gather_ms": gather_ms,
+            "per_rank": {"ms_per_step": per_rank_step_ms, "ms_per_step_min": min(per_rank_step_ms), "ms_per_step_max": max(per_rank_step_ms),
+                         "gather_ms": per_rank_gather_ms, "expansions": per_rank_expansions,
+                         "note": "each rank's own wall time of the timed steps before the exchange step (ms_per_step above is the max over ranks of "
+                                 "steps + gather + closing barrier), its own time in the exchange step, its own expansions"},
             "gather_note": "the path's one exchange step, inside the timed region: counts all-gather + one padded all-gather of 48-byte move "
                            "records copied device to device out of each engine's HBM buffer (max over ranks; pooled == sum of per_rank checked)",
             "slot_ply_spread_rank0": [int(ply_now.min()), int(ply_now.max())],
@@ -425,13 +437,29 @@ def run_rank(args, rank, world, local_rank, t_proc):
                                "fp32 values carried as two fp16 planes, 3 fp16 MFMA products per fp32 product, fp32 accumulate; pi, v within 1e-5 of float64")
         wall = {"setup_s": round(t_setup, 2), "stagger_s": round(t_stagger, 2), "timed_region_s": round(dt, 2)}      # where this process's wall time goes
         out["wall_breakdown"] = wall
+        # what THIS device's matrix pipes sustain right now, measured right after the timed region: a pure-MFMA loop (no LDS, no loads, no barriers) per
+        # instruction the two precisions run on.  The GEMM kernels' rate moves with it from box to box (and with a power cap), so a reader can
+        # tell a slow box from a regression: roofline.achieved x 3 / device_calibration.f16.tflops is the kernel's share of what the pipe gives HERE.
+        try:
+            cal = {k: _lib.mfma_rate(k, 50.0) for k in ("f16", "f32")}
+            out["device_calibration"] = {
+                "f16": {"instruction": "v_mfma_f32_16x16x32_f16, operands with busy mantissas in [2^-3, 2^-2)", "sustained_tflops": cal["f16"]["tflops"],
+                        "clock_ghz_at_back_to_back_issue": cal["f16"]["clock_ghz"], "ms": cal["f16"]["ms"], "nominal_peak_tflops": 2500.0},
+                "f32": {"instruction": "v_mfma_f32_32x32x2_f32", "sustained_tflops": cal["f32"]["tflops"],
+                        "clock_ghz_at_back_to_back_issue": cal["f32"]["clock_ghz"], "ms": cal["f32"]["ms"], "nominal_peak_tflops": 157.3},
+                "dominant_kernel_share_of_sustained": ((3.0 if args.precision == "f16x2" else 1.0) * achieved /
+                                                       max(cal["f16" if args.precision == "f16x2" else "f32"]["tflops"], 1e-9)),
+                "note": "oz_selftest_mfma_rate: one block per CU, one wave per SIMD, four independent accumulators back to back, ~50 ms each, rank 0, right "
+                        "after the timed region; roofline.peak stays the nominal figure of MI355X_MICROARCH.md"}
+        except Exception as e:                                   # noqa: BLE001 -- a diagnostic, never a reason to lose the line
+            out["device_calibration"] = {"error": repr(e)}
         # ---- everything else of the line is measured AFTER the timed region, on fresh engines (bench_legs.py): kernels[] against their own roofs,
         # roofline.traffic from PMC child runs, the parity sample of both precisions, cross_game_dedup / eval_cache / other_driver /
         # all_layers_as_gemm, exact_fp32 (also as top-level value_exact_fp32 ...), config4 (6x6), config5 (BASELINE configs[4], whole games),
         # dropin_config0, cpu_baseline
         if world == 1:
             run_secondary(dict(args=args, out=out, wall=wall, world=world, net=net, eng=eng, make_engine=make_engine, measure=measure, advance=advance,
-                               layer=layer, n=n, G=G, cap_main=cap_main, d=d, dom_launches=dom_launches, flop_ref=flop_ref))
+                               layer=layer, n=n, G=G, cap_main=cap_main, d=d, dom_launches=dom_launches, flop_ref=flop_ref, batch_cap=batch_cap))
             del eng
         # the whole metric once more as the LAST key of the line: a reader (or a log) that keeps only the tail of stdout still sees it
         out["headline"] = {"node_expansions_per_s": out["value"], "games_per_s": out["games_per_s"], "sims_per_s": out["sims_per_s"],

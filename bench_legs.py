@@ -180,14 +180,44 @@ def _cpu_model():
         return ""
 
 
-def host_threads():
-    """the host threads this process may use: its CPU affinity / cgroup share, at most the 16 a one-GPU box gives"""
+GPU_BOX_CPU_SHARE_PER_GPU = 16     # the pool's stated CPU share of a one-GPU box ("size worker pools to the box's CPU share: 16 for one GPU")
+
+
+def host_cpu_share():
+    """the host threads this process may use, and why: its scheduler affinity, its cgroup CPU quota (cpu.max), what OpenMP would start --
+    the CPU legs use the smallest of them; only when NEITHER the affinity nor the cgroup says less than the whole host (the GPU boxes show all
+    256 CPUs of the node to every lease) the pool's stated share per GPU caps it.  Returned with every CPU baseline (`host_share`)."""
     import oracle
     try:
-        avail = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
-    return max(1, min(oracle.lib().orc_nn_max_threads(), avail, 16))
+        affinity = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            parts = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    quota = float(parts[0]) / float(parts[1])
+            else:
+                q = float(parts[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    omp = int(oracle.lib().orc_nn_max_threads())
+    limits = [affinity, omp] + ([max(1, int(quota))] if quota else [])
+    used, rule = max(1, min(limits)), "min(sched_getaffinity, cgroup cpu.max, OpenMP max threads)"
+    if affinity >= (os.cpu_count() or 1) and not quota and used > GPU_BOX_CPU_SHARE_PER_GPU:
+        used, rule = GPU_BOX_CPU_SHARE_PER_GPU, (f"neither the affinity mask nor a cgroup quota restricts this process (all {affinity} host CPUs visible): "
+                                                 f"the pool's stated share of {GPU_BOX_CPU_SHARE_PER_GPU} CPUs per GPU")
+    return {"threads_used": used, "sched_getaffinity": affinity, "cgroup_cpu_quota": quota, "openmp_max_threads": omp,
+            "host_cpus": os.cpu_count(), "rule": rule}
+
+
+def host_threads():
+    return host_cpu_share()["threads_used"]
 
 
 def cpu_baseline(n, channels, sims, budget_s=12.0):
@@ -220,6 +250,7 @@ def cpu_baseline(n, channels, sims, budget_s=12.0):
         "sample": f"{plies} plies of {games} sequential {n}x{n} game(s) at {sims} sims/move "
                   f"({exp} expansions, {plies * sims} sims, {t:.1f} s), batch-1 leaf eval, OpenMP x{threads} inside every evaluation",
         "sims_per_s": plies * sims / t, "games_per_s": games / t, "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
+        "host_share": host_cpu_share(),
     }
     # ---- one game per thread, all the host threads this process has: every thread its own tree and its own single-threaded evaluator
     nets1 = [oracle.CNet(w, n, channels=channels, nthreads=1) for _ in range(threads)]
@@ -307,7 +338,7 @@ def dropin_config0(channels, precision):
     t_gpu = time.perf_counter() - t0
     moves = len(ex) // 8
     w = init_weights(n, seed=0, channels=channels)
-    threads = min(oracle.lib().orc_nn_max_threads(), 16)
+    threads = host_threads()
     cnet = oracle.CNet(w, n, channels=channels, nthreads=threads)
     m = oracle.Mcts(n, 1.0, oracle.QMODE_F64, evaluator=cnet.evaluator())
     t0 = time.perf_counter()
@@ -432,10 +463,19 @@ def config5_arena(channels, precision, plies=0, games=512, sims=800, sample=2, d
     n = 8
     nets = [NNetWrapper((n, n), num_channels_1=channels, max_batch=games, seed=sd, precision=precision) for sd in (0, 1)]
     arena_batch(nets[0], nets[1], n, games, 8, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=2)      # untimed: allocation, code load
-    # headline of the leg: every expansion evaluated by itself (cross-game de-duplication off, as in the self-play headline)
+    # headline of the leg: every expansion evaluated by itself (cross-game de-duplication off, as in the self-play headline); HIP events
+    # around the dominant launch of both networks (conv3) ride along: two events per simulation step, the same instrumentation as the
+    # self-play timed region
+    for nt in nets:
+        nt.profile_kernels(reset=True); nt.profile(1)
     t0 = time.perf_counter()
     r = arena_batch(nets[0], nets[1], n, games, sims, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=plies, dedup=False)
     dt = time.perf_counter() - t0
+    dom = [nt.profile_read() for nt in nets]
+    dom_layer = nets[0].profiled_layer()
+    conv3_rows = nets[0].conv3_tile_rows()
+    for nt in nets:
+        nt.profile(0)
     # the library default (on) -- arena games start from ONE opening and play deterministically, so most expansions of a step share a board --
     # on the opening plies, against the same plies of the run above
     t0 = time.perf_counter()
@@ -467,6 +507,35 @@ def config5_arena(channels, precision, plies=0, games=512, sims=800, sample=2, d
             ok = ok and bool(o["finished"]) and int(r["winner"][gi]) == int(o["winner"]) and int(r["points"][gi]) == int(o["points"])
         bad += 0 if ok else 1
     whole = plies <= 0
+    # ---- the regime in kernels: a network batch holds the leaves of ONE agent's movers (<= `games`), so every GEMM runs far below the shapes
+    # of the self-play line -- roofline of the dominant launch from the timed run above, kernels[] from a bounded run of `kernel_plies` plies
+    # with events around every launch of both networks and both searches (events between ~12 launches per 0.4 ms step are not free: the
+    # timed run above carries only the two around conv3)
+    dom_ms, dom_launches = dom[0][0] + dom[1][0], dom[0][1] + dom[1][1]
+    leaves = int(r["leaves_evaluated"])
+    ach = leaves * conv_flop_per_leaf(dom_layer, n, channels) / max(dom_ms * 1e-3, 1e-9) / 1e12
+    roof = roofline(precision, dom_layer, ach, dom_ms, dom_launches, leaves, n, channels, conv3_rows=conv3_rows)
+    roof["traffic"], roof["traffic_source"] = None, "not measured at this launch shape"
+    roof["leaves_per_launch"] = leaves / max(dom_launches, 1)
+    roof["grid_note"] = (f"{leaves / max(dom_launches, 1):.0f} leaves per launch = {leaves / max(dom_launches, 1) * (n - 2) ** 2:.0f} rows on {conv3_rows}-row tiles: "
+                         f"{-(-int(leaves / max(dom_launches, 1) * (n - 2) ** 2) // conv3_rows) * (channels // 256)} blocks on 256 CUs, one k-slice each")
+    kernel_plies = 4
+    for nt in nets:
+        nt.profile_kernels(reset=True); nt.profile(2)
+    rk = arena_batch(nets[0], nets[1], n, games, sims, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=kernel_plies, dedup=False, profile=True)
+    net_k = {}
+    for nt in nets:
+        for name, (ms, cnt) in nt.profile_kernels().items():
+            a0 = net_k.setdefault(name, [0.0, 0])
+            a0[0] += ms; a0[1] += cnt
+        nt.profile(0)
+    steps_k = kernel_plies * sims
+    stk = rk["stats_black"] + rk["stats_white"]
+    ktab = kernel_table({k: tuple(v) for k, v in net_k.items()}, rk["tree_kernels"], steps_k, int(rk["leaves_evaluated"]), int(stk[0]), n, channels,
+                        precision, dom_layer == 3)
+    for row in ktab:                                            # a "step" of this table is ONE simulation step (one network batch), not 100 of them
+        row["us_per_sim_step"] = row.pop("ms_per_step") * 1e3
+        row["launches_per_sim_step"] = row.pop("launches_per_step")
     out = {"workload": f"BASELINE configs[4]: {games} parallel 8x8 arena games, {sims} sims/move per agent, two {channels}-filter OthelloNN "
                        f"(random init, seeds 0 / 1), temperature 0, deterministic; " + ("every game played to the end" if whole else f"first {plies} plies of every game"),
            "seconds": dt, "games": games, "games_finished": int((r["n_moves"] > 0).sum()) if whole else 0, "moves": moves,
@@ -477,6 +546,10 @@ def config5_arena(channels, precision, plies=0, games=512, sims=800, sample=2, d
            "with_cross_game_dedup": {"plies": dedup_compare_plies, "seconds": dtd, "sims_per_s": float(rd["stats_black"][0] + rd["stats_white"][0]) / dtd,
                                      "leaves_evaluated": int(rd["leaves_evaluated"]), "identical_moves_on_those_plies": same,
                                      "note": "library default: a board several games reach in one step is evaluated once (timed on the opening plies only)"},
+           "us_per_sim_step": dt / max(moves / games * sims, 1) * 1e6,
+           "roofline": roof, "kernels": ktab,
+           "kernels_note": f"HIP events around every launch of both networks and both searches over the first {kernel_plies} plies of a second run "
+                           "(per simulation step = one network batch of one agent); roofline.avg_launch_ms is from the timed whole-game run",
            "sample_games_replayed_by_oracle": sample, "sample_plies_replayed": replayed_plies, "sample_mismatches": bad,
            "oracle_replay_s": round(time.perf_counter() - t1, 2),
            "note": "oz_arena_run_rounds: BLACK movers search in net A's trees, WHITE movers in net B's, one searched ply per game and round; "
@@ -642,18 +715,56 @@ def run_secondary(ctx):
         out["roofline_exact_fp32_frac"] = out["exact_fp32"]["roofline"]["frac"]
         wall["exact_fp32_s"] = round(time.perf_counter() - t_sec, 2)
     if secondary and n == 8:
-        # ---- BASELINE configs[3]: 6x6 boards, same network family, same engine
+        # ---- BASELINE configs[3]: 6x6 boards, same network family, same engine -- with its own roofline (dominant launch: conv3 of the 6x6
+        # network on the 256-row tile), kernels[], parity sample (both precisions, same rows) and exact-fp32 rate
         t_sec = time.perf_counter()
+        cap6 = ctx["batch_cap"](6, G) if "batch_cap" in ctx else 0
         net6 = NNetWrapper((6, 6), num_channels_1=args.channels, max_batch=G, seed=0, precision=args.precision)
         e6 = make_engine(args.dedup == "on", the_net=net6, board=6)
         e6.stagger(cheap_pre)
-        q6, dt6 = measure(e6, args.steps)
+        q6, dt6 = measure(e6, args.steps, net6)
+        ms6, l6 = net6.profile_read()
+        layer6 = net6.profiled_layer()
+        ach6 = q6["leaves_evaluated"] * conv_flop_per_leaf(layer6, 6, args.channels) / max(ms6 * 1e-3, 1e-9) / 1e12
+        roof6 = roofline(args.precision, layer6, ach6, ms6, l6, q6["leaves_evaluated"], 6, args.channels, conv3_rows=conv3_tile_rows(6, cap6 or G, args.channels))
+        roof6["traffic"], roof6["traffic_source"] = None, "not measured for the 6x6 network"
+        roof6["leaves_per_launch"] = q6["leaves_evaluated"] / max(l6, 1)
         out["config4"] = {
             "workload": f"{G} concurrent 6x6 self-play games, {args.sims} sims/move (BASELINE configs[3])",
             "value": q6["expansions"] / dt6, "unit": "node-expansions/s", "ms_per_step": dt6 / args.steps * 1e3,
             "games_per_s": q6["games_completed"] / dt6, "sims_per_s": q6["simulations"] / dt6,
-            "flop_per_expansion_reference": FLOP_PER_EXPANSION[6]}
+            "flop_per_expansion_reference": FLOP_PER_EXPANSION[6], "precision": args.precision, "roofline": roof6}
+        rounds6 = 2                                             # every kernel of a 6x6 step against its own roof, as for the headline
+        e6.profile(True); net6.profile(2)
+        e6.profile_read(reset=True); net6.profile_kernels(reset=True)
+        a6 = e6.stats()
+        advance(e6, rounds6, True)
+        b6 = e6.stats()
+        out["config4"]["kernels"] = kernel_table(net6.profile_kernels(), e6.profile_read(), rounds6, b6["leaves_evaluated"] - a6["leaves_evaluated"],
+                                                 b6["simulations"] - a6["simulations"], 6, args.channels, args.precision, layer6 == 3, args.driver)
+        e6.profile(False); net6.profile(0)
+        ps6 = None
+        if not args.no_cpu_baseline:
+            rep6, ps6 = parity_sample(net6, e6, 6, args.channels, G, check=256)
+            out["config4"]["parity_sample"] = rep6
         del e6, net6
+        if args.precision == "f16x2":
+            n32 = NNetWrapper((6, 6), num_channels_1=args.channels, max_batch=G, seed=0, precision="f32")
+            e632 = make_engine(args.dedup == "on", the_net=n32, board=6)
+            e632.stagger(cheap_pre)
+            steps632 = max(args.steps // 2, 1)
+            q632, dt632 = measure(e632, steps632, n32)
+            ms632, l632 = n32.profile_read()
+            lay632 = n32.profiled_layer()
+            a632 = q632["leaves_evaluated"] * conv_flop_per_leaf(lay632, 6, args.channels) / max(ms632 * 1e-3, 1e-9) / 1e12
+            r632 = roofline("f32", lay632, a632, ms632, l632, q632["leaves_evaluated"], 6, args.channels)
+            r632["traffic"], r632["traffic_source"] = None, "not measured for the 6x6 network"
+            out["config4"]["exact_fp32"] = {"value": q632["expansions"] / dt632, "unit": "node-expansions/s", "ms_per_step": dt632 / steps632 * 1e3,
+                                            "steps": steps632, "games_per_s": q632["games_completed"] / dt632, "dtype": "f32", "roofline": r632,
+                                            "conv3_tile_rows": n32.conv3_tile_rows()}
+            if ps6 is not None:
+                out["config4"]["exact_fp32"]["parity_sample"] = parity_rows(n32, ps6)
+            del e632, n32
         wall["config4_s"] = round(time.perf_counter() - t_sec, 2)
     if secondary and n == 8 and not args.no_cpu_baseline:
         # ---- BASELINE configs[4]: arena evaluation with two real networks (bounded plies), sampled games replayed by the oracle

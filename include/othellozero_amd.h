@@ -325,6 +325,10 @@ int oz_arena_stats(oz_arena* a, int64_t* black5, int64_t* white5);
  * networks have evaluated so far (<= expansions when concurrent games share boards -- arena games start from one opening) */
 int oz_arena_set_dedup(oz_arena* a, int enable);
 int oz_arena_leaves_evaluated(oz_arena* a, int64_t* black, int64_t* white);
+/* HIP-event timing of the two agents' tree kernels on the launch stream, slots of oz_selfplay_profile (0 select 1 leaf compaction 2 evaluator = all
+ * network launches 3 expand + backup 4 move), summed over both searches; the networks' own kernels: oz_net_profile on net_a / net_b */
+int oz_arena_profile(oz_arena* a, int enable);
+int oz_arena_profile_read(oz_arena* a, double* ms_total /* [OZ_TREE_KERNELS] */, int64_t* launches /* [OZ_TREE_KERNELS] */, int reset);
 int oz_arena_results(oz_arena* a, int8_t* winner /* +1 net_a */, int32_t* points, int32_t* n_moves,
                      uint8_t* actions /* [num_games][128] */, int8_t* players /* [num_games][128] */,
                      uint64_t* final_black, uint64_t* final_white);

@@ -116,7 +116,7 @@ SIGNATURES = {
     "oz_selfplay_gather_records": [_vp, _vp, C.c_int64, _vp, C.c_int64, _i64p, _i64p],
     "oz_arena_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_uint64, _vp, _vp, C.c_int],
     "oz_arena_destroy": [_vp], "oz_arena_run": [_vp], "oz_arena_run_rounds": [_vp, C.c_int], "oz_arena_stats": [_vp, _i64p, _i64p],
-    "oz_arena_set_dedup": [_vp, C.c_int], "oz_arena_leaves_evaluated": [_vp, _i64p, _i64p],
+    "oz_arena_set_dedup": [_vp, C.c_int], "oz_arena_profile": [_vp, C.c_int], "oz_arena_profile_read": [_vp, _f64p, _i64p, C.c_int], "oz_arena_leaves_evaluated": [_vp, _i64p, _i64p],
     "oz_arena_results": [_vp, _i8p, _i32p, _i32p, _u8p, _i8p, _u64p, _u64p],
     "oz_examples_expand": [_vp, C.c_int64, C.c_int, C.c_int, _u8p, _i32p, _i8p],
     "oz_symmetry_table": [C.c_int, _i32p],

@@ -74,13 +74,14 @@ def duel_between_agents(game, agent_1, agent_2):
 
 
 def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, degree_exploration=1.0, seed=0,
-                first_game_id=0, q_mode=_lib.QMODE_F64, node_cap=0, max_rounds=0, dedup=True):
+                first_game_id=0, q_mode=_lib.QMODE_F64, node_cap=0, max_rounds=0, dedup=True, profile=False):
     """num_games games of net_a (BLACK) vs net_b (WHITE), temperature 0, max-visit ties broken by the RNG_TIE
     stream keyed (seed, game id, ply).  One of the two may be None: RandomOthelloAgent plays that colour.
     max_rounds > 0 stops after that many plies per game (unfinished boards: winner / points then describe the position reached).
     Returns dict(winner (+1 = BLACK's agent), points, n_moves, actions, players, final boards, stats_black / stats_white =
     the two agents' search counters [simulations, node visits, expansions, terminal hits, fallbacks], leaves_evaluated = positions the
-    networks evaluated: fewer than the expansions with dedup=True (the default), where a board several games reach in one step is evaluated once)."""
+    networks evaluated: fewer than the expansions with dedup=True (the default), where a board several games reach in one step is evaluated once;
+    tree_kernels = {slot: (ms, launches)} of both searches' tree kernels with profile=True, else None)."""
     lib = _lib.require_gpu()
     h = C.c_void_p()
     _lib.check(lib.oz_arena_create(C.byref(h), board_size, num_games, num_simulations, float(degree_exploration), q_mode,
@@ -89,7 +90,14 @@ def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, 
     try:
         if not dedup:                                        # every expansion evaluated by itself (identical results; bench.py's config5 headline)
             _lib.check(lib.oz_arena_set_dedup(h, 0))
+        if profile:                                          # HIP events around the tree kernels of both searches (bench.py's config5 kernels[])
+            _lib.check(lib.oz_arena_profile(h, 1))
         _lib.check(lib.oz_arena_run_rounds(h, int(max_rounds)))
+        tree = None
+        if profile:
+            ms, cnt = np.zeros(len(_lib.TREE_KERNELS), np.float64), np.zeros(len(_lib.TREE_KERNELS), np.int64)
+            _lib.check(lib.oz_arena_profile_read(h, _lib.p_f64(ms), _lib.p_i64(cnt), 0))
+            tree = {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.TREE_KERNELS)}
         G = num_games
         sa, sb = np.zeros(5, np.int64), np.zeros(5, np.int64)
         _lib.check(lib.oz_arena_stats(h, _lib.p_i64(sa), _lib.p_i64(sb)))
@@ -103,4 +111,4 @@ def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, 
     finally:
         lib.oz_arena_destroy(h)
     return dict(winner=winner, points=points, n_moves=nm, actions=acts, players=pls, final_black=fb, final_white=fw,
-                stats_black=sa, stats_white=sb, leaves_evaluated=ea.value + eb.value)
+                stats_black=sa, stats_white=sb, leaves_evaluated=ea.value + eb.value, tree_kernels=tree)

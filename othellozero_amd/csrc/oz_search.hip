@@ -1669,6 +1669,27 @@ OZ_API int oz_arena_set_dedup(oz_arena* a, int enable) {
     a->mb->d.dedup = enable ? 1 : 0;
     return OZ_OK;
 }
+// HIP-event timing of both agents' tree kernels (slots of oz_selfplay_profile; the sums of the two searches)
+OZ_API int oz_arena_profile(oz_arena* a, int enable) {
+    OZ_REQUIRE(a, "null arena");
+    std::lock_guard<std::mutex> lk(a->mu);
+    a->games.m->profile = enable != 0;
+    a->mb->profile = enable != 0;
+    return OZ_OK;
+}
+OZ_API int oz_arena_profile_read(oz_arena* a, double* ms_total, int64_t* launches, int reset) {
+    OZ_REQUIRE(a, "null arena");
+    std::lock_guard<std::mutex> lk(a->mu);
+    hipSetDevice(a->games.m->device);
+    oz_mcts* both[2] = {a->games.m, a->mb};
+    for (oz_mcts* m : both) if (int rc = mcts_collect_eval_time(m)) return rc;
+    for (int i = 0; i < OZ_TREE_KERNELS; ++i) {
+        if (ms_total) ms_total[i] = both[0]->timer.ms[i] + both[1]->timer.ms[i];
+        if (launches) launches[i] = both[0]->timer.count[i] + both[1]->timer.count[i];
+    }
+    if (reset) for (oz_mcts* m : both) m->timer.reset();
+    return OZ_OK;
+}
 // positions the two agents' networks have evaluated so far (<= expansions when boards are shared between games)
 OZ_API int oz_arena_leaves_evaluated(oz_arena* a, int64_t* black, int64_t* white) {
     OZ_REQUIRE(a && black && white, "null argument");
@@ -1729,8 +1750,14 @@ OZ_API int oz_arena_run_rounds(oz_arena* a, int max_rounds_arg) {
             if (!rc) rc = mcts_steps_close(mb);
         }
         if (rc) break;
-        if (run_a) hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, ma->d, 1);
-        if (run_b) hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, mb->d, 1);
+        {
+            const long long ta = (run_a && ma->profile) ? ma->timer.begin(TS_MOVE, s) : -1;
+            if (run_a) hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, ma->d, 1);
+            ma->timer.end(ta, s);
+            const long long tb = (run_b && mb->profile) ? mb->timer.begin(TS_MOVE, s) : -1;
+            if (run_b) hipLaunchKernelGGL(k_sp_move, dim3(G), dim3(64), 0, s, sp->gm, mb->d, 1);
+            mb->timer.end(tb, s);
+        }
         if (hipGetLastError() != hipSuccess) { oz_set_error("arena kernel launch failed"); rc = OZ_ERR_HIP; break; }
         if ((round & 3) == 3 || round + 1 == max_rounds) {
             if ((rc = check_error_flag(ma))) break;

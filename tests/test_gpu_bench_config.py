@@ -191,6 +191,14 @@ def test_config5_real_networks_whole_games_vs_oracle(oz):
     # the leg's headline evaluates every expansion by itself; the library default shares boards between the games of a step -- same moves
     assert out["leaves_evaluated"] == out["expansions"]
     assert out["with_cross_game_dedup"]["identical_moves_on_those_plies"]
+    # round 5: the leg carries the regime's own roofline (conv3 at <= 512 leaves per launch, events in the timed run) and kernels[]
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["launches"] == out["simulations"] // 512 * 1 or rf["launches"] > 0
+    assert 0 < rf["frac"] < 1 and rf["leaves_per_launch"] <= 512 and rf["avg_launch_ms"] > 0
+    names = {k["name"] for k in out["kernels"]}
+    assert {"conv2", "conv3", "conv4", "fc1", "fc2", "heads", "select", "compact"} <= names
+    assert all(k["us_per_sim_step"] > 0 for k in out["kernels"])
+    assert abs(sum(k["us_per_sim_step"] for k in out["kernels"]) / out["us_per_sim_step"] - 1) < 0.6
     # the bounded form (quick looks) still says that it is bounded
     short = bench.config5_arena(C, "f16x2", plies=3, sample=1)
     assert short["plies_per_game"] == 3 and short["moves"] == 512 * 3 and short["sample_mismatches"] == 0 and "games_per_s" not in short
@@ -214,15 +222,16 @@ def test_network_at_bench_batch_gemm_form_vs_float64_oracle(oz, precision):
         assert np.array_equal(p1, pi) and np.array_equal(v1, v)          # documented bit-identical to mode 0
 
 
-@pytest.mark.parametrize("precision,dedup", [("f16x2", False), ("f16x2", True), ("f32", False)])
-def test_config2_real_network_search_replay(oz, precision, dedup):
-    """BASELINE configs[1] with the real network: 4096 concurrent 8x8 games x 100 sims/move x 2 move rounds on the
-    512-filter OthelloNN (max_batch 4096: the kernels bench.py times); 16 sampled games are replayed by the oracle's search
-    fed with the GPU network's own (pi, v) per position -- moves, boards and root visit counts must match bit for bit
-    (network rounding cannot excuse a divergent game), with the cross-game leaf de-duplication off (bench headline) and on"""
+@pytest.mark.parametrize("n,precision,dedup", [(8, "f16x2", False), (8, "f16x2", True), (8, "f32", False), (6, "f16x2", False), (6, "f32", False)])
+def test_config2_real_network_search_replay(oz, n, precision, dedup):
+    """BASELINE configs[1] (8x8) and configs[3] (6x6) with the real network: 4096 concurrent games x 100 sims/move x 2 move rounds on the
+    512-filter OthelloNN (max_batch 4096: the kernels bench.py times -- on 6x6 what its `config4` leg times); 16 sampled games are replayed by
+    the oracle's search (training.py:26-72, MCTS/__init__.py:30-84 restated) fed with the GPU network's own (pi, v) per position -- moves, boards
+    and root visit counts must match bit for bit (network rounding cannot excuse a divergent game), with the cross-game leaf de-duplication
+    off (bench headline) and on"""
     from othellozero_amd.NNet import NNetWrapper
     from othellozero_amd.training import SelfPlayEngine
-    n, G, sims, rounds = 8, B, 100, 2
+    G, sims, rounds = B, 100, 2
     net = NNetWrapper((n, n), num_channels_1=C, max_batch=G, seed=0, precision=precision)        # bench.py's network (seed 0)
     eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=0, q_mode=1, dedup=dedup)
     eng.run(1)

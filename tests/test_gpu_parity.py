@@ -1245,6 +1245,16 @@ def test_bench_single_rank_contract(tmp_path):
     assert out["roofline_exact_fp32_frac"] == e32["roofline"]["frac"]
     assert "measured in this run" in (e32["roofline"]["traffic_source"] or ""), e32["roofline"].get("live_traffic_error")
     assert out["config4"]["value"] > 0 and out["config4"]["games_per_s"] > 0
+    # round 5: the 6x6 config carries its own roofline (conv3 of the 6x6 network, HIP events in ITS timed steps), kernels[] and exact-fp32 rate
+    c4 = out["config4"]
+    assert c4["roofline"]["bound"] == "mfma" and c4["roofline"]["launches"] == 3 * 16 and 0 < c4["roofline"]["frac"] < 1 and c4["roofline"]["flop_per_leaf"] == 2 * 16 * 4608 * 512
+    assert {"conv3", "conv4", "fc1", "select"} <= {k["name"] for k in c4["kernels"]}
+    assert c4["exact_fp32"]["value"] > 0 and c4["exact_fp32"]["roofline"]["peak"] == 157.3
+    # ... the device calibration (what the matrix pipes of THIS box sustain) and the per-rank view of the timed region are in the line
+    cal = out["device_calibration"]
+    assert 500 < cal["f16"]["sustained_tflops"] < 2600 and 50 < cal["f32"]["sustained_tflops"] < 165 and 0 < cal["dominant_kernel_share_of_sustained"] < 1
+    pr = out["per_rank"]
+    assert len(pr["ms_per_step"]) == 1 and pr["ms_per_step_min"] == pr["ms_per_step_max"] <= out["ms_per_step"] and pr["expansions"] == [out["expansions"]]
     assert out["config"]["driver"] == "free" and out["other_driver"]["driver"] == "lockstep" and out["other_driver"]["value"] > 0
     names = [k["name"] for k in out["kernels"]]
     for k in ("conv2", "conv3", "conv4", "fc1", "fc2", "heads", "select", "compact", "expand_backup"):      # (free-running driver: moves ride in "select")
