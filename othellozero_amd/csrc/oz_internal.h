@@ -81,6 +81,7 @@ struct OzTimer {
 // kernels of one stream, so a lookup never sees a half-written entry; `stamp` arbitrates two inserts into one entry within a batch.
 // A position's (pi, v) does not depend on the batch it is evaluated in (oz_net.hip), so serving it from the cache changes no bit.
 #define OZ_EC_WAYS 4
+#define OZ_PREDICT_DIRECT 8
 struct EvalCacheDev {
     unsigned long long* keys = nullptr;     // [entries][2]
     float* pi = nullptr;                    // [entries][n2]
@@ -105,6 +106,13 @@ struct oz_net {
     float* p_out = nullptr;
     std::vector<uint64_t> h_in;
     std::vector<float> h_out;
+    // calls of at most OZ_PREDICT_DIRECT positions (the drop-in predict of ONE position, Net/NNet.py:70-87) move no buffer at all: the boards sit in
+    // pinned host memory the first kernel reads directly, (pi, v) are written by the heads kernel straight into pinned host memory, and the
+    // leaf count is a pointer into a device-resident table of constants -- the two staging copies were 7 us of blit kernels + their launches
+    // around an 80 us forward (round 5)
+    uint64_t* hp_in = nullptr;              // pinned host: own[OZ_PREDICT_DIRECT] | opp[OZ_PREDICT_DIRECT]
+    float* hp_out = nullptr;                // pinned host: pi[OZ_PREDICT_DIRECT][64] | v[OZ_PREDICT_DIRECT]
+    int* d_counts = nullptr;                // device: d_counts[i] = i, i = 0 .. OZ_PREDICT_DIRECT
     EvalCacheDev ec;         // oz_net_set_eval_cache; cleared whenever the weights change (oz_net_commit)
     void free_eval_cache() {
         if (!ec.buckets) return;
@@ -114,6 +122,7 @@ struct oz_net {
     }
     virtual ~oz_net() {
         if (p_in) { hipSetDevice(device); hipFree(p_in); hipFree(p_out); }
+        if (hp_in) { hipSetDevice(device); hipHostFree(hp_in); hipHostFree(hp_out); hipFree(d_counts); }
         free_eval_cache();
     }
     virtual int check() { return 0; }      // sticky device-side validity flags (f16x2 range)

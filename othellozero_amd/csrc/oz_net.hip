@@ -345,10 +345,17 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_f32(const float* __restri
     const long long total = (long long)(*d_count) * P * N;
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= total) return;
+    // the slices are ADDED in order s = 0, 1, 2, ... (bit-reproducible) but FETCHED 24 at a time: a thread's loop over `ksplit` slabs was a chain of
+    // dependent-looking L2 round trips -- 72 slabs of one position's conv3 took 18.9 us, twice the weight-stream kernel in front of it (round 5,
+    // rocprofv3 of predict(): tools/trace_gaps.py); the additions and their order are unchanged
     f32x4 a = *reinterpret_cast<const f32x4*>(partial + i);
-    for (int s = 1; s < ksplit; ++s) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(partial + (size_t)s * slab + i);
-        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    constexpr int RB = 24;                                   // slices in flight per thread (72 slabs of a one-position conv layer = three round trips)
+    for (int s0 = 1; s0 < ksplit; s0 += RB) {
+        f32x4 b[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) if (s0 + q < ksplit) b[q] = *reinterpret_cast<const f32x4*>(partial + (size_t)(s0 + q) * slab + i);
+#pragma unroll
+        for (int q = 0; q < RB; ++q) if (s0 + q < ksplit) { a[0] += b[q][0]; a[1] += b[q][1]; a[2] += b[q][2]; a[3] += b[q][3]; }
     }
     const int col = (int)(i % N);
     f32x4 r;
@@ -398,6 +405,8 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
             tile_rows = 64;
             hipLaunchKernelGGL(k_gemm_f32_skinny, dim3(N / SK_COLS, ks), dim3(256), 0, s, in, Wt, d_count, g.K, N, kb, partial, slab, g);
             const long long quads = (slab + 3) / 4;
+            // (round 5, measured and removed: one output per thread with all 72 slices in flight -- 6.1 against 6.6 us: a kernel of this kind is
+            //  launch + count + one round trip to the slabs + store ~ 5 us whatever the loop looks like; fewer launches is what is left)
             hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, partial, slab, ks, N, Pout, d_count, scale,
                                shift, relu, out);
             OZ_HIP(hipGetLastError());
@@ -530,13 +539,25 @@ __global__ __launch_bounds__(256) void k_heads_t(const float* __restrict__ f2 /*
     __shared__ __attribute__((aligned(16))) float xs[LP][512];
     __shared__ float part[4][LP][64];
     __shared__ float vpart_s[4][LP];
-    const int b0 = blockIdx.x * LP, lane = threadIdx.x & 63, w = threadIdx.x >> 6, count = *d_count;
+    const int b0 = blockIdx.x * LP, lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), count = *d_count;
     if (b0 >= count) return;
     const bool act = lane < A;
-    // this wave's first batch of weight rows is requested before the f2 rows are staged: the two round trips overlap
-    float wgt[32];
+    // wave-uniform row base (scalar registers) + ONE per-lane offset for all the loads below; lanes beyond the A policy columns read column 0
+    // (their sums are never used: no select behind every load, which doubled the registers of a batch)
+    // (buffer loads: ONE per-lane offset register + a scalar row offset per load.  With plain pointers the compiler kept a 64-bit address pair per load
+    //  in flight -- 256 registers for 128 loads, and spilled.)
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wpi + (size_t)w * 128 * A), 0, 128 * A * 4, 0x00020000);
+    const int lo = (act ? lane : 0) * 4;
+    // the small operands of the tail (value weights, biases) are requested here, with the first batch: every dependent round trip of this one-
+    // block-per-few-positions kernel is ~1.5 us of its launch
+    const float wv0 = Wv[w * 128 + lane * 2], wv1 = Wv[w * 128 + lane * 2 + 1];
+    const float bl = act ? bpi[lane] : 0.f, bvv = bv[0];
+    // this wave's first batch of weight rows is requested before the f2 rows are staged: the two round trips overlap.  WB rows per batch:
+    // 64 on the latency path (two round trips), 32 for batches of 16 positions (registers)
+    constexpr int WB = LP <= 8 ? 64 : 32;
+    float wgt[WB];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) wgt[j] = act ? Wpi[(size_t)(w * 128 + j) * A + lane] : 0.f;
+    for (int j = 0; j < WB; ++j) wgt[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, lo, j * A * 4, 0));
     for (int q = threadIdx.x; q < LP * 128; q += 256) {                 // 16-byte pieces; rows beyond the batch repeat the last one (never stored)
         const int p = q >> 7, c4 = (q & 127) * 4;
         *reinterpret_cast<f32x4*>(&xs[p][c4]) = *reinterpret_cast<const f32x4*>(f2 + (size_t)(b0 + p < count ? b0 + p : count - 1) * 512 + c4);
@@ -546,16 +567,16 @@ __global__ __launch_bounds__(256) void k_heads_t(const float* __restrict__ f2 /*
 #pragma unroll
     for (int p = 0; p < LP; ++p) { logit[p] = 0.f; vp[p] = 0.f; }
 #pragma unroll 1
-    for (int i0 = 0; i0 < 128; i0 += 32) {                   // (rolled, with scheduling fences per position: fully unrolled the compiler hoisted every
-        float nxt[32];                                       //  LDS read of the loop to the top -- 512 VGPRs and 6 KB of scratch per thread, 64 us per launch)
-        const bool more = i0 + 32 < 128;
+    for (int i0 = 0; i0 < 128; i0 += WB) {                   // (rolled, with scheduling fences per position: fully unrolled the compiler hoisted every
+        float nxt[WB];                                       //  LDS read of the loop to the top -- 512 VGPRs and 6 KB of scratch per thread, 64 us per launch)
+        const bool more = i0 + WB < 128;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) nxt[j] = (act && more) ? Wpi[(size_t)(w * 128 + (more ? i0 + 32 : 0) + j) * A + lane] : 0.f;
+        for (int j = 0; j < WB; ++j) nxt[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, lo, ((more ? i0 + WB : 0) + j) * A * 4, 0));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < LP; ++p) {
 #pragma unroll
-            for (int j4 = 0; j4 < 32; j4 += 4) {
+            for (int j4 = 0; j4 < WB; j4 += 4) {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[p][w * 128 + i0 + j4]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) logit[p] = fmaf(x[j], wgt[j4 + j], logit[p]);
@@ -563,11 +584,11 @@ __global__ __launch_bounds__(256) void k_heads_t(const float* __restrict__ f2 /*
             if ((p & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int j = 0; j < 32; ++j) wgt[j] = nxt[j];
+        for (int j = 0; j < WB; ++j) wgt[j] = nxt[j];
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const float wv = Wv[w * 128 + lane * 2 + i];
+        const float wv = i == 0 ? wv0 : wv1;
 #pragma unroll
         for (int p = 0; p < LP; ++p) vp[p] = fmaf(xs[p][w * 128 + lane * 2 + i], wv, vp[p]);
     }
@@ -579,7 +600,6 @@ __global__ __launch_bounds__(256) void k_heads_t(const float* __restrict__ f2 /*
         if (lane == 0) vpart_s[w][p] = vp[p];
     }
     __syncthreads();
-    const float bl = act ? bpi[lane] : 0.f, bvv = bv[0];
 #pragma unroll
     for (int q = 0; q < LP / 4; ++q) {
         const int p = w * (LP / 4) + q;
@@ -1341,7 +1361,14 @@ struct OnnNet : oz_net {
             if (begin) tidx = timer.begin(slot, s);
             else { timer.end(tidx, s); tidx = -1; }
         };
-        if (use_t2f) {
+        if (use_t2f && max_batch <= 32 && C == 512) {
+            // few positions: pattern ids computed inside the gather (INLINE_IDS) -- one launch less
+            mark(1, true);
+            const unsigned blocks = 8u * (unsigned)(((long long)max_count * P + 32 * OZ_C2L_PPT - 1) / (32 * OZ_C2L_PPT));
+            if (n == 8) hipLaunchKernelGGL((k_conv2_lut_xcd<8, false, true>), dim3(blocks), dim3(256), 0, s, (const unsigned*)nullptr, d_count, d_t2, d_scale[1], d_shift[1], (void*)act2, (int*)nullptr, H2Low(), 0.f, d_own, d_opp);
+            else hipLaunchKernelGGL((k_conv2_lut_xcd<6, false, true>), dim3(blocks), dim3(256), 0, s, (const unsigned*)nullptr, d_count, d_t2, d_scale[1], d_shift[1], (void*)act2, (int*)nullptr, H2Low(), 0.f, d_own, d_opp);
+            mark(1, false);
+        } else if (use_t2f) {
             const long long cells = (long long)max_count * (n + 2) * (n + 2);
             mark(0, true);
             hipLaunchKernelGGL(k_lut_ids, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, d_lut_ids,
@@ -1635,6 +1662,38 @@ OZ_API int oz_net_predict(oz_net* net, const uint64_t* own, const uint64_t* opp,
     hipSetDevice(net->device);
     const int n2 = net->n * net->n;
     const size_t B = (size_t)net->max_batch;
+    if (count <= OZ_PREDICT_DIRECT) {
+        // few positions (the drop-in predict: one): no staging copies -- see oz_net::hp_in
+        if (!net->hp_in) {
+            hipError_t e;
+            int consts[OZ_PREDICT_DIRECT + 1];
+            for (int i = 0; i <= OZ_PREDICT_DIRECT; ++i) consts[i] = i;
+            if ((e = hipHostMalloc((void**)&net->hp_in, 8 * 2 * OZ_PREDICT_DIRECT, hipHostMallocDefault)) != hipSuccess ||
+                (e = hipHostMalloc((void**)&net->hp_out, 4 * OZ_PREDICT_DIRECT * 65, hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void**)&net->d_counts, sizeof consts)) != hipSuccess ||
+                (e = hipMemcpy(net->d_counts, consts, sizeof consts, hipMemcpyHostToDevice)) != hipSuccess) {
+                if (net->hp_in) hipHostFree(net->hp_in);
+                if (net->hp_out) hipHostFree(net->hp_out);
+                if (net->d_counts) hipFree(net->d_counts);
+                net->hp_in = nullptr; net->hp_out = nullptr; net->d_counts = nullptr;
+                oz_set_error("pinned staging allocation failed: %s", hipGetErrorString(e));
+                return OZ_ERR_HIP;
+            }
+        }
+        memcpy(net->hp_in, own, 8ull * count);
+        memcpy(net->hp_in + OZ_PREDICT_DIRECT, opp, 8ull * count);
+        float* h_pi = net->hp_out;
+        float* h_v = net->hp_out + (size_t)OZ_PREDICT_DIRECT * 64;
+        if (int rc = net->forward_device(net->hp_in, net->hp_in + OZ_PREDICT_DIRECT, net->d_counts + count, count, h_pi, h_v, 0)) return rc;
+        int flag = 0;
+        const int* fd = net->flag_device();
+        if (fd) OZ_HIP(hipMemcpyAsync(&flag, fd, sizeof(int), hipMemcpyDeviceToHost, 0));
+        hipError_t e = hipStreamSynchronize(0);
+        if (e != hipSuccess) { oz_set_error("forward failed: %s", hipGetErrorString(e)); return OZ_ERR_HIP; }
+        memcpy(pi, h_pi, 4ull * count * n2);
+        memcpy(v, h_v, 4ull * count);
+        return flag ? net->check() : OZ_OK;
+    }
     if (!net->p_in) {           // staging buffers live with the network
         hipError_t e;
         if ((e = hipMalloc((void**)&net->p_in, 8 * (2 * B + 1))) != hipSuccess || (e = hipMalloc((void**)&net->p_out, 4 * B * (n2 + 1))) != hipSuccess) {

@@ -201,10 +201,21 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_h2(const float* __restric
     const float* p = part + (size_t)m * N + c8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = p[j];
-    for (int s = 1; s < ksplit; ++s) {
-        const float* q = p + (size_t)s * slab;
+    // added in order s = 1, 2, ... (bit-reproducible), fetched four slices (8 x 16 B per thread) at a time: see k_splitk_reduce_f32
+    for (int s0 = 1; s0 < ksplit; s0 += 4) {
+        f32x4v b[4][2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += q[j];
+        for (int q = 0; q < 4; ++q)
+            if (s0 + q < ksplit) {
+                const f32x4v* src = reinterpret_cast<const f32x4v*>(p + (size_t)(s0 + q) * slab);
+                b[q][0] = src[0]; b[q][1] = src[1];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (s0 + q < ksplit) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[j] += b[q][0][j]; acc[j + 4] += b[q][1][j]; }
+            }
     }
     f16x8 h1, h2;
     bool over = false;
@@ -575,10 +586,31 @@ __device__ __forceinline__ bool c2l_finish(const f32x4& lo, const f32x4& hi, con
 // C = 512: block b works on slice b & 7 (its XCD's eighth of the table) for pixels [(b >> 3) * 32 * PPT, ...): a wave = 8 pixels x 8 lanes
 // (lane j of a pixel: channels 64 * slice + 8 j .. + 7, two 16-byte loads per tap), OZ_C2L_PPT pixel groups per thread.
 #define OZ_C2L_PPT 2
-template <int N, bool OUT_H2>
+// pattern id of cell (cy, cx) of an N x N board straight from the bitboards (k_lut_ids' arithmetic; off the board = the all-zero row)
+template <int N>
+__device__ __forceinline__ unsigned lut_id_of(uint64_t o, uint64_t p, int cy, int cx) {
+    if (cy < 0 || cy >= N || cx < 0 || cx >= N) return OZ_LUT_PATTERNS;
+    unsigned id = 0, pw = 1;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = cy + ky - 1, ix = cx + kx - 1;
+            if (iy >= 0 && iy < N && ix >= 0 && ix < N) {
+                const int bit = iy * 8 + ix;
+                id += pw * ((unsigned)((o >> bit) & 1) + 2u * (unsigned)((p >> bit) & 1));
+            }
+            pw *= 3;
+        }
+    return id;
+}
+// INLINE_IDS (few positions: the latency path of precision f32): the nine pattern ids of a pixel are computed from the bitboards here instead of
+// read from the padded id boards k_lut_ids writes -- one launch less in front of a forward that is all launch latency (same ids, same sums)
+template <int N, bool OUT_H2, bool INLINE_IDS = false>
 __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restrict__ ids, const int* __restrict__ d_count,
                                                        const float* __restrict__ T2, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       void* __restrict__ out, int* __restrict__ flag, H2Low low, float floor) {
+                                                       void* __restrict__ out, int* __restrict__ flag, H2Low low, float floor,
+                                                       const uint64_t* __restrict__ own = nullptr, const uint64_t* __restrict__ opp = nullptr) {
     constexpr int P = N * N, W = N + 2, PW = W * W, C = 512;
     const float relu_floor = OUT_H2 ? 0.f : floor;            // fp32 rows: 0 = ReLU, -inf = the BN output itself (calibration passes)
     const int slice = blockIdx.x & 7, j = threadIdx.x & 7;
@@ -594,10 +626,16 @@ __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restric
         const long long pixel = ((long long)(blockIdx.x >> 3) * OZ_C2L_PPT + k) * 32 + (threadIdx.x >> 3);
         if (pixel >= total) break;
         const int b = (int)(pixel / P), pix = (int)(pixel - (long long)b * P), y = pix / N, x = pix - y * N;
-        const unsigned* idp = ids + (size_t)b * PW + y * W + x;
         unsigned id[9];
+        if constexpr (INLINE_IDS) {
+            const uint64_t o = own[b], p = opp[b];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) id[t] = idp[(t / 3) * W + t % 3];
+            for (int t = 0; t < 9; ++t) id[t] = lut_id_of<N>(o, p, y + t / 3 - 1, x + t % 3 - 1);
+        } else {
+            const unsigned* idp = ids + (size_t)b * PW + y * W + x;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) id[t] = idp[(t / 3) * W + t % 3];
+        }
         f32x4 ra[9], rb[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
