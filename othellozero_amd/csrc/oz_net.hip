@@ -490,9 +490,16 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
     // Both add every output's products in the same order.
     auto tile_cost = [&](int bm) { return ((((Mmax + bm - 1) / bm) * (N / 256) + 255) / 256) * bm; };
     const bool mid = big && tile_cost(192) < tile_cost(256);
-    const int BM = mid ? 192 : big ? 256 : 128, BN = big ? 256 : 128;
+    // (round 5, measured and removed: a few 256 x 256 tiles with an 8 .. 16-way k split for launches of 8 .. 96 big tiles -- the trainer's GEMMs at the
+    //  reference's batch -- 45 us + a larger reduce against 40 us on the 128 x 128 tiles: 0.99 -> 1.04 ms per step)
+    const bool bigk = false;
+    const int BM = mid ? 192 : (big || bigk) ? 256 : 128, BN = (big || bigk) ? 256 : 128;
     const int num_mt = (int)((Mmax + BM - 1) / BM);
     int ksplit = 1;
+    if (bigk) {
+        const int nk = g.K / H2_BK;
+        while (ksplit < 16 && big_blocks * ksplit < 128 && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * Mmax * N <= partial_floats) ksplit *= 2;
+    } else
     if (!big && partial) {
         const long long blocks = (long long)num_mt * (N / BN);
         const int nk = g.K / H2_BK;
@@ -505,7 +512,7 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
     if (mid)
         hipLaunchKernelGGL(k_gemm_h2<H2MidPP>, dim3(grid), dim3(H2MidPP::NT), H2MidPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
                            d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
-    else if (big)
+    else if (big || bigk)
         hipLaunchKernelGGL(k_gemm_h2<H2BigPP>, dim3(grid), dim3(H2BigPP::NT), H2BigPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
                            d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
     else if (ksplit <= 4)

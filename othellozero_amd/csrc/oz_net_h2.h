@@ -138,6 +138,8 @@ typedef H2Cfg<1, 2, 2, 2> H2Thin2;    // 64 x 128, 2 waves, two stages
 // bit-identical results (tools/pp_race_check.py).  Measured: -4 .. -6 % per forward at 128 .. 512 positions, +-0 at 4096,
 // but SLOWER on the 16-way split-K launches of one-position networks (9 k-tiles per block) -- oz_net.hip picks per network.
 typedef H2Cfg<2, 2, 2, 2, 3> H2Small; // 128 x 128, 3 x 32 KB of LDS
+// (round 5, measured and removed: four stages -- three k-tiles in flight -- for the trainer's launches of 18 .. 36 k-tiles per block: 1.04-1.07 against
+//  0.98-1.00 ms per step at the reference's batch)
 typedef H2Cfg<1, 2, 2, 2, 3> H2Thin;  // dense layers (M = batch): 64 x 128, 2 waves -> 512 / 256 blocks at B = 4096; 3 x 24 KB
 // fc2 at large batches (one k-slice, 228 blocks of 32 k-tiles: at most one block per CU): the same 64 x 128 tile on FOUR waves of 32 x 64 --
 // every SIMD has a wave and the MFMA section of a k-tile halves.  Same accumulation order per output element as H2Thin: bit-identical.

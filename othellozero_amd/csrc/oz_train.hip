@@ -59,18 +59,27 @@ __global__ __launch_bounds__(256) void k_t_conv1_fwd(const uint64_t* __restrict_
     const int co = (int)(idx % Q) * 4;
     const int b = (int)(m / P), pix = (int)(m % P), y = pix / n, x = pix % n;
     const uint64_t o = own[b], p = opp[b];
+    // all 9 * cin weight vectors of this thread's four channels in flight at once (the tap loop with its border test was a chain of 18 dependent
+    // L2 round trips: 33 us per launch at the reference's batch, round 5); the products are added in the same tap / plane order, a tap outside
+    // the board is skipped as before
+    f32x4 w[18];                                            // [tap][plane]: static register indices whatever cin is
+#pragma unroll
+    for (int i = 0; i < 18; ++i) if ((i & 1) < cin) w[i] = *reinterpret_cast<const f32x4*>(W + (size_t)((i >> 1) * cin + (i & 1)) * C + co);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
         if (iy < 0 || iy >= n || ix < 0 || ix >= n) continue;
-        for (int ch = 0; ch < cin; ++ch) {
-            const float xv = t_plane(o, p, iy * 8 + ix, ch, cin);
-            const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)(t * cin + ch) * C + co);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = fmaf(xv, w[k], acc[k]);
+        for (int ch = 0; ch < 2; ++ch) {
+            if (ch >= cin) break;
+            const float xv = t_plane(o, p, iy * 8 + ix, ch, cin);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(xv, w[2 * t + ch][k], acc[k]);
         }
     }
-    *reinterpret_cast<f32x4*>(z + (size_t)m * C + co) = acc + *reinterpret_cast<const f32x4*>(bias + co);
+    *reinterpret_cast<f32x4*>(z + (size_t)m * C + co) = acc + bv;
 }
 
 // dW1[t][ch][co] = sum_m x[m shifted by t][ch] * dz[m][co]: ONE pass over dz -- a thread owns an output channel and keeps the
@@ -340,8 +349,9 @@ __global__ __launch_bounds__(128) void k_t_heads_wgrad(const float* __restrict__
 // dbpi[a] = sum_b dlogit[b][a]; dbv = sum_b dvpre[b]; losses[0..2] = total, pi, v (batch means)
 __global__ __launch_bounds__(128) void k_t_heads_bias(const float* __restrict__ dlogit, const float* __restrict__ dvpre, const float* __restrict__ loss,
                                                       const int* __restrict__ d_count, int A, float* __restrict__ dbpi, float* __restrict__ dbv,
-                                                      float* __restrict__ losses) {
+                                                      float* __restrict__ losses, unsigned* __restrict__ zero6 /* nullable: six words cleared here */) {
     const int a = threadIdx.x, B = *d_count;
+    if (zero6 && a >= 120 && a < 126) zero6[a - 120] = 0u;   // the per-layer |dz| maxima of the f16x2 mode (a 24-byte memset was two fill launches on the chain)
     if (a < A) { float s = 0.f; _Pragma("unroll 8") for (int b = 0; b < B; ++b) s += dlogit[(size_t)b * A + a]; dbpi[a] = s; }
     if (a == A) { float s = 0.f; _Pragma("unroll 8") for (int b = 0; b < B; ++b) s += dvpre[b]; dbv[0] = s; }
     if (a == A + 1) {
@@ -576,13 +586,25 @@ __global__ __launch_bounds__(256) void k_t_absmax(AbsMaxArgs a, unsigned* __rest
     const int l = blockIdx.y;
     const float* p = a.p[l];
     float m = 0.f;
-    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n[l]; i += (long long)gridDim.x * 1024) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
-        m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3]))));
-        if (v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3]) m = INFINITY;         // fmaxf drops NaNs: a NaN weight must not pass as finite
+    // twelve 16-byte loads in flight per trip (the one-load-per-trip loop took 40 us for 28 MB at the reference's batch, round 5)
+    const long long stride = (long long)gridDim.x * 1024;
+    for (long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i0 < a.n[l]; i0 += 12 * stride) {
+        f32x4 v[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) { const long long i = i0 + q * stride; v[q] = i < a.n[l] ? *reinterpret_cast<const f32x4*>(p + i) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            m = fmaxf(fmaxf(fabsf(v[q][0]), fabsf(v[q][1])), fmaxf(m, fmaxf(fabsf(v[q][2]), fabsf(v[q][3]))));
+            if (v[q][0] != v[q][0] || v[q][1] != v[q][1] || v[q][2] != v[q][2] || v[q][3] != v[q][3]) m = INFINITY;   // fmaxf drops NaNs: a NaN weight must not pass as finite
+        }
     }
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out + l, __float_as_uint(m));
+    // ONE atomic per block: an atomic on one address costs ~12 ns whoever issues it, and the 3072 per-wave atomics of this launch were its 40 us
+    // (round 5: the loads in flight changed nothing)
+    __shared__ float wmaxs[4];
+    if ((threadIdx.x & 63) == 0) wmaxs[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out + l, __float_as_uint(fmaxf(fmaxf(wmaxs[0], wmaxs[1]), fmaxf(wmaxs[2], wmaxs[3]))));
 }
 // power-of-two exponent that brings a tensor whose |maximum| has bit pattern max_bits to ~target; a non-finite maximum (a diverged
 // step) gives exponent 0 and t_bad_max() -- the converting kernels raise the sticky flag (bit 2) so that the step fails loudly
@@ -863,6 +885,8 @@ struct oz_trainer {
     uint64_t *d_own = nullptr, *d_opp = nullptr;
     float *d_pit = nullptr, *d_zt = nullptr;
     int* d_count = nullptr;
+    unsigned char *d_in = nullptr, *h_in = nullptr;      // the device block the five pointers above point into, and its pinned host mirror
+    size_t in_bytes = 0;
     float *z[6] = {}, *a[6] = {}, *mean[6] = {}, *rstd[6] = {}, *dz[6] = {};
     float *dA[2] = {}, *sums = nullptr, *partial = nullptr, *ones = nullptr, *zeros = nullptr;
     float *p = nullptr, *v = nullptr, *dlogit = nullptr, *dvpre = nullptr, *loss = nullptr, *losses = nullptr;
@@ -900,6 +924,7 @@ struct oz_trainer {
         if (s) hipStreamSynchronize(s);
         for (void* q : allocs) hipFree(q);
         for (void* q : {(void*)ds_own, (void*)ds_opp, (void*)ds_pi, (void*)ds_z, (void*)ds_order, (void*)ds_acc}) if (q) hipFree(q);
+        if (h_in) hipHostFree(h_in);
         for (hipEvent_t e : ev_dz) if (e) hipEventDestroy(e);
         if (ev_w) hipEventDestroy(ev_w);
         for (hipEvent_t e : {ev_pre, ev_wt, ev_wd}) if (e) hipEventDestroy(e);
@@ -981,8 +1006,16 @@ OZ_API int oz_trainer_create(oz_trainer** out, int n, int channels, int in_chann
         OZ_HIP(hipStreamSynchronize(t->s));
         for (int l = 1; l < 6; ++l) T_ALLOC(t->Wt[l], t->size[6 * l]);
         for (int l = 1; l < 4; ++l) T_ALLOC(t->Wd[l], t->size[6 * l]);
-        T_ALLOC(t->d_own, max_batch); T_ALLOC(t->d_opp, max_batch); T_ALLOC(t->d_pit, (size_t)max_batch * A); T_ALLOC(t->d_zt, max_batch);
-        T_ALLOC(t->d_count, 1);
+        // the inputs of a step live in ONE device block [own | opp | pi targets | z targets | count] mirrored by a pinned host block: the step-wise
+        // oz_trainer_forward_backward uploads it with one copy (five copies were five blit launches, ~30 us, in front of every step)
+        t->in_bytes = (size_t)max_batch * (8 + 8 + 4 * A + 4) + 16;
+        T_ALLOC(t->d_in, t->in_bytes);
+        OZ_HIP(hipHostMalloc((void**)&t->h_in, t->in_bytes, hipHostMallocDefault));
+        t->d_own = reinterpret_cast<uint64_t*>(t->d_in);
+        t->d_opp = t->d_own + max_batch;
+        t->d_pit = reinterpret_cast<float*>(t->d_opp + max_batch);
+        t->d_zt = t->d_pit + (size_t)max_batch * A;
+        t->d_count = reinterpret_cast<int*>(t->d_zt + max_batch);
         T_ALLOC(t->p, (size_t)max_batch * A); T_ALLOC(t->v, max_batch); T_ALLOC(t->dlogit, (size_t)max_batch * A); T_ALLOC(t->dvpre, max_batch);
         T_ALLOC(t->loss, 2 * (size_t)max_batch); T_ALLOC(t->losses, 4);
         T_ALLOC(t->gpartial, t->gpartial_floats);
@@ -1117,7 +1150,7 @@ static int t_refresh(oz_trainer* t) {
         OZ_HIP(hipMemsetAsync(t->wmax, 0, 3 * sizeof(unsigned), r));
         AbsMaxArgs am;
         for (int l = 1; l < 4; ++l) { am.p[l - 1] = t->param(6 * l); am.n[l - 1] = 9LL * C * C; }
-        hipLaunchKernelGGL(k_t_absmax, dim3(256, 3), dim3(256), 0, r, am, t->wmax);
+        hipLaunchKernelGGL(k_t_absmax, dim3(192, 3), dim3(256), 0, r, am, t->wmax);      // (12 x 16-byte loads per thread cover 9 x 512 x 512 floats in one trip)
         for (int l = 1; l < 4; ++l)
             hipLaunchKernelGGL(k_t_w_to_h2<0>, dim3(h2_blocks), dim3(256), 0, r, t->param(6 * l), C, C, t->wmax + (l - 1), t->Wh[l], t->wscale[l], t->h2flag);
         OZ_HIP(hipGetLastError());
@@ -1153,9 +1186,14 @@ static int t_reduce(oz_trainer* t, RedArgs r) {
 static int t_bn_forward(oz_trainer* t, int l, int B) {
     const int Cc = t->Co[l], P = t->P_[l];
     if ((long long)B * P <= OZ_BN_FUSED_MAX_ROWS) {      // small batch: the whole layer in one launch (oz_train_fused.h)
-        hipLaunchKernelGGL(k_t_bn_fwd_fused, dim3(Cc / OZ_BN_COLS), dim3(1024), 0, t->s, t->z[l], t->a[l], t->d_count, P, Cc, t->param(6 * l + 2),
-                           t->param(6 * l + 3), t->mean[l], t->rstd[l], t->stats[6 * l + 4], t->stats[6 * l + 5], t->stats_new[6 * l + 4],
-                           t->stats_new[6 * l + 5], t->mom, l < 4 ? 1 : 0, l >= 4 ? t->rate : 0.f, t->seed, (uint64_t)t->step, l - 4);
+        if ((long long)B * P <= 32 * OZ_BN_RL)
+            hipLaunchKernelGGL(k_t_bn_fwd_fused<32>, dim3(Cc / OZ_BN_COLS), dim3(1024), 0, t->s, t->z[l], t->a[l], t->d_count, P, Cc, t->param(6 * l + 2),
+                               t->param(6 * l + 3), t->mean[l], t->rstd[l], t->stats[6 * l + 4], t->stats[6 * l + 5], t->stats_new[6 * l + 4],
+                               t->stats_new[6 * l + 5], t->mom, l < 4 ? 1 : 0, l >= 4 ? t->rate : 0.f, t->seed, (uint64_t)t->step, l - 4);
+        else
+            hipLaunchKernelGGL(k_t_bn_fwd_fused<64>, dim3(Cc / OZ_BN_COLS), dim3(1024), 0, t->s, t->z[l], t->a[l], t->d_count, P, Cc, t->param(6 * l + 2),
+                               t->param(6 * l + 3), t->mean[l], t->rstd[l], t->stats[6 * l + 4], t->stats[6 * l + 5], t->stats_new[6 * l + 4],
+                               t->stats_new[6 * l + 5], t->mom, l < 4 ? 1 : 0, l >= 4 ? t->rate : 0.f, t->seed, (uint64_t)t->step, l - 4);
         OZ_HIP(hipGetLastError());
         return OZ_OK;
     }
@@ -1205,12 +1243,12 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
 
     // ---- backward
     hipLaunchKernelGGL(k_t_heads_wgrad, dim3(512), dim3(128), 0, s, t->a[5], t->dlogit, t->dvpre, t->d_count, A, t->grad(36), t->grad(38));
-    hipLaunchKernelGGL(k_t_heads_bias, dim3(1), dim3(128), 0, s, t->dlogit, t->dvpre, t->loss, t->d_count, A, t->grad(37), t->grad(39), t->losses);
+    hipLaunchKernelGGL(k_t_heads_bias, dim3(1), dim3(128), 0, s, t->dlogit, t->dvpre, t->loss, t->d_count, A, t->grad(37), t->grad(39), t->losses,
+                       t->h2 ? t->dzmax : (unsigned*)nullptr);
     hipLaunchKernelGGL(k_t_heads_dgrad, dim3((unsigned)(((long long)B * 512 + 255) / 256)), dim3(256), 0, s, t->dlogit, t->dvpre, t->param(36),
                        t->param(38), t->d_count, A, t->dA[1]);
     OZ_HIP(hipGetLastError());
     int cur = 1;                                   // dA[cur] = gradient wrt a[l]
-    if (t->h2) OZ_HIP(hipMemsetAsync(t->dzmax, 0, 6 * sizeof(unsigned), s));
     for (int l = 5; l >= 0; --l) {
         bool have_dzmax = false;
         const int Cc = t->Co[l], P = t->P_[l];
@@ -1270,6 +1308,8 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
             const long long wcount = (long long)taps[l] * Cin[l] * Cc, wtiles = ((long long)B * P + 31) / 32;
             int msplit = 1;
             while (msplit < 16 && wblocks * msplit < 512 && wtiles / (msplit * 2) >= 8 && wcount * msplit * 2 <= t->gpartial_floats) msplit *= 2;
+            // (round 5, measured and removed: 3 splits instead of 4 so that 144 tiles x splits stays below 512 blocks -- the launch got SLOWER, 147 -> 227 us on
+            //  conv2: more than two of these 40 KB-LDS blocks share a CU, 576 blocks are one round)
             // the weight gradient only needs a[l - 1] and dz[l]: it runs on the second stream beside the data-gradient chain
             // (dgrad -> BN backward of the layer below -> ...), whose small-batch launches leave most CUs idle
             hipStream_t sw = s;
@@ -1359,11 +1399,15 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
     OZ_HIP(hipSetDevice(t->device));
     hipStream_t s = t->s;
     const int A = t->n * t->n;
-    OZ_HIP(hipMemcpyAsync(t->d_own, own, B * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    OZ_HIP(hipMemcpyAsync(t->d_opp, opp, B * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    OZ_HIP(hipMemcpyAsync(t->d_pit, pi_target, (size_t)B * A * sizeof(float), hipMemcpyHostToDevice, s));
-    OZ_HIP(hipMemcpyAsync(t->d_zt, z_target, B * sizeof(float), hipMemcpyHostToDevice, s));
-    OZ_HIP(hipMemcpyAsync(t->d_count, &B, sizeof(int), hipMemcpyHostToDevice, s));
+    {   // one upload (the call synchronises before it returns, so the pinned block is free again at the next call)
+        unsigned char* h = t->h_in;
+        memcpy(h + ((unsigned char*)t->d_own - t->d_in), own, B * sizeof(uint64_t));
+        memcpy(h + ((unsigned char*)t->d_opp - t->d_in), opp, B * sizeof(uint64_t));
+        memcpy(h + ((unsigned char*)t->d_pit - t->d_in), pi_target, (size_t)B * A * sizeof(float));
+        memcpy(h + ((unsigned char*)t->d_zt - t->d_in), z_target, B * sizeof(float));
+        memcpy(h + ((unsigned char*)t->d_count - t->d_in), &B, sizeof(int));
+        OZ_HIP(hipMemcpyAsync(t->d_in, h, t->in_bytes, hipMemcpyHostToDevice, s));
+    }
     if (int rc = t_forward_backward_async(t, B)) return rc;
     float h[4];
     OZ_HIP(hipMemcpyAsync(h, t->losses, 3 * sizeof(float), hipMemcpyDeviceToHost, s));

@@ -23,6 +23,7 @@ __device__ __forceinline__ float t_block_sum4(float v, float (*sh)[OZ_BN_COLS], 
 }
 
 // a = relu((z - mean) * rstd * gamma + beta) [* keep / (1 - rate)]; also mean, rstd and the staged moving statistics
+template <int RMAX>                        // rows per thread the launch is built for: 32 (up to 2048 rows: no spill at 128 registers) or 64
 __global__ __launch_bounds__(1024) void k_t_bn_fwd_fused(const float* __restrict__ z, float* __restrict__ a, const int* __restrict__ d_count,
                                                         int P, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -32,11 +33,24 @@ __global__ __launch_bounds__(1024) void k_t_bn_fwd_fused(const float* __restrict
     __shared__ float sh[OZ_BN_RL][OZ_BN_COLS];
     const int c64 = threadIdx.x & (OZ_BN_COLS - 1), lane4 = threadIdx.x / OZ_BN_COLS, c = blockIdx.x * OZ_BN_COLS + c64;
     const long long M = (long long)(*d_count) * P;
+    // a thread's rows (at most OZ_BN_FUSED_MAX_ROWS / OZ_BN_RL = 64) are fetched ONCE, all loads in flight, and stay in registers for the three
+    // passes (sum, centred squares, apply): one round trip to z instead of 3 x rows / 4 of them -- 38 us for the 2048 rows of conv1 at the
+    // reference's batch, round 5 (rocprofv3 timeline of a step, tools/trace_timeline.py).  The sums are formed in the same row order as before.
+    static_assert(RMAX * OZ_BN_RL <= OZ_BN_FUSED_MAX_ROWS, "rows per thread");
+    float zr[RMAX];
+    const float g = gamma[c], b = beta[c];
+    // (buffer loads: one per-thread offset register + a scalar row-block offset per load; rows beyond M fall outside the descriptor's range and read 0)
+    const auto zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(z), 0, (int)(M * C * 4), 0x00020000);
+    const int zoff = (lane4 * C + c) * 4;
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k) zr[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, zoff, k * OZ_BN_RL * C * 4, 0));
     float s = 0.f;
-    _Pragma("unroll 4") for (long long m = lane4; m < M; m += OZ_BN_RL) s += z[(size_t)m * C + c];
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k) if (lane4 + (long long)k * OZ_BN_RL < M) s += zr[k];
     const float mean = t_block_sum4(s, sh, lane4, c64) / (float)M;
     float q = 0.f;
-    _Pragma("unroll 4") for (long long m = lane4; m < M; m += OZ_BN_RL) { const float d = z[(size_t)m * C + c] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k) if (lane4 + (long long)k * OZ_BN_RL < M) { const float d = zr[k] - mean; q = fmaf(d, d, q); }
     const float var = t_block_sum4(q, sh, lane4, c64) / (float)M;
     const float rstd = 1.0f / sqrtf(var + 1e-3f);
     if (lane4 == 0) {
@@ -45,13 +59,16 @@ __global__ __launch_bounds__(1024) void k_t_bn_fwd_fused(const float* __restrict
         mm_new[c] = mm[c] * mom + mean * (1.0f - mom);
         mv_new[c] = mv[c] * mom + uv * (1.0f - mom);
     }
-    const float g = gamma[c], b = beta[c];
-    _Pragma("unroll 4") for (long long m = lane4; m < M; m += OZ_BN_RL) {
-        const size_t i = (size_t)m * C + c;
-        float y = (z[i] - mean) * rstd * g + b;
-        y = y > 0.f ? y : 0.f;
-        if (rate > 0.f) y = oz_dropout_keep(seed, step, (uint64_t)dlayer, (uint64_t)i, rate) ? y / (1.0f - rate) : 0.f;
-        a[i] = y;
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k) {
+        const long long m = lane4 + (long long)k * OZ_BN_RL;
+        if (m < M) {
+            const size_t i = (size_t)m * C + c;
+            float y = (zr[k] - mean) * rstd * g + b;
+            y = y > 0.f ? y : 0.f;
+            if (rate > 0.f) y = oz_dropout_keep(seed, step, (uint64_t)dlayer, (uint64_t)i, rate) ? y / (1.0f - rate) : 0.f;
+            a[i] = y;
+        }
     }
 }
 
@@ -90,9 +107,16 @@ __global__ __launch_bounds__(1024) void k_t_bn_bwd_fused(const float* __restrict
         sb += g;
         amax = fmaxf(amax, fabsf(g));
     }
-    if (dzmax) {
+    if (dzmax) {                                             // one atomic per block (see k_t_bnb_apply)
+        __shared__ float wm_s[16];
         for (int o = 32; o; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-        if ((threadIdx.x & 63) == 0) atomicMax(dzmax, __float_as_uint(amax));
+        if ((threadIdx.x & 63) == 0) wm_s[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mx = wm_s[0];
+            for (int k = 1; k < 16; ++k) mx = fmaxf(mx, wm_s[k]);
+            atomicMax(dzmax, __float_as_uint(mx));
+        }
     }
     const float SB = t_block_sum4(sb, sh, lane4, c64);
     if (lane4 == 0) { dgamma[c] = S1; dbeta[c] = S0; dbias[c] = SB; }
@@ -155,12 +179,16 @@ __global__ __launch_bounds__(256) void k_t_bnb_apply(const float* __restrict__ d
         const int b = (int)(m / P), pix = (int)(m % P);
         *reinterpret_cast<f32x4*>(dz + (((size_t)b * Hz + pix / Hout + zoff) * Hz + pix % Hout + zoff) * C + c) = g;
     }
+    // the block's largest |dz|: ONE atomic per block -- an atomic on one word costs ~12 ns each, and with one per wave the 512 .. 2048 of them
+    // were most of this launch at the reference's batch (round 5)
+    __shared__ float wm_s[4];
     if (dzmax) {
         for (int o = 32; o; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-        if ((threadIdx.x & 63) == 0) atomicMax(dzmax, __float_as_uint(amax));
+        if ((threadIdx.x & 63) == 0) wm_s[threadIdx.x >> 6] = amax;
     }
     sh[0][threadIdx.x] = sb;
     __syncthreads();
+    if (dzmax && threadIdx.x == 0) atomicMax(dzmax, __float_as_uint(fmaxf(fmaxf(wm_s[0], wm_s[1]), fmaxf(wm_s[2], wm_s[3]))));
     if (rsub == 0 && valid) {
         f32x4 t = sh[0][threadIdx.x];
         for (int k = 1; k < rpp; ++k) t += sh[0][threadIdx.x + k * lpr];
