@@ -57,12 +57,12 @@ def test_product_never_imports_oracle():
 
 def test_bench_uses_the_oracle_only_as_checker_and_cpu_baseline():
     """bench.py (launcher + timed region) never imports the oracle; bench_legs.py imports it only inside the legs that ARE the checker or the
-    CPU baseline (cpu_baseline*, parity_sample, config5_arena's replay, dropin_config0's CPU port) -- never at module level, never in run_secondary"""
+    CPU baseline (cpu_baseline*, host_cpu_share = how many threads the CPU legs may use, parity_sample, config5_arena's replay, dropin_config0's CPU port) -- never at module level, never in run_secondary"""
     import ast
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert not re.search(r"^\s*(import|from)\s+oracle", src, flags=re.M)
     tree = ast.parse(open(os.path.join(ROOT, "bench_legs.py")).read())
-    allowed = {"cpu_baseline", "cpu_baseline_config", "parity_sample", "config5_arena", "dropin_config0", "host_threads"}
+    allowed = {"cpu_baseline", "cpu_baseline_config", "parity_sample", "config5_arena", "dropin_config0", "host_threads", "host_cpu_share"}
     for node in tree.body:
         names = []
         for sub in ast.walk(node):
