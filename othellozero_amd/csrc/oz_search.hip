@@ -1728,7 +1728,7 @@ OZ_API int oz_arena_run_rounds(oz_arena* a, int max_rounds_arg) {
         // a->sims steps (11 launches each over zero leaves) are skipped -- one 8-byte read-back per round buys ~10 % at 800 sims per move.
         // (Round 5, measured and removed: BOTH agents in every round -- the odd slots held back one ply, agent A's and agent B's chains on two
         //  streams, k-splits sized for half batches -- 350.6 against 348.7 ms per ply of 512 games in an A/B on one device: the second chain's
-        //  kernels run beside the first one's and slow them by what they gain, the chip is power limited; DESIGN.md section 4.)
+        //  kernels run beside the first one's and slow them by what they gain, the chip is power limited; DESIGN.md section 9.)
         int movers[2] = {0, 0};
         hipMemsetAsync(a->d_movers, 0, sizeof movers, s);
         hipLaunchKernelGGL(k_arena_movers, dim3((G + 255) / 256), dim3(256), 0, s, sp->gm, a->d_movers);
@@ -2015,7 +2015,7 @@ OZ_API int oz_selftest_arith(const double* a, const double* b, int count, double
 // Sustained matrix-pipe rate of THIS device, right now: a pure-MFMA loop (no LDS, no loads, no barriers; one block per CU, one wave per SIMD,
 // four independent accumulators back to back -- the issue pattern of the GEMM kernels' clusters) for about `target_ms`.  kind 0 =
 // v_mfma_f32_32x32x2_f32 (what k_gemm_f32 runs on), kind 1 = v_mfma_f32_16x16x32_f16 on operands with every mantissa bit busy (what k_gemm_h2
-// runs on; the sustained clock of that pipe follows the operand bits).  bench.py puts both numbers into its line as
+// runs on; the sustained clock of that pipe follows the operand bits, docs/HISTORY.md section 4).  bench.py puts both numbers into its line as
 // `device_calibration`, so that a reader can tell a slow box (or a power-capped one) from a regression: the GEMM kernels' own rate moves
 // with this one.  tflops = FLOP of the issued MFMAs / HIP-event time; clock_ghz = the clock at which back-to-back issue (64 / 16 cycles per
 // MFMA and SIMD) gives that rate.
