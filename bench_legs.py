@@ -108,7 +108,7 @@ def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tabl
             per_leaf, src = None, None
             try:
                 import csv
-                rel = os.path.join("profiles", f"r3_{precision}_bench_pmc_by_shape.csv")
+                rel = os.path.join("profiles", f"r5_{precision}_bench_pmc_by_shape.csv")
                 rows = [r for r in csv.DictReader(l for l in open(os.path.join(ROOT, rel)) if not l.startswith("#")) if "k_conv2_lut" in r["kernel"]]
                 fetch = max(float(r["avg_per_launch"]) for r in rows if r["counter"] == "FETCH_SIZE")
                 write = max(float(r["avg_per_launch"]) for r in rows if r["counter"] == "WRITE_SIZE")

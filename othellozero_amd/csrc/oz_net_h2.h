@@ -1124,7 +1124,10 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     // h2 output: each wave transposes its tile through its own 16 KB LDS slice, 64 rows x 64 channels at a time:
     // slice[row][group(8)][plane(2)][8 halfs] = 256 B per row; then 16-byte chunks go out, 16 lanes per row.
     static_assert(RJ == 4, "the h2 epilogue assumes a 64-channel wave tile");
-    bool over = false;
+    // the high-side guard as a RUNNING maximum of |v| (one register): written as `over |= |v| > 65504` the compiler turned the chain into one
+    // max3 tree at the END of the epilogue and kept every v alive for it -- the kernel's 45 spilled registers, 184 B of scratch per thread,
+    // 0.095 GB of extra writes (and reads) per conv3 launch (round 5)
+    float amax = 0.f;
     constexpr int PB = CF::PB;
     _Float16* slice = reinterpret_cast<_Float16*>(smem + wave * CF::SLICE);
     uint4* o = reinterpret_cast<uint4*>(out);
@@ -1144,12 +1147,13 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                     const int lr = ii * 16 + kg * 4 + r;     // row inside the pass
                     float v = fmaf(acc[i][j][r], sc, sh);
                     if (g.relu) v = fmaxf(v, 0.f);
-                    over |= fabsf(v) > H2_F16_MAX;
+                    amax = fmaxf(amax, fabsf(v));
                     _Float16 h1, h2;
                     h2_split(v, h1, h2);
                     _Float16* p = slice + lr * 128 + (lc >> 3) * 16 + (lc & 7);
                     p[0] = h1; p[8] = h2;
                 }
+                asm volatile("" : "+v"(amax));               // the maximum so far is MATERIALISED here (max is reassociable: without this the tree is built at the end)
             }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's LDS writes have landed
@@ -1176,5 +1180,5 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
     }
-    if (over) atomicOr(flag, H2_FLAG_OVER);
+    if (amax > H2_F16_MAX) atomicOr(flag, H2_FLAG_OVER);
 }
