@@ -481,6 +481,31 @@ def config5_arena(channels, precision, plies=0, games=512, sims=800, sample=2, d
     t0 = time.perf_counter()
     rd = arena_batch(nets[0], nets[1], n, games, sims, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=dedup_compare_plies, dedup=True)
     dtd = time.perf_counter() - t0
+    # ... and every sharing the library offers: de-duplication + the two networks' persistent evaluation caches, WHOLE games, next to
+    # the pure number -- not instead of it -- and checked against it move for move over all games
+    from othellozero_amd import _lib as _ozlib
+    for nt in nets:
+        nt.set_option(_ozlib.NET_OPT_LATENCY_SPLITS, 1)        # batches of a few leaves: k-splits chosen for latency (oz_net_set_option; a per-network constant)
+        nt.commit()
+        nt.set_eval_cache(1 << 22)
+    t0 = time.perf_counter()
+    rc = arena_batch(nets[0], nets[1], n, games, sims, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=plies, dedup=True, eval_cache=True)
+    dtc = time.perf_counter() - t0
+    cstats = [nt.eval_cache_stats() for nt in nets]
+    for nt in nets:
+        nt.set_eval_cache(0)
+    # its checker: the SAME networks (same k-splits, so the same bits) with every expansion evaluated by itself, on the opening plies
+    rp = arena_batch(nets[0], nets[1], n, games, sims, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=dedup_compare_plies, dedup=False)
+    kc = np.minimum(rp["n_moves"], rc["n_moves"])
+    livec = np.arange(128)[None, :] < kc[:, None]
+    same_cached_plies = bool(np.array_equal(rp["actions"][livec], rc["actions"][livec]) and np.array_equal(rp["players"][livec], rc["players"][livec]))
+    for nt in nets:
+        nt.set_eval_cache(0)
+        nt.set_option(_ozlib.NET_OPT_LATENCY_SPLITS, 0)
+        nt.commit()
+    # (against the pure run ABOVE the networks differ in their k-splits, i.e. in the last bits of (pi, v): the games usually agree, and how many do is reported)
+    games_equal_to_pure = int(sum(1 for g_ in range(games) if r["n_moves"][g_] == rc["n_moves"][g_]
+                                  and np.array_equal(r["actions"][g_], rc["actions"][g_]) and r["winner"][g_] == rc["winner"][g_] and r["points"][g_] == rc["points"][g_]))
     k_cmp = np.minimum(rd["n_moves"], r["n_moves"])
     live = np.arange(128)[None, :] < k_cmp[:, None]                             # the plies both runs played
     same = bool(np.array_equal(r["actions"][live], rd["actions"][live]) and np.array_equal(r["players"][live], rd["players"][live]))
@@ -550,6 +575,15 @@ def config5_arena(channels, precision, plies=0, games=512, sims=800, sample=2, d
            "roofline": roof, "kernels": ktab,
            "kernels_note": f"HIP events around every launch of both networks and both searches over the first {kernel_plies} plies of a second run "
                            "(per simulation step = one network batch of one agent); roofline.avg_launch_ms is from the timed whole-game run",
+           "with_dedup_and_eval_cache": {"seconds": dtc, "games_per_s": games / dtc if whole else None,
+                                         "sims_per_s": float(rc["stats_black"][0] + rc["stats_white"][0]) / dtc,
+                                         "leaves_evaluated": int(rc["leaves_evaluated"]), "expansions": int((rc["stats_black"] + rc["stats_white"])[2]),
+                                         "cache_hit_rate": sum(c["hits"] for c in cstats) / max(sum(c["lookups"] for c in cstats), 1),
+                                         "identical_moves_on_the_opening_plies_vs_every_expansion_evaluated": same_cached_plies, "plies_compared": dedup_compare_plies,
+                                         "games_identical_to_the_pure_run_above": games_equal_to_pure,
+                                         "note": "oz_arena_set_eval_cache + cross-game de-duplication + OZ_NET_OPT_LATENCY_SPLITS (batches of ~15 leaves): checked move for move on the opening plies against the same "
+                                                 "networks evaluating every expansion (same k-splits = same bits); whole games compared with the pure run above, whose networks differ "
+                                                 "in the last bits of (pi, v); reported BESIDE the pure number"},
            "sample_games_replayed_by_oracle": sample, "sample_plies_replayed": replayed_plies, "sample_mismatches": bad,
            "oracle_replay_s": round(time.perf_counter() - t1, 2),
            "note": "oz_arena_run_rounds: BLACK movers search in net A's trees, WHITE movers in net B's, one searched ply per game and round; "

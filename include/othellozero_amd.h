@@ -142,6 +142,13 @@ int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int
  * on the 128 x 128 one (GmStd) like every other layer.  Both tiles add every output element's products in the same order: bit-identical
  * results -- the screen test_f32_big_tile_bit_identical_to_the_standard_tile compares them.  Takes effect at the next forward. */
 #define OZ_NET_OPT_F32_STD_TILE 6
+/* precision f16x2, medium networks (32 < max_batch < ~1000), default 0: 1 = the k-splits of the 3x3 convolutions are chosen for LATENCY (a cost
+ * model of grid rounds x k-tiles per block + reduce slabs) instead of "the fewest slices that fill 192 blocks".  For callers whose batches are
+ * usually far smaller than max_batch -- an arena with the library's de-duplication and evaluation cache evaluates ~15 leaves per step, and a
+ * launch of one-slice 144-k-tile blocks takes 205 us whatever it holds: bench.py's config5, 31 -> 45 games/s -- at a price for full batches
+ * (407 -> 430 us per 512-leaf step).  A per-network constant: a position's (pi, v) does not depend on the size of the call; two networks with
+ * different settings agree to rounding.  Takes effect at the next oz_net_commit. */
+#define OZ_NET_OPT_LATENCY_SPLITS 7
 int oz_net_set_option(oz_net* net, int option, int value);
 int oz_net_self_check(oz_net* net, double* max_dpi, double* max_dv, int* positions);
 /* precision f16x2: the exponents chosen at the last commit.  which = 0 .. 4: per-channel activation exponents of the conv1, conv2, conv3,
@@ -325,6 +332,9 @@ int oz_arena_stats(oz_arena* a, int64_t* black5, int64_t* white5);
  * networks have evaluated so far (<= expansions when concurrent games share boards -- arena games start from one opening) */
 int oz_arena_set_dedup(oz_arena* a, int enable);
 int oz_arena_leaves_evaluated(oz_arena* a, int64_t* black, int64_t* white);
+/* the two agents' leaves go through their networks' persistent evaluation caches (oz_net_set_eval_cache; default 0 = every leaf is evaluated):
+ * identical moves, boards and results -- the reference's per-search _predict_cache (othelo_mcts.py:13,82-88) across games, plies and steps */
+int oz_arena_set_eval_cache(oz_arena* a, int enable);
 /* HIP-event timing of the two agents' tree kernels on the launch stream, slots of oz_selfplay_profile (0 select 1 leaf compaction 2 evaluator = all
  * network launches 3 expand + backup 4 move), summed over both searches; the networks' own kernels: oz_net_profile on net_a / net_b */
 int oz_arena_profile(oz_arena* a, int enable);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("OZ_LIB_PATH") or os.path.join(_HERE, "lib", "libothel
 OZ_OK, OZ_ERR_HIP, OZ_ERR_ARG, OZ_ERR_CAPACITY, OZ_ERR_KEY, OZ_ERR_STATE = range(6)
 QMODE_NEP50, QMODE_F64 = 0, 1
 DEDUP_DEFAULT, DEDUP_ON, DEDUP_OFF = 0, 1, 2                                          # oz_selfplay_config.dedup
-NET_OPT_SIMPLE_LOOP, NET_OPT_ACT_TARGET_LOG2, NET_OPT_LOW_GUARD_LOG2, NET_OPT_SELF_CHECK, NET_OPT_W_TARGET_LOG2, NET_OPT_F32_STD_TILE = 1, 2, 3, 4, 5, 6      # oz_net_set_option
+NET_OPT_SIMPLE_LOOP, NET_OPT_ACT_TARGET_LOG2, NET_OPT_LOW_GUARD_LOG2, NET_OPT_SELF_CHECK, NET_OPT_W_TARGET_LOG2, NET_OPT_F32_STD_TILE, NET_OPT_LATENCY_SPLITS = 1, 2, 3, 4, 5, 6, 7      # oz_net_set_option
 NET_INFO_CONV3_TILE_ROWS, NET_INFO_SELF_CHECK_GUARD = 1, 2                                                          # oz_net_get_info
 LEAF_IDLE, LEAF_TERMINAL, LEAF_EVAL = 0, 1, 2
 VT_INT, VT_F32, VT_F64 = 0, 1, 2
@@ -116,7 +116,7 @@ SIGNATURES = {
     "oz_selfplay_gather_records": [_vp, _vp, C.c_int64, _vp, C.c_int64, _i64p, _i64p],
     "oz_arena_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_uint64, _vp, _vp, C.c_int],
     "oz_arena_destroy": [_vp], "oz_arena_run": [_vp], "oz_arena_run_rounds": [_vp, C.c_int], "oz_arena_stats": [_vp, _i64p, _i64p],
-    "oz_arena_set_dedup": [_vp, C.c_int], "oz_arena_profile": [_vp, C.c_int], "oz_arena_profile_read": [_vp, _f64p, _i64p, C.c_int], "oz_arena_leaves_evaluated": [_vp, _i64p, _i64p],
+    "oz_arena_set_dedup": [_vp, C.c_int], "oz_arena_set_eval_cache": [_vp, C.c_int], "oz_arena_profile": [_vp, C.c_int], "oz_arena_profile_read": [_vp, _f64p, _i64p, C.c_int], "oz_arena_leaves_evaluated": [_vp, _i64p, _i64p],
     "oz_arena_results": [_vp, _i8p, _i32p, _i32p, _u8p, _i8p, _u64p, _u64p],
     "oz_examples_expand": [_vp, C.c_int64, C.c_int, C.c_int, _u8p, _i32p, _i8p],
     "oz_symmetry_table": [C.c_int, _i32p],

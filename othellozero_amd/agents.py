@@ -74,7 +74,7 @@ def duel_between_agents(game, agent_1, agent_2):
 
 
 def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, degree_exploration=1.0, seed=0,
-                first_game_id=0, q_mode=_lib.QMODE_F64, node_cap=0, max_rounds=0, dedup=True, profile=False):
+                first_game_id=0, q_mode=_lib.QMODE_F64, node_cap=0, max_rounds=0, dedup=True, profile=False, eval_cache=False):
     """num_games games of net_a (BLACK) vs net_b (WHITE), temperature 0, max-visit ties broken by the RNG_TIE
     stream keyed (seed, game id, ply).  One of the two may be None: RandomOthelloAgent plays that colour.
     max_rounds > 0 stops after that many plies per game (unfinished boards: winner / points then describe the position reached).
@@ -90,6 +90,8 @@ def arena_batch(net_a, net_b, board_size=8, num_games=512, num_simulations=800, 
     try:
         if not dedup:                                        # every expansion evaluated by itself (identical results; bench.py's config5 headline)
             _lib.check(lib.oz_arena_set_dedup(h, 0))
+        if eval_cache:                                       # leaves looked up in / inserted into the two networks' evaluation caches (net.set_eval_cache first)
+            _lib.check(lib.oz_arena_set_eval_cache(h, 1))
         if profile:                                          # HIP events around the tree kernels of both searches (bench.py's config5 kernels[])
             _lib.check(lib.oz_arena_profile(h, 1))
         _lib.check(lib.oz_arena_run_rounds(h, int(max_rounds)))

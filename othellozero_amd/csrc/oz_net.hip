@@ -758,6 +758,7 @@ struct OnnNet : oz_net {
     int tables_mode = -1;            // oz_net_set_tables: -1 = default (2), 0 / 1 / 2 see forward_h2
     int sizing() const { return max_batch; }     // the batch size the k-splits of the medium path are chosen for: the capacity, a per-network constant
     size_t partial_cap = 0;          // floats d_partial holds
+    bool latency_splits = false;     // oz_net_set_option(OZ_NET_OPT_LATENCY_SPLITS): see conv_ksplit
     bool f32_std_tile = false;       // oz_net_set_option(OZ_NET_OPT_F32_STD_TILE): precision f32 never takes the 256 x 256 tile (bit-identity screen)
     bool simple_loop = false;        // oz_net_set_option(OZ_NET_OPT_SIMPLE_LOOP): one-barrier-per-k-tile loop for the 3x3 layers (race screen)
     float* d_t2rows = nullptr;       // commit staging: one tap's T2 rows [OZ_LUT_PATTERNS][C] before the slice-major re-layout
@@ -827,10 +828,24 @@ struct OnnNet : oz_net {
     }
     // k-split of a 3x3 convolution on BM-row tiles (N = C, 256-column tiles): the smallest power of two <= 8 that brings
     // the grid to >= 192 blocks, from max_batch (a per-network constant, so results do not depend on the size of a call)
+    // OZ_NET_OPT_LATENCY_SPLITS (round 5, default off): ... or the split a cost model prefers -- rounds of the 256 CUs x k-tiles per block + the
+    // fixed-order reduce's slabs.  Written for max_batch = 512 on 8x8 (the arena's networks): conv3 = 192 blocks of 144 k-tiles = 205 us per
+    // launch WHATEVER the batch holds; 4 k-slices = 768 blocks of 36 k-tiles.  Measured (bench.py's config5 leg, 512 games x 800 sims): with
+    // every expansion evaluated (512-leaf batches) the split LOSES, 407 -> 430 us per step (the slab epilogues and the reduce cost more than
+    // the idle quarter of the chip), so it is not the default; with the library's cross-game de-duplication + evaluation cache (batches of
+    // ~15 leaves) it is what the step waits for: 31.3 -> 44.8 games/s.  Every call of a network uses the same split either way.
     int conv_ksplit(int pixels, int BM) const {
         const long long blocks = (((long long)sizing() * pixels + BM - 1) / BM) * (C / 256);
         int k = 1;
         while (k < 8 && blocks * k < 192) k *= 2;
+        if (latency_splits && sizing() > 32 && blocks * k < 1024) {
+            const double nk = 9.0 * C / 32, t_kt = 1.42e-6 * BM / 192.0, t_slab = (double)sizing() * pixels * C * 4.0 / 8.0e12 + 1.0e-6;
+            auto cost = [&](int q) { return (double)((blocks * q + 255) / 256) * (nk / q) * t_kt + (q > 1 ? q * t_slab : 0.0); };
+            int best = k;
+            for (int q = 1; q <= 8; q *= 2)
+                if (nk / q >= 8 && cost(q) < 0.95 * cost(best)) best = q;
+            k = best;
+        }
         return k;
     }
     size_t partial_floats() const {
@@ -1859,11 +1874,12 @@ OZ_API int oz_net_set_option(oz_net* net, int option, int value) {
     OnnNet* o = as_onn(net);
     OZ_REQUIRE(o, "not an OthelloNN network");
     OZ_REQUIRE(option == OZ_NET_OPT_SIMPLE_LOOP || option == OZ_NET_OPT_ACT_TARGET_LOG2 || option == OZ_NET_OPT_LOW_GUARD_LOG2 ||
-               option == OZ_NET_OPT_SELF_CHECK || option == OZ_NET_OPT_W_TARGET_LOG2 || option == OZ_NET_OPT_F32_STD_TILE,
-               "unknown network option %d", option);
+               option == OZ_NET_OPT_SELF_CHECK || option == OZ_NET_OPT_W_TARGET_LOG2 || option == OZ_NET_OPT_F32_STD_TILE ||
+               option == OZ_NET_OPT_LATENCY_SPLITS, "unknown network option %d", option);
     std::lock_guard<std::mutex> lk(o->mu);
     if (option == OZ_NET_OPT_SIMPLE_LOOP) o->simple_loop = value != 0;
     else if (option == OZ_NET_OPT_F32_STD_TILE) o->f32_std_tile = value != 0;
+    else if (option == OZ_NET_OPT_LATENCY_SPLITS) { if (o->latency_splits != (value != 0)) { o->latency_splits = value != 0; o->committed = false; } }
     else if (option == OZ_NET_OPT_W_TARGET_LOG2) {
         OZ_REQUIRE(value >= -12 && value <= 15, "OZ_NET_OPT_W_TARGET_LOG2 must be in [-12, 15] (got %d)", value);
         if (o->w_target_log2 != value) { o->w_target_log2 = value; o->committed = false; }

@@ -1572,6 +1572,7 @@ struct oz_arena {
     uint8_t* d_actions = nullptr; int8_t* d_players = nullptr;
     int* d_nmoves = nullptr;
     int* d_movers = nullptr;     // [2] live games with BLACK / WHITE to move (k_arena_movers)
+    int eval_cache = 0;          // oz_arena_set_eval_cache: the two searches look their leaves up in (and insert them into) their networks' evaluation caches
 };
 
 // live games per mover: counts[0] = BLACK to move, counts[1] = WHITE to move (an agent with nothing to move this round is not launched)
@@ -1703,6 +1704,17 @@ OZ_API int oz_arena_leaves_evaluated(oz_arena* a, int64_t* black, int64_t* white
     return OZ_OK;
 }
 
+// the persistent evaluation caches of the two networks (oz_net_set_eval_cache) serve the arena's searches too: arena games start from ONE opening
+// and play deterministically, so across games, plies and steps most boards recur -- the reference's own per-search _predict_cache
+// (othelo_mcts.py:13,82-88) generalised to everything that uses the network.  A hit changes no bit (a position's (pi, v) does not depend on the
+// batch it is evaluated in): moves, boards and results are those of the uncached arena.  Default off, like oz_selfplay_config.eval_cache.
+OZ_API int oz_arena_set_eval_cache(oz_arena* a, int enable) {
+    OZ_REQUIRE(a, "null arena");
+    std::lock_guard<std::mutex> lk(a->mu);
+    a->eval_cache = enable ? 1 : 0;
+    return OZ_OK;
+}
+
 OZ_API int oz_arena_run_rounds(oz_arena* a, int max_rounds_arg) {
     OZ_REQUIRE(a, "null arena");
     OZ_REQUIRE(max_rounds_arg >= 0, "oz_arena_run_rounds: max_rounds %d", max_rounds_arg);
@@ -1710,6 +1722,10 @@ OZ_API int oz_arena_run_rounds(oz_arena* a, int max_rounds_arg) {
     oz_selfplay* sp = &a->games;
     oz_mcts *ma = sp->m, *mb = a->mb;
     hipSetDevice(ma->device);
+    // (the caches as they are NOW: oz_net_set_eval_cache may have been called since the arena was created.  The two searches run one after
+    //  the other on one stream, so even ONE network playing itself never has two users of its cache at a time.)
+    ma->d.ec = (a->eval_cache && a->na && a->na->ec.buckets && a->na->ec.n2 == ma->d.n2) ? a->na->ec : EvalCacheDev();
+    mb->d.ec = (a->eval_cache && a->nb && a->nb->ec.buckets && a->nb->ec.n2 == mb->d.n2) ? a->nb->ec : EvalCacheDev();
     const int G = sp->gm.G;
     hipStream_t s = ma->stream;          // both searches are driven on agent A's stream (they share game state)
     hipStream_t sb_saved = mb->stream;

@@ -191,6 +191,10 @@ def test_config5_real_networks_whole_games_vs_oracle(oz):
     # the leg's headline evaluates every expansion by itself; the library default shares boards between the games of a step -- same moves
     assert out["leaves_evaluated"] == out["expansions"]
     assert out["with_cross_game_dedup"]["identical_moves_on_those_plies"]
+    cc = out["with_dedup_and_eval_cache"]                      # the cached arena plays the SAME 512 games, and evaluates far fewer positions
+    assert cc["identical_moves_on_the_opening_plies_vs_every_expansion_evaluated"] and cc["games_identical_to_the_pure_run_above"] >= 500
+    assert cc["leaves_evaluated"] < 0.5 * cc["expansions"] and cc["cache_hit_rate"] > 0.005     # (of the lookups LEFT after the same-step de-duplication)
+    assert cc["games_per_s"] > out["games_per_s"]
     # round 5: the leg carries the regime's own roofline (conv3 at <= 512 leaves per launch, events in the timed run) and kernels[]
     rf = out["roofline"]
     assert rf["bound"] == "mfma" and rf["launches"] == out["simulations"] // 512 * 1 or rf["launches"] > 0
