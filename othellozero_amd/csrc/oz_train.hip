@@ -84,28 +84,29 @@ __global__ __launch_bounds__(256) void k_t_conv1_fwd(const uint64_t* __restrict_
 
 // dW1[t][ch][co] = sum_m x[m shifted by t][ch] * dz[m][co]: ONE pass over dz -- a thread owns an output channel and keeps the
 // 9 * cin sums of its row split in registers (the input planes are bits of the two bitboards, wave-uniform per row)
+template <int NB>                          // board size as a constant: the row -> (board, pixel) split is a shift / a multiply, not a 64-bit division per row
 __global__ __launch_bounds__(256) void k_t_conv1_wgrad(const uint64_t* __restrict__ own, const uint64_t* __restrict__ opp,
-                                                       const int* __restrict__ d_count, int n, int C, int cin,
+                                                       const int* __restrict__ d_count, int C, int cin,
                                                        const float* __restrict__ dz, float* __restrict__ partial /*[S][9*cin][C]*/, int S) {
-    const int P = n * n;
+    constexpr int n = NB, P = NB * NB;
     const int co = blockIdx.x * 256 + threadIdx.x, sp = blockIdx.y;
     if (co >= C) return;
-    const long long M = (long long)(*d_count) * P;
+    const int M = (*d_count) * P;
     float acc[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) acc[i] = 0.f;
     // four rows of the split per trip: their loads (a dz element and two bitboards each) are issued together, the sums stay in row order
-    for (long long m0 = sp; m0 < M; m0 += 4LL * S) {
+    for (int m0 = sp; m0 < M; m0 += 4 * S) {
         float d[4];
         uint64_t o[4], p[4];
         int pixs[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long long m = m0 + (long long)u * S;
+            const int m = m0 + u * S;
             const bool in = m < M;
-            const long long mm = in ? m : m0;
-            const int b = (int)(mm / P);
-            pixs[u] = in ? (int)(mm % P) : -1;
+            const int mm = in ? m : m0;
+            const int b = mm / P;
+            pixs[u] = in ? mm % P : -1;
             o[u] = own[b]; p[u] = opp[b];
             d[u] = dz[(size_t)mm * C + co];
         }
@@ -290,10 +291,21 @@ __global__ __launch_bounds__(64) void k_t_heads(const float* __restrict__ f2 /*[
     if (b >= B) return;
     const float* x = f2 + (size_t)b * 512;
     float logit = -INFINITY, vacc = 0.f;
-    if (lane < A) {
+    {
+        // 64 weight rows in flight per batch (buffer loads: one per-lane offset register + a scalar row offset each), the fmaf chain stays in k order:
+        // the loop is a chain of L2 round trips, 32 of them with 16 rows in flight = 19 us per launch at the reference's batch (round 5)
+        const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wpi), 0, 512 * A * 4, 0x00020000);
+        const int lo = (lane < A ? lane : 0) * 4;
         float acc = 0.f;
-        _Pragma("unroll 16") for (int k = 0; k < 512; ++k) acc = fmaf(x[k], Wpi[(size_t)k * A + lane], acc);      // 16 row loads in flight, the fmaf chain stays in k order
-        logit = acc + bpi[lane];
+#pragma unroll 1
+        for (int k0 = 0; k0 < 512; k0 += 64) {
+            float wv[64];
+#pragma unroll
+            for (int j = 0; j < 64; ++j) wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, lo, (k0 + j) * A * 4, 0));
+#pragma unroll
+            for (int j = 0; j < 64; ++j) acc = fmaf(x[k0 + j], wv[j], acc);
+        }
+        if (lane < A) logit = acc + bpi[lane];
     }
     for (int k = lane; k < 512; k += 64) vacc = fmaf(x[k], Wv[k], vacc);
     for (int o = 32; o; o >>= 1) vacc += __shfl_xor(vacc, o);
@@ -1297,8 +1309,8 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
         if (l == 0) {
             int S1 = 8;                                    // row splits: ~16 rows per thread (each a dependent ~1 us load at small batch), at most RED_S (the partial buffer's capacity)
             while (S1 < RED_S && (long long)B * A > 16LL * S1) S1 *= 2;
-            hipLaunchKernelGGL(k_t_conv1_wgrad, dim3((C + 255) / 256, S1), dim3(256), 0, s, t->d_own, t->d_opp, t->d_count, n, C, t->cin,
-                               t->dz[0], t->partial, S1);
+            if (n == 8) hipLaunchKernelGGL(k_t_conv1_wgrad<8>, dim3((C + 255) / 256, S1), dim3(256), 0, s, t->d_own, t->d_opp, t->d_count, C, t->cin, t->dz[0], t->partial, S1);
+            else hipLaunchKernelGGL(k_t_conv1_wgrad<6>, dim3((C + 255) / 256, S1), dim3(256), 0, s, t->d_own, t->d_opp, t->d_count, C, t->cin, t->dz[0], t->partial, S1);
             const long long cnt = 9LL * t->cin * C;
             hipLaunchKernelGGL(k_t_sum_partials, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, t->partial, S1, cnt, t->grad(0));
             OZ_HIP(hipGetLastError());
