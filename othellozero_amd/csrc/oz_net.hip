@@ -1177,7 +1177,11 @@ struct OnnNet : oz_net {
     // kernels have their own rounding), D <= 3.8e-6; the badly conditioned test network (conv2 kernel x 2^-12, conv3's BN variance x 2^-24):
     // 8x8 / 256 filters E16 6.5e-6, D 1.4e-5; 8x8 / 512 E16 2.5e-6, D 6.2e-6; 6x6 / 512 E16 1.06e-5 (a MISS), D 2.3e-5 -- D runs at 2-3 x E16 once
     // conditioning dominates, so 8e-6 refuses networks from E16 ~ 3-4e-6 on and leaves every healthy one alone.
-    // A refused network fails here, at commit, with OZ_ERR_STATE ("use precision f32").  OZ_NET_OPT_SELF_CHECK: 0 off, 2 measure only.
+    // TRAINED networks (round 5, tools/trained_net_self_check.py: 8x8 / 512 filters, three iterations of self-play + fit on the GPU, the trained weights
+    // committed in measure-only mode): D = 1.7e-6, 8.9e-7, 4.8e-7 after iterations 1, 2, 3 (E16 <= 8.4e-7) -- further from the limit than the random-init
+    // networks above (profiles/r5_trained_network_self_check.json).
+    // A refused network fails here, at commit, with OZ_ERR_STATE ("use precision f32"; NNetWrapper.train falls back to precision f32 with a warning).
+    // OZ_NET_OPT_SELF_CHECK: 0 off, 2 measure only (the commit succeeds; oz_net_self_check / OZ_NET_INFO_SELF_CHECK_GUARD say what was seen).
     int run_self_check() {
         const int gl[5] = {6, 12, 18, 24, 30};
         const int Ks[5] = {9 * C, 9 * C, 9 * C, F, 1024}, Ns[5] = {C, C, C, 1024, 512};
