@@ -149,13 +149,18 @@ int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int
  * (407 -> 430 us per 512-leaf step).  A per-network constant: a position's (pi, v) does not depend on the size of the call; two networks with
  * different settings agree to rounding.  Takes effect at the next oz_net_commit. */
 #define OZ_NET_OPT_LATENCY_SPLITS 7
+/* diagnostics switch, per network (default 0), precision f16x2, max_batch > 32: conv3 runs on the row tile of this height (128, 192 or 256)
+ * instead of the one the forward picks for the call (fewest grid rounds x tile height).  All three add every output element's products in the
+ * same order: bit-identical results -- test_conv3_tiles_bit_identical compares them.  Takes effect at the next forward. */
+#define OZ_NET_OPT_CONV3_TILE 8
 int oz_net_set_option(oz_net* net, int option, int value);
 int oz_net_self_check(oz_net* net, double* max_dpi, double* max_dv, int* positions);
 /* precision f16x2: the exponents chosen at the last commit.  which = 0 .. 4: per-channel activation exponents of the conv1, conv2, conv3,
  * conv4 (channels each) and fc1 (1024) outputs; which = 5 .. 9: per-column weight exponents of conv2, conv3, conv4 (channels), fc1 (1024), fc2 (512) */
 int oz_net_get_scaling(oz_net* net, int which, int32_t* out, int64_t nelem);
-/* launch facts of the last forward: OZ_NET_INFO_CONV3_TILE_ROWS = the row-tile height conv3 ran on.  Precision f16x2: 256 / 192, chosen per call
- * from the capacity the caller launches with (256 at bench.py's batch cap of 3640 leaves), 128 on the latency path (max_batch <= 32).
+/* launch facts of the last forward: OZ_NET_INFO_CONV3_TILE_ROWS = the row-tile height conv3 ran on.  Precision f16x2: 256 / 192 / 128, chosen per call
+ * from the capacity the caller launches with (256 at bench.py's batch cap of 3640 leaves; 128 when the call fits one grid round on that tile, e.g.
+ * an arena's ~430-leaf batches), 128 x 128 tiles on the latency path (max_batch <= 32).
  * Precision f32: what oz_gemm_f32_launch really launched -- 256 (GmBig: a 3x3 convolution whose 256 x 256 tiles fill the chip, e.g. every call
  * of a max_batch = 4096 network), 128 (GmStd: smaller networks, or OZ_NET_OPT_F32_STD_TILE), 64 (the weight-stream kernel of layers with at
  * most 64 rows: one-position networks). */

@@ -474,6 +474,7 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
 }
 
 #include "oz_net_h2.h"
+#define CONV3_LOW_COST 1.15     // a round of 128-row conv3 tiles against 128/192 of a 192-row round (forward_h2's tile choice)
 
 // k_gemm_h2 for callers outside the network object (the trainer's f16x2 mode): out[M][N] fp32 rows = (A . Wh^T) * scale + shift, A and Wh
 // in the h2 layout.  Tile and k-split are chosen from `max_count` (the caller's capacity -- a constant of the trainer, so a
@@ -759,6 +760,7 @@ struct OnnNet : oz_net {
     int sizing() const { return max_batch; }     // the batch size the k-splits of the medium path are chosen for: the capacity, a per-network constant
     size_t partial_cap = 0;          // floats d_partial holds
     bool latency_splits = false;     // oz_net_set_option(OZ_NET_OPT_LATENCY_SPLITS): see conv_ksplit
+    int conv3_tile = 0;              // oz_net_set_option(OZ_NET_OPT_CONV3_TILE): 0 = the forward picks, 128 / 192 / 256 = that tile (bit-identity screen of the three)
     bool f32_std_tile = false;       // oz_net_set_option(OZ_NET_OPT_F32_STD_TILE): precision f32 never takes the 256 x 256 tile (bit-identity screen)
     bool simple_loop = false;        // oz_net_set_option(OZ_NET_OPT_SIMPLE_LOOP): one-barrier-per-k-tile loop for the 3x3 layers (race screen)
     float* d_t2rows = nullptr;       // commit staging: one tap's T2 rows [OZ_LUT_PATTERNS][C] before the slice-major re-layout
@@ -1311,8 +1313,14 @@ struct OnnNet : oz_net {
             const long long blocks = (((long long)max_count * (n - 2) * (n - 2) + BM - 1) / BM) * (C / 256);
             return ((blocks + 255) / 256) * BM;
         };
-        const bool conv3_big = n == 6 || tile_cost(256) < tile_cost(192);
-        last_conv3_rows = small ? 128 : (pp && conv3_big) ? 256 : 192;
+        // ... and the 128-row tile when a call's rows fit ONE round on it but leave a third of the chip idle on the taller tiles (the arena's
+        // <= 512-leaf batches: 430 leaves = 162 blocks of 192 rows, 242 of 128).  Its round costs CONV3_LOW_COST of the row-proportional figure
+        // (12 instead of 18 / 24 MFMAs per phase against the same LDS reads and barriers).
+        int c3rows = n == 6 ? 256 : tile_cost(256) < tile_cost(192) ? 256 : 192;
+        if (n != 6 && pp && (double)tile_cost(128) * CONV3_LOW_COST < (double)tile_cost(c3rows)) c3rows = 128;
+        if (conv3_tile && pp && !small) c3rows = conv3_tile;
+        const bool conv3_big = c3rows == 256, conv3_low = c3rows == 128;
+        last_conv3_rows = small ? 128 : pp ? c3rows : 192;
         // (the k-split stays a constant of the network -- max_batch and the board decide it, not the tile this call picked -- so a position's
         //  result does not depend on the size of the call it sits in)
         const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), n == 6 ? 256 : 192),
@@ -1340,6 +1348,7 @@ struct OnnNet : oz_net {
         next_relu = h2o2;
         if (int rc = small ? launch_small<H2Small, H2Small2>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, 16)
                      : pp && conv3_big ? launch_gemm_h2<H2BigPP, 3>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
+                     : pp && conv3_low ? launch_gemm_h2<H2LowPP, 3>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                      : pp  ? launch_gemm_h2<H2MidPP, 3>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                            : launch_gemm_h2<H2Mid>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
         mark(2, false);
@@ -1879,10 +1888,14 @@ OZ_API int oz_net_set_option(oz_net* net, int option, int value) {
     OZ_REQUIRE(o, "not an OthelloNN network");
     OZ_REQUIRE(option == OZ_NET_OPT_SIMPLE_LOOP || option == OZ_NET_OPT_ACT_TARGET_LOG2 || option == OZ_NET_OPT_LOW_GUARD_LOG2 ||
                option == OZ_NET_OPT_SELF_CHECK || option == OZ_NET_OPT_W_TARGET_LOG2 || option == OZ_NET_OPT_F32_STD_TILE ||
-               option == OZ_NET_OPT_LATENCY_SPLITS, "unknown network option %d", option);
+               option == OZ_NET_OPT_LATENCY_SPLITS || option == OZ_NET_OPT_CONV3_TILE, "unknown network option %d", option);
     std::lock_guard<std::mutex> lk(o->mu);
     if (option == OZ_NET_OPT_SIMPLE_LOOP) o->simple_loop = value != 0;
     else if (option == OZ_NET_OPT_F32_STD_TILE) o->f32_std_tile = value != 0;
+    else if (option == OZ_NET_OPT_CONV3_TILE) {
+        OZ_REQUIRE(value == 0 || value == 128 || value == 192 || value == 256, "OZ_NET_OPT_CONV3_TILE must be 0, 128, 192 or 256 (got %d)", value);
+        o->conv3_tile = value;
+    }
     else if (option == OZ_NET_OPT_LATENCY_SPLITS) { if (o->latency_splits != (value != 0)) { o->latency_splits = value != 0; o->committed = false; } }
     else if (option == OZ_NET_OPT_W_TARGET_LOG2) {
         OZ_REQUIRE(value >= -12 && value <= 15, "OZ_NET_OPT_W_TARGET_LOG2 must be in [-12, 15] (got %d)", value);

@@ -112,7 +112,7 @@ template <int NWM, int NWN, int NTI, int NTJ, int NST = 2> struct H2Cfg {
     static constexpr int TILEA = BM * 128, TILEB = BN * 128, BUF = TILEA + TILEB, LDS = NST * BUF;
     static constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW);     // LDS-DMA instructions per wave per operand tile
     // h2 epilogue: each wave transposes PB 16-row blocks (x 64 channels) per pass through a private LDS slice
-    static constexpr int PB = (NTI % 2 == 0) ? 4 : 2, SLICE = PB * 16 * 256;
+    static constexpr int PB = (NTI % 2 == 0 && NW * 4 * 16 * 256 <= LDS) ? 4 : 2, SLICE = PB * 16 * 256;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
     static_assert(NW * SLICE <= LDS, "epilogue slices must fit in the staging buffers");
     static constexpr bool PP = false;     // main loop: false = one barrier per k-tile; true = 4-phase ping-pong (H2BigPP)
@@ -123,6 +123,9 @@ typedef H2Cfg<2, 4, 4, 2> H2Big;      // conv2, conv4: 256 x 256
 // apart, so one of them is in its MFMA cluster while the other issues LDS reads and LDS-DMA (see k_gemm_h2)
 struct H2BigPP : H2Cfg<2, 4, 4, 2> { static constexpr bool PP = true; };
 struct H2MidPP : H2Cfg<2, 4, 3, 2> { static constexpr bool PP = true; };
+// 128 x 256: conv3 of a call whose rows fit one grid round on this tile but leave a third of the CUs idle on the 192-row one
+// (the arena's <= 512-leaf batches); same k order per output element as the other two: bit-identical
+struct H2LowPP : H2Cfg<2, 4, 2, 2, 3> { static constexpr bool PP = true; };
 // conv2 with conv1 folded into a lookup: the conv1 + BN + ReLU output of a pixel depends only on the 3 x 3 neighbourhood
 // of the position (9 cells, each empty / own / opponent: 3^9 = 19683 patterns), so conv2's A rows are LDS-DMA'd straight
 // from a table of the 19683 possible rows (+ one zero row for taps outside the board) instead of from a conv1 output
@@ -808,12 +811,13 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     // rows of the FIRST half of every wave tile (A: the first RI/2 16-row blocks of each wave row; B: the first RJ/2 of
     // each wave column), instructions 2,3 rows of the second half -- the main loop reads the halves in different phases.
     // (192-row tile: 3 A pieces per wave -- piece 0 early, piece 2 late, piece 1 early for waves 0-3 and late for waves 4-7)
-    auto a_late = [&](int i) -> int { return IA == 4 ? (i >> 1) : (i == 0 ? 0 : i == 2 ? 1 : (wave >= 4 ? 1 : 0)); };
+    // (128-row tile: 2 A pieces per wave -- piece 0 early, piece 1 late)
+    auto a_late = [&](int i) -> int { return IA == 4 ? (i >> 1) : IA == 2 ? i : (i == 0 ? 0 : i == 2 ? 1 : (wave >= 4 ? 1 : 0)); };
     auto a_row0 = [&](int i) -> int {
         if constexpr (!CF::PP) return (wave * IA + i) * 8;
         else {
             constexpr int HR = BM / 4, HBLK = HR / 8;            // rows / 8-row blocks in one half of a wave row
-            const int hb = IA == 4 ? 2 * wave + (i & 1) : (i == 1 ? 8 + (wave & 3) : wave);
+            const int hb = IA == 4 ? 2 * wave + (i & 1) : IA == 2 ? wave : (i == 1 ? 8 + (wave & 3) : wave);
             return (hb / HBLK) * (BM / 2) + a_late(i) * HR + (hb % HBLK) * 8;
         }
     };
@@ -921,10 +925,29 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         // phases after its last ds_read.
         // 192-row tile (IA = 3): a wave issues 7 pieces per tile, 2 or 1 of them per A phase depending on the wave, and
         // vmcnt(3) (the stricter of the two per-wave counts) retires what the next phase reads.
-        static_assert((IA == 4 || IA == 3) && IB == 4 && RI % 2 == 0 && RJ == 4, "ping-pong loop: 256 x 256 or 192 x 256 tile, 8 waves");
+        static_assert((IA == 4 || IA == 3 || IA == 2) && IB == 4 && RI % 2 == 0 && RJ == 4, "ping-pong loop: 256 / 192 / 128 x 256 tile, 8 waves");
         constexpr int HA = RI / 2;                           // 16-row A blocks per half of the wave tile
+        // three LDS stages (the 128-row tile, 3 x 48 KB): the loop stages tile kt + 2 while it multiplies tile kt, so a piece has a whole
+        // k-tile more to land -- with 12 MFMAs per phase the two-stage schedule's two phases (~0.35 us) are shorter than an L2 round trip
+        // and the loop waits on the DMA instead of the matrix pipe.  Same piece order, same waits + the IA + IB pieces of the tile between.
+        constexpr int S = CF::STAGES;
+        static_assert(S == 2 || (S == 3 && IA == 2), "ping-pong loop: two stages, or three on the 128-row tile");
         stage(kbeg, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (S == 3) {                              // tile kbeg + 1 in the loop's piece order: [B e][A e][B l][A l]
+            const int kt1 = kbeg + 1 < nk ? kbeg + 1 : nk - 1;
+            const int slice1 = kt1 / g.taps, tap1 = kt1 - slice1 * g.taps;
+            const long long toff1 = ((long long)(tap1 / 3) * g.Hin + (tap1 % 3)) * rowq + slice1 * 8;
+            unsigned char* la1 = smem + CF::BUF;
+            unsigned char* lb1 = la1 + CF::TILEA;
+            auto pa = [&](int i) {
+                const uint4* ga = ((amask[i] >> tap1) & 1) ? in + (aidx[i] + toff1) : zsrc;
+                __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la1 + a_row0(i) * 128), 16, 0, 0);
+            };
+            auto pb = [&](int i) { __builtin_amdgcn_global_load_lds((h2_gptr)(Wh + bidx[i] + kt1 * 8), (h2_lptr)(lb1 + b_row0(i) * 128), 16, 0, 0); };
+            pb(0); pb(1); pa(0); pb(2); pb(3); pa(1);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(IA + IB) : "memory");       // tile kbeg has landed
+        } else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         f16x8 fa1[HA], fa2[HA], fb1[4], fb2[4];
@@ -940,17 +963,17 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         }
         if (wm == 1) __builtin_amdgcn_s_barrier();           // stagger: wave row 1 is one barrier behind
         // (slice, tap) of the tile being staged, advanced incrementally: no integer division in the loop
-        int ktn = kbeg + 1 < nk ? kbeg + 1 : nk - 1;
+        int ktn = kbeg + (S - 1) < nk ? kbeg + (S - 1) : nk - 1;
         int slice_n = ktn / g.taps, tap_n = ktn - slice_n * g.taps;
+        int bcur = 0, bnext = 1, bstage = S == 3 ? 2 : 1;    // LDS stage of tile kt, of tile kt + 1, of the tile being staged
         for (int kt = kbeg; kt < nk; ++kt) {
-            const int buf = (kt - kbeg) & 1;
             const int slice = slice_n, tap = tap_n, dy = (tap * 11) >> 5, dx = tap - 3 * dy;            // tap / 3, tap % 3 for tap < 9
             const int ktc = ktn;
             const long long toff = ((long long)dy * g.Hin + dx) * rowq + slice * 8;
-            unsigned char* la = smem + (size_t)(buf ^ 1) * CF::BUF;
+            unsigned char* la = smem + (size_t)bstage * CF::BUF;
             unsigned char* lb = la + CF::TILEA;
-            const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * RI * 16 + r16) * 128;
-            const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+            const unsigned char* At = smem + (size_t)bcur * CF::BUF + (wm * RI * 16 + r16) * 128;
+            const unsigned char* Bt = smem + (size_t)bcur * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
             auto dma_a = [&](int i) {
                 const uint4* ga;
                 if constexpr (CF::LUT) ga = lut_src(i, aid[i], slice);
@@ -981,16 +1004,11 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                     fb2[half * 2 + j] = *reinterpret_cast<const f16x8*>(base + (half * 2 + j) * 16 * 128 + oh2);
                 }
             };
-            const unsigned char* Btn = smem + (size_t)(buf ^ 1) * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+            const unsigned char* Btn = smem + (size_t)bnext * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
             // end of an L section: all but the `keep` youngest DMA pieces of this wave have landed, then the barrier
             auto l_end = [&](auto keep) {
                 constexpr int K = decltype(keep)::value;
-                if constexpr (K == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else if constexpr (K == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else if constexpr (K == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else if constexpr (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if constexpr (K == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K) : "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -1016,14 +1034,16 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                 __builtin_amdgcn_sched_barrier(0);
             };
             using std::integral_constant;
-            auto dma_a_early = [&]() { dma_a(0); if (IA == 4 || wave < 4) dma_a(1); };
-            auto dma_a_late = [&]() { dma_a(IA - 1); if (IA == 4) dma_a(2); else if (wave >= 4) dma_a(1); };
-            constexpr int KEEP = IA == 4 ? 4 : 3;
+            auto dma_a_early = [&]() { dma_a(0); if (IA == 4 || (IA == 3 && wave < 4)) dma_a(1); };
+            auto dma_a_late = [&]() { dma_a(IA - 1); if (IA == 4) dma_a(2); else if (IA == 3 && wave >= 4) dma_a(1); };
+            constexpr int KEEP = (IA == 4 ? 4 : 3) + (S == 3 ? IA + IB : 0);
             lda(0); ld_ids(); dma_b(0); dma_b(1); l_end(integral_constant<int, KEEP>{}); mma(0, 0); m_end();     // phase 1
             ldb(1, Bt); dma_a_early(); l_end(integral_constant<int, KEEP>{}); mma(0, 1); m_end();                // phase 2
             lda(1); dma_b(2); dma_b(3); l_end(integral_constant<int, KEEP>{}); mma(1, 0); m_end();               // phase 3
             ldb(0, Btn); dma_a_late(); l_end(integral_constant<int, KEEP>{}); mma(1, 1); m_end();                // phase 4 (B n0 of the next tile)
             if (ktn + 1 < nk) { ++ktn; if (++tap_n == g.taps) { tap_n = 0; ++slice_n; } }    // past the end: re-stage the last tile
+            if constexpr (S == 3) { const int t = bcur; bcur = bnext; bnext = bstage; bstage = t; }
+            else { bcur ^= 1; bnext ^= 1; bstage ^= 1; }
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave rows
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every piece has landed before the epilogue reuses the LDS
