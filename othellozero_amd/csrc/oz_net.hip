@@ -474,7 +474,7 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
 }
 
 #include "oz_net_h2.h"
-#define CONV3_LOW_COST 1.15     // a round of 128-row conv3 tiles against 128/192 of a 192-row round (forward_h2's tile choice)
+#define CONV3_LOW_COST 1.30     // a round of 128-row conv3 tiles against 128/192 of a 192-row round (forward_h2's tile choice)
 
 // k_gemm_h2 for callers outside the network object (the trainer's f16x2 mode): out[M][N] fp32 rows = (A . Wh^T) * scale + shift, A and Wh
 // in the h2 layout.  Tile and k-split are chosen from `max_count` (the caller's capacity -- a constant of the trainer, so a
@@ -1315,7 +1315,8 @@ struct OnnNet : oz_net {
         };
         // ... and the 128-row tile when a call's rows fit ONE round on it but leave a third of the chip idle on the taller tiles (the arena's
         // <= 512-leaf batches: 430 leaves = 162 blocks of 192 rows, 242 of 128).  Its round costs CONV3_LOW_COST of the row-proportional figure
-        // (12 instead of 18 / 24 MFMAs per phase against the same LDS reads and barriers).
+        // (24 instead of 36 MFMAs per phase of the 2-phase loop against the same LDS reads and barriers: 151 / 158 us against 172 / 177 us
+        // for one round of 192-row tiles).
         int c3rows = n == 6 ? 256 : tile_cost(256) < tile_cost(192) ? 256 : 192;
         if (n != 6 && pp && (double)tile_cost(128) * CONV3_LOW_COST < (double)tile_cost(c3rows)) c3rows = 128;
         if (conv3_tile && pp && !small) c3rows = conv3_tile;

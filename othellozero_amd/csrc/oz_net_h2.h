@@ -116,16 +116,17 @@ template <int NWM, int NWN, int NTI, int NTJ, int NST = 2> struct H2Cfg {
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
     static_assert(NW * SLICE <= LDS, "epilogue slices must fit in the staging buffers");
     static constexpr bool PP = false;     // main loop: false = one barrier per k-tile; true = 4-phase ping-pong (H2BigPP)
+    static constexpr int PHASES = 4;      // ping-pong loop: phases per k-tile (2: the (m0, m1) x n half loop of the smaller tiles)
     static constexpr bool LUT = false;    // A rows gathered from the conv1 pattern table (H2BigPPLut), see k_lut_build
 };
 typedef H2Cfg<2, 4, 4, 2> H2Big;      // conv2, conv4: 256 x 256
 // the same tile with the ping-pong main loop: the two wave rows (= the two waves of every SIMD) run half a phase
 // apart, so one of them is in its MFMA cluster while the other issues LDS reads and LDS-DMA (see k_gemm_h2)
 struct H2BigPP : H2Cfg<2, 4, 4, 2> { static constexpr bool PP = true; };
-struct H2MidPP : H2Cfg<2, 4, 3, 2> { static constexpr bool PP = true; };
+struct H2MidPP : H2Cfg<2, 4, 3, 2> { static constexpr bool PP = true; static constexpr int PHASES = 2; };
 // 128 x 256: conv3 of a call whose rows fit one grid round on this tile but leave a third of the CUs idle on the 192-row one
 // (the arena's <= 512-leaf batches); same k order per output element as the other two: bit-identical
-struct H2LowPP : H2Cfg<2, 4, 2, 2, 3> { static constexpr bool PP = true; };
+struct H2LowPP : H2Cfg<2, 4, 2, 2> { static constexpr bool PP = true; static constexpr int PHASES = 2; };
 // conv2 with conv1 folded into a lookup: the conv1 + BN + ReLU output of a pixel depends only on the 3 x 3 neighbourhood
 // of the position (9 cells, each empty / own / opponent: 3^9 = 19683 patterns), so conv2's A rows are LDS-DMA'd straight
 // from a table of the 19683 possible rows (+ one zero row for taps outside the board) instead of from a conv1 output
@@ -907,7 +908,113 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     const int swz = h2_swz(r16);                             // tile bases are multiples of 16 rows
     const int oh1 = ((2 * kg) ^ swz) * 16, oh2 = ((2 * kg + 1) ^ swz) * 16;
 
-    if constexpr (CF::PP) {
+    if constexpr (CF::PP && CF::PHASES == 2) {
+        // ---- 2-phase ping-pong main loop (192 / 128 x 256 tiles): the same two wave rows half a phase apart, but a k-tile is two phases
+        // instead of four -- (m0, m1) x n0, then (m0, m1) x n1 -- so the 12 / 18 MFMAs of a quadrant, too short to cover an L section and
+        // its two barriers (the 4-phase loop on these tiles ran at 0.63 / 0.78 of its MFMA time), become 24 / 36:
+        //   phase 1  L: A m0, m1 of tile t (4 * HA ds_reads);  DMA [Bl(t + 1)] [Be(t + 2)];  M: quadrants (m0, n0) (m1, n0)
+        //   phase 2  L: B n1 of tile t, B n0 of tile t + 1 (8 ds_reads);  DMA [A(t + 2)];     M: quadrants (m0, n1) (m1, n1)
+        // Every output element still receives its products in the same order (k-tile by k-tile, the three plane products in order).
+        // DMA schedule: a region of the two-stage buffer is refilled in the phase after its last ds_read -- the L section ends with
+        // lgkmcnt(0) BEFORE the barrier here, so every wave's reads of phase q are complete before any wave issues phase q + 1's DMA --
+        // and is read two phases (= one k-tile) after its issue; all but the 4 + IA youngest pieces are complete at every L-section end.
+        // Measured (conv3, one MI355X): 192 rows 234 -> 177 us at 512 leaves (one grid round), 1371 -> 1212 us at 4096 (6 rounds); 128 rows
+        // 174 -> 151 us at 430 leaves.  The 256-row tile stays on the 4-phase loop: its m0 x (n0, n1) | m1 x (n0, n1) two-phase form (the
+        // register file has no room for this one) measured -2 % in one round and +1 % at 3640 leaves, and deeper DMA schedules of the 4-phase
+        // loop (a group issued 3 .. 5 phases ahead instead of 2, refilling each region right after its last read) 0 .. +16 %.
+        static_assert(!CF::LUT && (IA == 3 || IA == 2) && IB == 4 && RI % 2 == 0 && RJ == 4 && CF::STAGES == 2, "2-phase ping-pong loop: 192 / 128 x 256 tile, 8 waves");
+        constexpr int HA = RI / 2, KEEP = 4 + IA;
+        auto put_a = [&](int i, int slice, int tap, unsigned char* la) {
+            const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;                                      // tap / 3, tap % 3 for tap < 9
+            const uint4* ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + ((long long)dy * g.Hin + dx) * rowq + slice * 8) : zsrc;
+            __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la + a_row0(i) * 128), 16, 0, 0);
+        };
+        auto put_b = [&](int i, int ktc, unsigned char* lb) {
+            __builtin_amdgcn_global_load_lds((h2_gptr)(Wh + bidx[i] + ktc * 8), (h2_lptr)(lb + b_row0(i) * 128), 16, 0, 0);
+        };
+        int k1 = kbeg + 1 < nk ? kbeg + 1 : nk - 1, slice1 = k1 / g.taps, tap1 = k1 - slice1 * g.taps;      // tile kt + 1, kt + 2 (past the end: the last again)
+        int k2 = kbeg + 2 < nk ? kbeg + 2 : nk - 1, slice2 = k2 / g.taps, tap2 = k2 - slice2 * g.taps;
+        stage(kbeg, 0);
+        {   // what phases 1 and 2 of the tile before the first would have issued: [Be] [A] of tile kbeg + 1
+            unsigned char* st1 = smem + CF::BUF;
+            put_b(0, k1, st1 + CF::TILEA); put_b(1, k1, st1 + CF::TILEA);
+#pragma unroll
+            for (int i = 0; i < IA; ++i) put_a(i, slice1, tap1, st1);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 + IA) : "memory");     // tile kbeg has landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        f16x8 fa1[RI], fa2[RI], fb1[4], fb2[4];
+        {   // B n0 of the first tile (later tiles get it in phase 2 of the tile before)
+            const unsigned char* Bt0 = smem + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                fb1[j] = *reinterpret_cast<const f16x8*>(Bt0 + j * 16 * 128 + oh1);
+                fb2[j] = *reinterpret_cast<const f16x8*>(Bt0 + j * 16 * 128 + oh2);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (wm == 1) __builtin_amdgcn_s_barrier();           // stagger: wave row 1 is one barrier behind
+        for (int kt = kbeg; kt < nk; ++kt) {
+            const int buf = (kt - kbeg) & 1;
+            unsigned char* la_cur = smem + (size_t)buf * CF::BUF;           // stage of tile kt (and of tile kt + 2)
+            unsigned char* la_oth = smem + (size_t)(buf ^ 1) * CF::BUF;     // stage of tile kt + 1
+            const unsigned char* At = la_cur + (wm * RI * 16 + r16) * 128;
+            const unsigned char* Bt = la_cur + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+            const unsigned char* Btn = la_oth + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+            auto ldb = [&](int half, const unsigned char* base) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    fb1[half * 2 + j] = *reinterpret_cast<const f16x8*>(base + (half * 2 + j) * 16 * 128 + oh1);
+                    fb2[half * 2 + j] = *reinterpret_cast<const f16x8*>(base + (half * 2 + j) * 16 * 128 + oh2);
+                }
+            };
+            auto l_end = [&]() {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto mma = [&](int nh) {                         // (m0, nh) (m1, nh): 3 * 2 * RI MFMAs, product-major
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int i = 0; i < RI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            f32x4v& c = acc[i][nh * 2 + j];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? fa2[i] : fa1[i], p == 1 ? fb2[nh * 2 + j] : fb1[nh * 2 + j], c, 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto m_end = [&]() {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // phase 1
+#pragma unroll
+            for (int i = 0; i < RI; ++i) {
+                fa1[i] = *reinterpret_cast<const f16x8*>(At + i * 16 * 128 + oh1);
+                fa2[i] = *reinterpret_cast<const f16x8*>(At + i * 16 * 128 + oh2);
+            }
+            put_b(2, k1, la_oth + CF::TILEA); put_b(3, k1, la_oth + CF::TILEA); put_b(0, k2, la_cur + CF::TILEA); put_b(1, k2, la_cur + CF::TILEA);
+            l_end(); mma(0); m_end();
+            // phase 2
+            ldb(1, Bt); ldb(0, Btn);
+#pragma unroll
+            for (int i = 0; i < IA; ++i) put_a(i, slice2, tap2, la_cur);
+            l_end(); mma(1); m_end();
+            k1 = k2; slice1 = slice2; tap1 = tap2;
+            if (k2 + 1 < nk) { ++k2; if (++tap2 == g.taps) { tap2 = 0; ++slice2; } }
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave rows
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every piece has landed before the epilogue reuses the LDS
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else if constexpr (CF::PP) {
         // ---- 4-phase ping-pong main loop (block 256 x 256, 8 waves = 2 wave rows x 4 wave columns).
         // A k-tile is processed as four quadrants of the 128 x 64 wave tile, (m0,n0) (m0,n1) (m1,n0) (m1,n1); phase q =
         //   L section: ds_read the half-fragments the next MFMAs need (8 / 4 / 8 / 4 reads: A m0 | B n1 | A m1 | B n0 of the
@@ -925,29 +1032,10 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         // phases after its last ds_read.
         // 192-row tile (IA = 3): a wave issues 7 pieces per tile, 2 or 1 of them per A phase depending on the wave, and
         // vmcnt(3) (the stricter of the two per-wave counts) retires what the next phase reads.
-        static_assert((IA == 4 || IA == 3 || IA == 2) && IB == 4 && RI % 2 == 0 && RJ == 4, "ping-pong loop: 256 / 192 / 128 x 256 tile, 8 waves");
+        static_assert((IA == 4 || IA == 3) && IB == 4 && RI % 2 == 0 && RJ == 4, "ping-pong loop: 256 x 256 or 192 x 256 tile, 8 waves");
         constexpr int HA = RI / 2;                           // 16-row A blocks per half of the wave tile
-        // three LDS stages (the 128-row tile, 3 x 48 KB): the loop stages tile kt + 2 while it multiplies tile kt, so a piece has a whole
-        // k-tile more to land -- with 12 MFMAs per phase the two-stage schedule's two phases (~0.35 us) are shorter than an L2 round trip
-        // and the loop waits on the DMA instead of the matrix pipe.  Same piece order, same waits + the IA + IB pieces of the tile between.
-        constexpr int S = CF::STAGES;
-        static_assert(S == 2 || (S == 3 && IA == 2), "ping-pong loop: two stages, or three on the 128-row tile");
         stage(kbeg, 0);
-        if constexpr (S == 3) {                              // tile kbeg + 1 in the loop's piece order: [B e][A e][B l][A l]
-            const int kt1 = kbeg + 1 < nk ? kbeg + 1 : nk - 1;
-            const int slice1 = kt1 / g.taps, tap1 = kt1 - slice1 * g.taps;
-            const long long toff1 = ((long long)(tap1 / 3) * g.Hin + (tap1 % 3)) * rowq + slice1 * 8;
-            unsigned char* la1 = smem + CF::BUF;
-            unsigned char* lb1 = la1 + CF::TILEA;
-            auto pa = [&](int i) {
-                const uint4* ga = ((amask[i] >> tap1) & 1) ? in + (aidx[i] + toff1) : zsrc;
-                __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(la1 + a_row0(i) * 128), 16, 0, 0);
-            };
-            auto pb = [&](int i) { __builtin_amdgcn_global_load_lds((h2_gptr)(Wh + bidx[i] + kt1 * 8), (h2_lptr)(lb1 + b_row0(i) * 128), 16, 0, 0); };
-            pb(0); pb(1); pa(0); pb(2); pb(3); pa(1);
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(IA + IB) : "memory");       // tile kbeg has landed
-        } else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         f16x8 fa1[HA], fa2[HA], fb1[4], fb2[4];
@@ -963,17 +1051,17 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         }
         if (wm == 1) __builtin_amdgcn_s_barrier();           // stagger: wave row 1 is one barrier behind
         // (slice, tap) of the tile being staged, advanced incrementally: no integer division in the loop
-        int ktn = kbeg + (S - 1) < nk ? kbeg + (S - 1) : nk - 1;
+        int ktn = kbeg + 1 < nk ? kbeg + 1 : nk - 1;
         int slice_n = ktn / g.taps, tap_n = ktn - slice_n * g.taps;
-        int bcur = 0, bnext = 1, bstage = S == 3 ? 2 : 1;    // LDS stage of tile kt, of tile kt + 1, of the tile being staged
         for (int kt = kbeg; kt < nk; ++kt) {
+            const int buf = (kt - kbeg) & 1;
             const int slice = slice_n, tap = tap_n, dy = (tap * 11) >> 5, dx = tap - 3 * dy;            // tap / 3, tap % 3 for tap < 9
             const int ktc = ktn;
             const long long toff = ((long long)dy * g.Hin + dx) * rowq + slice * 8;
-            unsigned char* la = smem + (size_t)bstage * CF::BUF;
+            unsigned char* la = smem + (size_t)(buf ^ 1) * CF::BUF;
             unsigned char* lb = la + CF::TILEA;
-            const unsigned char* At = smem + (size_t)bcur * CF::BUF + (wm * RI * 16 + r16) * 128;
-            const unsigned char* Bt = smem + (size_t)bcur * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+            const unsigned char* At = smem + (size_t)buf * CF::BUF + (wm * RI * 16 + r16) * 128;
+            const unsigned char* Bt = smem + (size_t)buf * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
             auto dma_a = [&](int i) {
                 const uint4* ga;
                 if constexpr (CF::LUT) ga = lut_src(i, aid[i], slice);
@@ -1004,11 +1092,16 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                     fb2[half * 2 + j] = *reinterpret_cast<const f16x8*>(base + (half * 2 + j) * 16 * 128 + oh2);
                 }
             };
-            const unsigned char* Btn = smem + (size_t)bnext * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+            const unsigned char* Btn = smem + (size_t)(buf ^ 1) * CF::BUF + CF::TILEA + (wn * RJ * 16 + r16) * 128;
             // end of an L section: all but the `keep` youngest DMA pieces of this wave have landed, then the barrier
             auto l_end = [&](auto keep) {
                 constexpr int K = decltype(keep)::value;
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K) : "memory");
+                if constexpr (K == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else if constexpr (K == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if constexpr (K == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if constexpr (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if constexpr (K == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -1034,16 +1127,14 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
                 __builtin_amdgcn_sched_barrier(0);
             };
             using std::integral_constant;
-            auto dma_a_early = [&]() { dma_a(0); if (IA == 4 || (IA == 3 && wave < 4)) dma_a(1); };
-            auto dma_a_late = [&]() { dma_a(IA - 1); if (IA == 4) dma_a(2); else if (IA == 3 && wave >= 4) dma_a(1); };
-            constexpr int KEEP = (IA == 4 ? 4 : 3) + (S == 3 ? IA + IB : 0);
+            auto dma_a_early = [&]() { dma_a(0); if (IA == 4 || wave < 4) dma_a(1); };
+            auto dma_a_late = [&]() { dma_a(IA - 1); if (IA == 4) dma_a(2); else if (wave >= 4) dma_a(1); };
+            constexpr int KEEP = IA == 4 ? 4 : 3;
             lda(0); ld_ids(); dma_b(0); dma_b(1); l_end(integral_constant<int, KEEP>{}); mma(0, 0); m_end();     // phase 1
             ldb(1, Bt); dma_a_early(); l_end(integral_constant<int, KEEP>{}); mma(0, 1); m_end();                // phase 2
             lda(1); dma_b(2); dma_b(3); l_end(integral_constant<int, KEEP>{}); mma(1, 0); m_end();               // phase 3
             ldb(0, Btn); dma_a_late(); l_end(integral_constant<int, KEEP>{}); mma(1, 1); m_end();                // phase 4 (B n0 of the next tile)
             if (ktn + 1 < nk) { ++ktn; if (++tap_n == g.taps) { tap_n = 0; ++slice_n; } }    // past the end: re-stage the last tile
-            if constexpr (S == 3) { const int t = bcur; bcur = bnext; bnext = bstage; bstage = t; }
-            else { bcur ^= 1; bnext ^= 1; bstage ^= 1; }
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave rows
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every piece has landed before the epilogue reuses the LDS

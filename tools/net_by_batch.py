@@ -4,9 +4,10 @@ import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from othellozero_amd.NNet import NNetWrapper
 rs = np.random.RandomState(0)
-for B in (512, 1024, 2048):
+for B in (512, 1024, 2048, 4096):
     own = rs.randint(0, 2**63, size=B, dtype=np.uint64); opp = rs.randint(0, 2**63, size=B, dtype=np.uint64) & ~own
     net = NNetWrapper((8, 8), num_channels_1=512, max_batch=B, seed=0, precision="f16x2")
+    if B == 4096: own, opp = own[:3640], opp[:3640]          # bench.py's batch cap
     for _ in range(3): net.predict_batch(own, opp)
     net.profile(2); net.profile_kernels(reset=True)
     for _ in range(50): net.predict_batch(own, opp)
