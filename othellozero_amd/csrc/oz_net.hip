@@ -850,10 +850,17 @@ struct OnnNet : oz_net {
         }
         return k;
     }
+    // conv4 of a medium network (max_batch <= 1024) whose rows fit one grid round of 128 x 256 tiles runs on that tile (the 2-phase ping-pong
+    // loop) with half the k-slices the 256-row tile would need to fill the chip: the arena's 512-game networks 2 slices of 72 k-tiles instead of
+    // 4 of 36 (83 + 14 us -> see DESIGN.md); a per-network constant like every k-split
+    bool conv4_low() const {
+        const long long rows = (long long)sizing() * (n - 4) * (n - 4);
+        return sizing() > 32 && sizing() <= 1024 && ((rows + 127) / 128) * (C / 256) <= 256;
+    }
     size_t partial_floats() const {
         if (max_batch <= 32) return (size_t)16 * max_batch * 64 * 1024;
-        size_t need = (size_t)(sizing() >= 1024 ? 4 : 8) * max_batch * 1024;         // fc1 (forward_h2: kfc1)
-        const int px[3] = {n * n, (n - 2) * (n - 2), (n - 4) * (n - 4)}, bm[3] = {256, 192, 256};
+        size_t need = (size_t)(sizing() >= 1024 ? 4 : 16) * max_batch * 1024;        // fc1 (forward_h2: kfc1)
+        const int px[3] = {n * n, (n - 2) * (n - 2), (n - 4) * (n - 4)}, bm[3] = {256, 192, conv4_low() ? 128 : 256};
         for (int i = 0; i < 3; ++i) {
             int k = conv_ksplit(px[i], bm[i]);
             if (i == 1 && conv_ksplit(px[i], 256) > k) k = conv_ksplit(px[i], 256);          // conv3 may run on either tile
@@ -912,10 +919,12 @@ struct OnnNet : oz_net {
         return max_batch <= 32 ? launch_gemm_h2<CF2>(args...) : launch_gemm_h2<CF3>(args...);
     }
 
-    // policy / value heads: batches stage the f2 rows of 16 positions in LDS; few positions (the latency path) keep the 8-position kernel
-    // (same sums in the same order either way)
+    // policy / value heads: the largest batches stage the f2 rows of 16 positions per block in LDS, smaller ones 4 (a block's time is its chain of
+    // L2 round trips, not its arithmetic: 512 positions 21.6 us on 32 blocks, 11.0 us on 128; 2048: 22 -> 14 us; 3640: 23 us either way); one
+    // block of 8 for the few positions of the latency path (same sums in the same order in all three)
     void launch_heads(int max_count, const int* d_count, float* d_pi, float* d_v, hipStream_t s) {
-        if (max_count >= 64) hipLaunchKernelGGL(k_heads_t<HEADS_LP>, dim3((max_count + HEADS_LP - 1) / HEADS_LP), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        if (max_count >= 3072) hipLaunchKernelGGL(k_heads_t<HEADS_LP>, dim3((max_count + HEADS_LP - 1) / HEADS_LP), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        else if (max_count > HEADS_P) hipLaunchKernelGGL(k_heads_t<4>, dim3((max_count + 3) / 4), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
         else hipLaunchKernelGGL(k_heads_t<HEADS_P>, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
     }
 
@@ -1325,7 +1334,7 @@ struct OnnNet : oz_net {
         // (the k-split stays a constant of the network -- max_batch and the board decide it, not the tile this call picked -- so a position's
         //  result does not depend on the size of the call it sits in)
         const int k2 = conv_ksplit(n * n, 256), k3 = conv_ksplit((n - 2) * (n - 2), n == 6 ? 256 : 192),
-                  k4 = conv_ksplit((n - 4) * (n - 4), 256);
+                  k4 = conv_ksplit((n - 4) * (n - 4), conv4_low() ? 128 : 256);
         // h2 output (and the low-side guard of the tensor) unless this is the layer a calibration pass wants as fp32 rows
         const int h2o1 = calib == 1 ? 0 : 1, h2o2 = calib == 2 ? 0 : 1, h2o3 = calib == 3 ? 0 : 1, h2o4 = calib == 4 ? 0 : 1;
         mark(1, true);
@@ -1358,6 +1367,7 @@ struct OnnNet : oz_net {
         next_low = low_of(3, guard);
         next_relu = h2o3;
         if (int rc = small ? launch_small<H2Small, H2Small2>(act3, 3, act4, h2o3, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, 16)
+                     : pp && conv4_low() ? launch_gemm_h2<H2LowPP, 4>(act3, 3, act4, h2o3, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
                      : pp  ? launch_gemm_h2<H2BigPP, 4>(act3, 3, act4, h2o3, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
                            : launch_gemm_h2<H2Big>(act3, 3, act4, h2o3, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)) return rc;
         mark(3, false);
@@ -1368,12 +1378,14 @@ struct OnnNet : oz_net {
         //  the 128 x 128 tile because the k-slices and the order inside them are the same -- tools/pp_race_check.py)
         next_low = low_of(4, guard);
         next_relu = h2o4;
-        // (medium networks, max_batch < 1024: 8 k-slices -- fc1 at 512 rows is 32 output tiles of 128 x 128; 4 slices = 128 blocks of 64 k-tiles
-        //  took 58 us + its reduce in the arena's 512-leaf batches, round 5; the split is keyed on max_batch, a per-network constant)
-        const int kfc1 = sizing() >= 1024 ? 4 : 8;
+        // (medium networks, max_batch < 1024: 16 k-slices on the 128 x 256 tile of the 2-phase ping-pong loop -- fc1 at 512 rows is 16 output tiles,
+        //  x 16 slices = one block of 16 k-tiles per CU: 34 us in the arena's 512-leaf batches; 8 slices on 128 x 128 tiles 41 us, 4 slices 58 us
+        //  (round 5); the split is keyed on max_batch, a per-network constant)
+        const int kfc1 = sizing() >= 1024 ? 4 : 16;
         if (int rc = small ? launch_small<H2Small, H2Small2>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)
                      : (pp && sizing() >= 1024 && max_count >= 1024) ? launch_gemm_h2<H2BigPP, 5>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
-                                                          : launch_small<H2Small, H2Small2>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, kfc1)) return rc;
+                     : pp ? launch_gemm_h2<H2LowPP, 5>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, kfc1)
+                          : launch_small<H2Small, H2Small2>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, kfc1)) return rc;
         mark(4, false);
         if (calib == 4) { OZ_HIP(hipGetLastError()); return OZ_OK; }
         mark(5, true);
