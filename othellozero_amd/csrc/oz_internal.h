@@ -148,10 +148,13 @@ struct GemmGeom {
     // (adding exact zeros changes no bit of the result).  ksplit must be 1.
     int pixmajor, core_lo, core_hi;
 };
+// a split-K launch whose fixed-order reduce (+ scale, shift, ReLU) is left to the consumer of the rows (the heads kernel stages fc2's rows
+// straight from the k-slice slabs: one launch less per forward): slab s holds the raw sums of k-slice s at partial[s * slab + row * N + col]
+struct OzDeferredReduce { const float* partial = nullptr; long long slab = 0; int ksplit = 0; const float* scale = nullptr; const float* shift = nullptr; };
 int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
                        const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
                        hipStream_t s, float* partial, long long partial_floats, int sizing_count = 0, int core_lo = 0, int core_hi = -1,
-                       int* tile_rows_out = nullptr, int force_std_tile = 0);
+                       int* tile_rows_out = nullptr, int force_std_tile = 0, OzDeferredReduce* defer = nullptr);
 // the f16x2 GEMM (k_gemm_h2, oz_net_h2.h) on h2-layout operands, fp32 rows out; zero_line = >= 256 B of zeros, flag = sticky range flag
 int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, const float* shift, float* out, const int* d_count, int max_count,
                       int Hin, int Hout, int pad, int Cin, int taps, int N, hipStream_t s, float* partial, long long partial_floats,

@@ -388,7 +388,9 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_f32(const float* __restri
 int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, const float* shift, float* out,
                        const int* d_count, int max_count, int Hin, int Hout, int pad, int Cin, int taps, int N, int relu,
                        hipStream_t s, float* partial, long long partial_floats, int sizing_count, int core_lo, int core_hi,
-                       int* tile_rows_out, int force_std_tile) {
+                       int* tile_rows_out, int force_std_tile, OzDeferredReduce* defer) {
+    // defer (optional): a split launch leaves its reduce to the consumer (defer->ksplit > 1 says so; relu must be 1, the consumer applies it)
+    if (defer) *defer = OzDeferredReduce();
     // tile_rows_out (optional): the row-tile height this launch ran on -- 64 = the weight-stream kernel, 128 = GmStd, 256 = GmBig;
     // force_std_tile: never the 256 x 256 tile (OZ_NET_OPT_F32_STD_TILE: the bit-identity screen of the two tiles)
     int tile_rows_dummy = 0;
@@ -419,6 +421,7 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
             g.ksplit = ks; g.slab = slab; g.pixmajor = 0;
             tile_rows = 64;
             hipLaunchKernelGGL(k_gemm_f32_skinny, dim3(N / SK_COLS, ks), dim3(256), 0, s, in, Wt, d_count, g.K, N, kb, partial, slab, g);
+            if (defer && relu) { defer->partial = partial; defer->slab = slab; defer->ksplit = ks; defer->scale = scale; defer->shift = shift; OZ_HIP(hipGetLastError()); return OZ_OK; }
             const long long quads = (slab + 3) / 4;
             // (round 5, measured and removed: one output per thread with all 72 slices in flight -- 6.1 against 6.6 us: a kernel of this kind is
             //  launch + count + one round trip to the slabs + store ~ 5 us whatever the loop looks like; fewer launches is what is left)
@@ -464,7 +467,8 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
     tile_rows = GmStd::BM;
     hipLaunchKernelGGL(k_gemm_f32<GmStd>, dim3(grid, ksplit), dim3(GmStd::NT), GmStd::LDS_BYTES, s, in, Wt, scale, shift, out, d_count, g, num_mt, partial);
     OZ_HIP(hipGetLastError());
-    if (ksplit > 1) {
+    if (ksplit > 1 && defer && relu) { defer->partial = partial; defer->slab = g.slab; defer->ksplit = ksplit; defer->scale = scale; defer->shift = shift; }
+    else if (ksplit > 1) {
         const long long quads = (Mmax * N + 3) / 4;
         hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, partial, g.slab, ksplit, N, Hout * Hout,
                            d_count, scale, shift, relu, out);
@@ -558,7 +562,7 @@ template <int LP>
 __global__ __launch_bounds__(256) void k_heads_t(const float* __restrict__ f2 /*[B][512]*/, const int* __restrict__ d_count,
                                                  int A, const float* __restrict__ Wpi /*[512][A]*/, const float* __restrict__ bpi,
                                                  const float* __restrict__ Wv /*[512]*/, const float* __restrict__ bv,
-                                                 float* __restrict__ pi, float* __restrict__ v) {
+                                                 float* __restrict__ pi, float* __restrict__ v, OzDeferredReduce dr) {
     __shared__ __attribute__((aligned(16))) float xs[LP][512];
     __shared__ float part[4][LP][64];
     __shared__ float vpart_s[4][LP];
@@ -581,6 +585,30 @@ __global__ __launch_bounds__(256) void k_heads_t(const float* __restrict__ f2 /*
     float wgt[WB];
 #pragma unroll
     for (int j = 0; j < WB; ++j) wgt[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, lo, j * A * 4, 0));
+    if (dr.ksplit > 1) {
+        // fc2 ran as k-slices and left its reduce here (OzDeferredReduce): the rows are staged as k_splitk_reduce_f32 would have written them --
+        // slices added in order s = 0, 1, ..., then scale, shift, ReLU: the same bits -- one launch and one round trip through memory less
+#pragma unroll 1
+        for (int q = threadIdx.x; q < LP * 128; q += 256) {             // 16-byte pieces of the rows that exist (the others are never stored)
+            const int p = q >> 7, c4 = (q & 127) * 4;
+            if (b0 + p >= count) break;
+            const float* src = dr.partial + (size_t)(b0 + p) * 512 + c4;
+            f32x4 a = *reinterpret_cast<const f32x4*>(src);
+            constexpr int RB = 15;
+            for (int s0 = 1; s0 < dr.ksplit; s0 += RB) {
+                f32x4 b[RB];
+#pragma unroll
+                for (int t = 0; t < RB; ++t) if (s0 + t < dr.ksplit) b[t] = *reinterpret_cast<const f32x4*>(src + (size_t)(s0 + t) * dr.slab);
+#pragma unroll
+                for (int t = 0; t < RB; ++t) if (s0 + t < dr.ksplit) { a[0] += b[t][0]; a[1] += b[t][1]; a[2] += b[t][2]; a[3] += b[t][3]; }
+            }
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(dr.scale + c4), sh = *reinterpret_cast<const f32x4*>(dr.shift + c4);
+            f32x4 r;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const float y = fmaf(a[t], sc[t], sh[t]); r[t] = y < 0.f ? 0.f : y; }
+            *reinterpret_cast<f32x4*>(&xs[p][c4]) = r;
+        }
+    } else
     for (int q = threadIdx.x; q < LP * 128; q += 256) {                 // 16-byte pieces; rows beyond the batch repeat the last one (never stored)
         const int p = q >> 7, c4 = (q & 127) * 4;
         *reinterpret_cast<f32x4*>(&xs[p][c4]) = *reinterpret_cast<const f32x4*>(f2 + (size_t)(b0 + p < count ? b0 + p : count - 1) * 512 + c4);
@@ -814,11 +842,11 @@ struct OnnNet : oz_net {
     }
 
     int launch_gemm(const float* in, const float* Wt, int layer, float* out, const int* d_count, int max_count, int Hin,
-                    int Hout, int pad, int Cin, int taps, int N, hipStream_t s) {
+                    int Hout, int pad, int Cin, int taps, int N, hipStream_t s, OzDeferredReduce* defer = nullptr) {
         // small and medium networks (max_batch <= 512) split K over the idle CUs: latency, not throughput
         return oz_gemm_f32_launch(in, Wt, d_scale[layer], d_shift[layer], out, d_count, max_count, Hin, Hout, pad, Cin, taps, N, 1, s,
                                   d_part32, d_part32 ? (long long)part32_floats() : 0, sizing(), 0, -1,
-                                  layer == 2 ? &last_conv3_rows : nullptr, f32_std_tile ? 1 : 0);       // layer 2 = conv3: what oz_net_get_info reports
+                                  layer == 2 ? &last_conv3_rows : nullptr, f32_std_tile ? 1 : 0, defer);  // layer 2 = conv3: what oz_net_get_info reports
     }
 
     // precision f32: split-K slabs per position-row budget (small networks 16 slices, medium ones fewer; none for large batches)
@@ -902,7 +930,10 @@ struct OnnNet : oz_net {
             const long long threads = (long long)max_count * Hout * Hout * (N / 8);
             hipLaunchKernelGGL(k_splitk_reduce_h2, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)d_partial,
                                g.slab, ksplit, N, Hout * Hout, d_count, d_scale_h2[layer - 1], d_shift_h2[layer - 1], 1, (uint4*)out_final, d_flag, low);
-        } else if (ksplit > 1) {                  // fp32 rows out (fc2, calibration passes): the fp32 path's fixed-order reduce
+        } else if (ksplit > 1 && layer == 5 && relu && !scale_alt) {      // fc2: the heads kernel adds the slices (launch_heads)
+            fc2_defer.partial = d_partial; fc2_defer.slab = g.slab; fc2_defer.ksplit = ksplit;
+            fc2_defer.scale = d_scale_h2[layer - 1]; fc2_defer.shift = d_shift_h2[layer - 1];
+        } else if (ksplit > 1) {                  // fp32 rows out (calibration passes): the fp32 path's fixed-order reduce
             const long long quads = ((long long)max_count * Hout * Hout * N + 3) / 4;
             hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float*)d_partial, g.slab, ksplit, N,
                                Hout * Hout, d_count, scale_alt ? scale_alt : d_scale_h2[layer - 1], shift_alt ? shift_alt : d_shift_h2[layer - 1], relu,
@@ -922,10 +953,13 @@ struct OnnNet : oz_net {
     // policy / value heads: the largest batches stage the f2 rows of 16 positions per block in LDS, smaller ones 4 (a block's time is its chain of
     // L2 round trips, not its arithmetic: 512 positions 21.6 us on 32 blocks, 11.0 us on 128; 2048: 22 -> 14 us; 3640: 23 us either way); one
     // block of 8 for the few positions of the latency path (same sums in the same order in all three)
+    OzDeferredReduce fc2_defer;       // set by the fc2 launch of a forward when its k-slices are reduced by the heads kernel
     void launch_heads(int max_count, const int* d_count, float* d_pi, float* d_v, hipStream_t s) {
-        if (max_count >= 3072) hipLaunchKernelGGL(k_heads_t<HEADS_LP>, dim3((max_count + HEADS_LP - 1) / HEADS_LP), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
-        else if (max_count > HEADS_P) hipLaunchKernelGGL(k_heads_t<4>, dim3((max_count + 3) / 4), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
-        else hipLaunchKernelGGL(k_heads_t<HEADS_P>, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v);
+        const OzDeferredReduce dr = fc2_defer;
+        fc2_defer = OzDeferredReduce();
+        if (max_count >= 3072) hipLaunchKernelGGL(k_heads_t<HEADS_LP>, dim3((max_count + HEADS_LP - 1) / HEADS_LP), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v, dr);
+        else if (max_count > HEADS_P) hipLaunchKernelGGL(k_heads_t<4>, dim3((max_count + 3) / 4), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v, dr);
+        else hipLaunchKernelGGL(k_heads_t<HEADS_P>, dim3((max_count + HEADS_P - 1) / HEADS_P), dim3(256), 0, s, f2, d_count, A, d_wpi, d_bpi, d_wv, d_bv, d_pi, d_v, dr);
     }
 
     // conv1 + conv2 as the table gather-sum: one table slice per XCD at 512 filters, the thread-per-(pixel, 8 channels) kernel otherwise
@@ -1460,7 +1494,7 @@ struct OnnNet : oz_net {
         if (int rc = launch_gemm(act4, d_wt[3], 4, f1, d_count, max_count, 1, 1, 0, F, 1, 1024, s)) return rc;
         mark(4, false);
         mark(5, true);
-        if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s)) return rc;
+        if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, &fc2_defer)) return rc;
         mark(5, false);
         mark(6, true);
         launch_heads(max_count, d_count, d_pi, d_v, s);

@@ -923,7 +923,7 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
         // register file has no room for this one) measured -2 % in one round and +1 % at 3640 leaves, and deeper DMA schedules of the 4-phase
         // loop (a group issued 3 .. 5 phases ahead instead of 2, refilling each region right after its last read) 0 .. +16 %.
         static_assert(!CF::LUT && (IA == 3 || IA == 2) && IB == 4 && RI % 2 == 0 && RJ == 4 && CF::STAGES == 2, "2-phase ping-pong loop: 192 / 128 x 256 tile, 8 waves");
-        constexpr int HA = RI / 2, KEEP = 4 + IA;
+        constexpr int KEEP = 4 + IA;
         auto put_a = [&](int i, int slice, int tap, unsigned char* la) {
             const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;                                      // tap / 3, tap % 3 for tap < 9
             const uint4* ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + ((long long)dy * g.Hin + dx) * rowq + slice * 8) : zsrc;
