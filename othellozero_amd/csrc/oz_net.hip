@@ -495,6 +495,7 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
     if (!attr_set) {
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2BigPP::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2MidPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2MidPP::LDS));
+        OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2LowPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2LowPP::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small2::LDS));
         attr_set = true;
@@ -512,18 +513,17 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
     const bool mid = big && tile_cost(192) < tile_cost(256);
     // (round 5, measured and removed: a few 256 x 256 tiles with an 8 .. 16-way k split for launches of 8 .. 96 big tiles -- the trainer's GEMMs at the
     //  reference's batch -- 45 us + a larger reduce against 40 us on the 128 x 128 tiles: 0.99 -> 1.04 ms per step)
-    const bool bigk = false;
-    const int BM = mid ? 192 : (big || bigk) ? 256 : 128, BN = (big || bigk) ? 256 : 128;
+    // launches too small for those: the 128 x 256 tile of the 2-phase ping-pong loop (8 waves, 24 MFMAs per M section) with the k loop split until
+    // every CU has a block -- twice the 128 x 128 tile's work per k-tile in about the same time (1.0 against 1.06 us).  Needs a k-slice of >= 8 tiles.
+    const bool low = !big && partial != nullptr;
+    const int BM = mid ? 192 : big ? 256 : 128, BN = (big || low) ? 256 : 128;
     const int num_mt = (int)((Mmax + BM - 1) / BM);
     int ksplit = 1;
-    if (bigk) {
-        const int nk = g.K / H2_BK;
-        while (ksplit < 16 && big_blocks * ksplit < 128 && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * Mmax * N <= partial_floats) ksplit *= 2;
-    } else
     if (!big && partial) {
         const long long blocks = (long long)num_mt * (N / BN);
         const int nk = g.K / H2_BK;
-        while (ksplit < 16 && blocks * ksplit < 256 && nk / (ksplit * 2) >= 8 && (long long)(ksplit * 2) * Mmax * N <= partial_floats) ksplit *= 2;
+        // the largest split <= 16 that keeps the grid within one round of the 256 CUs (any number of slices: the k range is divided proportionally)
+        while (ksplit < 16 && blocks * (ksplit + 1) <= 256 && nk / (ksplit + 1) >= 8 && (long long)(ksplit + 1) * Mmax * N <= partial_floats) ++ksplit;
     }
     g.ksplit = ksplit;
     const int per_mt = (N / BN) * ksplit;
@@ -532,14 +532,14 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
     if (mid)
         hipLaunchKernelGGL(k_gemm_h2<H2MidPP>, dim3(grid), dim3(H2MidPP::NT), H2MidPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
                            d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
-    else if (big || bigk)
+    else if (big)
         hipLaunchKernelGGL(k_gemm_h2<H2BigPP>, dim3(grid), dim3(H2BigPP::NT), H2BigPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
                            d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
-    else if (ksplit <= 4)
-        hipLaunchKernelGGL(k_gemm_h2<H2Small>, dim3(grid), dim3(H2Small::NT), H2Small::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
+    else if (low)
+        hipLaunchKernelGGL(k_gemm_h2<H2LowPP>, dim3(grid), dim3(H2LowPP::NT), H2LowPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
                            d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
     else
-        hipLaunchKernelGGL(k_gemm_h2<H2Small2>, dim3(grid), dim3(H2Small2::NT), H2Small2::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
+        hipLaunchKernelGGL(k_gemm_h2<H2Small>, dim3(grid), dim3(H2Small::NT), H2Small::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
                            d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
     if (ksplit > 1) {
         const long long quads = (Mmax * N + 3) / 4;
@@ -1423,10 +1423,10 @@ struct OnnNet : oz_net {
         mark(4, false);
         if (calib == 4) { OZ_HIP(hipGetLastError()); return OZ_OK; }
         mark(5, true);
-        // fc2: one position has 4 blocks of 32 k-tiles -> small networks split k 8 ways too, medium ones 4 ways (from max_batch)
+        // fc2: one position has 4 blocks of 32 k-tiles -> small and medium networks split k 8 ways (from max_batch); the heads kernel adds the slices
         // (large networks: one k-slice on the four-wave form of the thin tile, bit-identical to the two-wave one)
         if (int rc = sizing() > 512 ? launch_gemm_h2<H2Thin4w, 6>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, 1)
-                                   : launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, small ? 8 : 4)) return rc;
+                                   : launch_small<H2Thin, H2Thin2>(f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, 8)) return rc;
         mark(5, false);
         mark(6, true);
         launch_heads(max_count, d_count, d_pi, d_v, s);
