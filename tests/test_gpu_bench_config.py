@@ -173,6 +173,38 @@ def test_f32_big_tile_bit_identical_to_the_standard_tile(oz):
         del net, one
 
 
+def test_conv3_tiles_bit_identical(oz):
+    """precision f16x2: conv3's three row tiles -- 256 rows (4-phase ping-pong loop), 192 and 128 rows (2-phase loop) -- add every output
+    element's products in the same order, so (pi, v) must be BIT-identical whichever tile a call runs on (OZ_NET_OPT_CONV3_TILE forces one):
+    the arena's network (max_batch 512: also conv4 and fc1 on the 128-row tile, fc2's k-slices added inside the heads kernel) at the call sizes
+    on either side of the forward's own choice, and bench.py's network at the cap and at a full call; every result within 1e-5 of float64.
+    Also the screen for the LDS-DMA schedule of the 2-phase loop (regions refilled in the phase after their last read)."""
+    from othellozero_amd.NNet import NNetWrapper
+    n = 8
+    w, own, opp, pi64, v64 = _case(n)
+    for max_batch, counts in ((512, ((100, 128), (430, 128), (456, 192), (512, 192))), (B, ((3640, 256), (B, 192)))):
+        net = NNetWrapper((n, n), num_channels_1=C, max_batch=max_batch, weights=w, precision="f16x2")
+        for count, picked in counts:
+            net.set_option(oz.NET_OPT_CONV3_TILE, 0)
+            p0, v0 = net.predict_batch(own[:count], opp[:count])
+            assert net.conv3_tile_rows() == picked, (max_batch, count, net.conv3_tile_rows())
+            assert np.abs(p0.reshape(count, -1) - pi64[:count]).max() <= TOL and np.abs(v0 - v64[:count]).max() <= TOL
+            for tile in (128, 192, 256):
+                net.set_option(oz.NET_OPT_CONV3_TILE, tile)
+                pt, vt = net.predict_batch(own[:count], opp[:count])
+                assert net.conv3_tile_rows() == tile
+                assert np.array_equal(pt, p0) and np.array_equal(vt, v0), (max_batch, count, tile)
+        net.set_option(oz.NET_OPT_CONV3_TILE, 0)
+        # a position's result does not depend on the size of the call (nor, therefore, on the tile the call picked)
+        pa, va = net.predict_batch(own[:counts[0][0]], opp[:counts[0][0]])
+        pb, vb = net.predict_batch(own[:counts[-1][0]], opp[:counts[-1][0]])
+        k = counts[0][0]
+        assert np.array_equal(pb.reshape(counts[-1][0], -1)[:k], pa.reshape(k, -1)) and np.array_equal(vb[:k], va)
+        with pytest.raises(oz.OzError):
+            net.set_option(oz.NET_OPT_CONV3_TILE, 64)
+        del net
+
+
 def test_config5_real_networks_whole_games_vs_oracle(oz):
     """bench.py's config5 leg (BASELINE configs[4] with REAL networks): 512 arena games x 800 sims per move and agent on two 512-filter
     networks (seeds 0 / 1), every game played TO THE END; two sampled WHOLE games are replayed by the oracle's arena (agents.py:44-84
