@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r26
+mkdir -p $O
+timeout -k 10 550 python tools/soak_real_net.py --driver lockstep --sample 6 > $O/soak_lockstep.txt 2>&1 || { tail -20 $O/soak_lockstep.txt; exit 1; }
+tail -3 $O/soak_lockstep.txt
+timeout -k 10 550 python tools/soak_real_net.py --driver free --batch-cap 0 --sample 6 > $O/soak_free_nocap.txt 2>&1 || { tail -20 $O/soak_free_nocap.txt; exit 1; }
+tail -3 $O/soak_free_nocap.txt
