@@ -61,9 +61,10 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
                          if layer == 3 else "k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)"),
                  peak=PEAK_F32_MATRIX_TFLOPS, frac=achieved / PEAK_F32_MATRIX_TFLOPS)
     else:
-        tail = "implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, 4-phase ping-pong loop"
+        loop = "4-phase ping-pong loop" if (layer != 3 or conv3_rows == 256) else "2-phase ping-pong loop"
+        tail = f"implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, {loop}"
         if layer == 3:
-            cfg = "H2BigPP" if conv3_rows == 256 else "H2MidPP"
+            cfg = {256: "H2BigPP", 192: "H2MidPP", 128: "H2LowPP"}.get(conv3_rows, "H2MidPP")
             kernel = (f"k_gemm_h2<{cfg}, 3> (conv3: 3x3 valid, 512->512, {n}x{n} -> {n - 2}x{n - 2}, {conv3_rows} x 256 tiles, {tail}); "
                       "conv1 + conv2 = k_conv2_lut table gather-sum")
         else:
@@ -542,8 +543,9 @@ def config5_arena(channels, precision, plies=0, games=512, sims=800, sample=2, d
     roof = roofline(precision, dom_layer, ach, dom_ms, dom_launches, leaves, n, channels, conv3_rows=conv3_rows)
     roof["traffic"], roof["traffic_source"] = None, "not measured at this launch shape"
     roof["leaves_per_launch"] = leaves / max(dom_launches, 1)
-    roof["grid_note"] = (f"{leaves / max(dom_launches, 1):.0f} leaves per launch = {leaves / max(dom_launches, 1) * (n - 2) ** 2:.0f} rows on {conv3_rows}-row tiles: "
-                         f"{-(-int(leaves / max(dom_launches, 1) * (n - 2) ** 2) // conv3_rows) * (channels // 256)} blocks on 256 CUs, one k-slice each")
+    roof["grid_note"] = (f"{leaves / max(dom_launches, 1):.0f} leaves per launch on average; the forward picks the tile per call: 192 rows (2-phase loop) while 456 .. 512 "
+                         "games are alive (512 leaves = 18432 rows = 192 blocks on 256 CUs, one k-slice each), 128 rows below (<= 256 blocks); conv3_tile_rows of the "
+                         f"LAST call of the run: {conv3_rows}")
     kernel_plies = 4
     for nt in nets:
         nt.profile_kernels(reset=True); nt.profile(2)
