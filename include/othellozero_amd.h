@@ -124,7 +124,7 @@ int oz_net_set_tables(oz_net* net, int mode);
 int oz_net_set_eval_cache(oz_net* net, int64_t entries);
 int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int64_t* hits, int64_t* inserts);
 /* diagnostics switch, per network (default 0): the 3x3 convolutions of precision f16x2 on the one-barrier-per-k-tile main loop instead of
- * the 4-phase ping-pong loop.  Same tiles' accumulation order, bit-identical results: the reference form the LDS-DMA race screen
+ * the ping-pong loops (4-phase on the 256-row tile, 2-phase on the 192- and 128-row tiles).  Same accumulation order, bit-identical results: the reference form the LDS-DMA race screen
  * (tools/pp_race_check.py, test_pingpong_conv_loop_bit_identical_to_simple_loop) compares the ping-pong schedule against. */
 #define OZ_NET_OPT_SIMPLE_LOOP 1
 /* precision f16x2, all take effect at the next oz_net_commit: the powers of two the per-channel calibration maxima (ACT, default -2) and the

@@ -1304,7 +1304,7 @@ struct OnnNet : oz_net {
     // layer's BN output BEFORE the ReLU as fp32 rows (no h2 split, no guard) into its activation buffer, for k_rows_colmax.
     int forward_h2(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi, float* d_v,
                    hipStream_t s, int calib = 0) {
-        // main loop of the 3x3 convolutions: the 4-phase ping-pong loop, or (oz_net_set_option OZ_NET_OPT_SIMPLE_LOOP: the reference
+        // main loop of the 3x3 convolutions: the ping-pong loops (4 phases per k-tile on 256-row tiles, 2 on 192 / 128), or (oz_net_set_option OZ_NET_OPT_SIMPLE_LOOP: the reference
         // form the race screen compares against, tools/pp_race_check.py) one barrier per k-tile; same accumulation order, bit-identical
         const bool pp = !simple_loop;
         // The input planes are discrete, so conv1 (and conv2 behind it) are functions of small neighbourhood patterns

@@ -51,9 +51,10 @@
 // ds_write pass); the LDS image is lane-linear per wave instruction (8 rows of 8 chunks) and made
 // bank-conflict-free by XOR-swizzling the 16-byte chunk index with h2_swz(row) on the SOURCE address and on the
 // read address (SQ_LDS_BANK_CONFLICT measured); A rows are gathered per 3x3 tap, out-of-image taps read a
-// zero line.  Two LDS stages.  Main loop of the 3x3 convolutions (H2BigPP / H2MidPP): 4-phase ping-pong -- the two
-// wave rows (one wave of each per SIMD) run one barrier apart, one in its MFMA cluster while the other issues its LDS
-// reads and LDS-DMA pieces, counted vmcnt so that pieces stay in flight across barriers (details at the loop).  The
+// zero line.  Two LDS stages.  Main loop of the 3x3 convolutions: ping-pong -- the two wave rows (one wave of each per SIMD)
+// run one barrier apart, one in its MFMA cluster while the other issues its LDS reads and LDS-DMA pieces, counted vmcnt
+// so that pieces stay in flight across barriers; four phases per k-tile on the 256-row tile (H2BigPP), two on the 192- and
+// 128-row tiles (H2MidPP / H2LowPP, round 5) -- details at the loops.  The
 // dense layers keep the simple loop: one barrier per k-tile, DMA interleaved with the MFMA stream (sched_group_barrier).
 // Epilogue = BN scale/shift + ReLU, then fp32 rows or the h2 layout for the
 // next layer (transposed through LDS so that global stores are 16-byte chunks of whole rows).
@@ -115,7 +116,7 @@ template <int NWM, int NWN, int NTI, int NTJ, int NST = 2> struct H2Cfg {
     static constexpr int PB = (NTI % 2 == 0 && NW * 4 * 16 * 256 <= LDS) ? 4 : 2, SLICE = PB * 16 * 256;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
     static_assert(NW * SLICE <= LDS, "epilogue slices must fit in the staging buffers");
-    static constexpr bool PP = false;     // main loop: false = one barrier per k-tile; true = 4-phase ping-pong (H2BigPP)
+    static constexpr bool PP = false;     // main loop: false = one barrier per k-tile; true = ping-pong (H2BigPP / H2MidPP / H2LowPP)
     static constexpr int PHASES = 4;      // ping-pong loop: phases per k-tile (2: the (m0, m1) x n half loop of the smaller tiles)
     static constexpr bool LUT = false;    // A rows gathered from the conv1 pattern table (H2BigPPLut), see k_lut_build
 };
