@@ -907,7 +907,8 @@ struct oz_trainer {
     hipStream_t s2 = nullptr;
     hipEvent_t ev_dz[6] = {}, ev_w = nullptr;
     hipEvent_t ev_pre = nullptr, ev_wt = nullptr, ev_wd = nullptr;      // derived weight operands are rebuilt on s2 beside the first forward kernels
-    bool wait_wt = false, wait_wd = false;
+    hipEvent_t ev_wl[4] = {nullptr, nullptr, nullptr, nullptr};         // f16x2: the h2 forward operand of layer l = 1 .. 3 is ready (the main stream waits layer by layer)
+    bool wait_wt = false, wait_wd = false, wait_wl[4] = {false, false, false, false};
     // f16x2 mode (oz_trainer_set_precision 1): conv2..4 forward and data gradient on k_gemm_h2
     int h2 = 0;
     uint4 *Wh[4] = {}, *Whd[4] = {}, *a_h2[3] = {}, *dz_h2[4] = {};
@@ -939,7 +940,7 @@ struct oz_trainer {
         if (h_in) hipHostFree(h_in);
         for (hipEvent_t e : ev_dz) if (e) hipEventDestroy(e);
         if (ev_w) hipEventDestroy(ev_w);
-        for (hipEvent_t e : {ev_pre, ev_wt, ev_wd}) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : {ev_pre, ev_wt, ev_wd, ev_wl[1], ev_wl[2], ev_wl[3]}) if (e) hipEventDestroy(e);
         if (s2) hipStreamDestroy(s2);
         if (s) hipStreamDestroy(s);
     }
@@ -1035,7 +1036,7 @@ OZ_API int oz_trainer_create(oz_trainer** out, int n, int channels, int in_chann
         OZ_HIP(hipStreamCreateWithFlags(&t->s2, hipStreamNonBlocking));
         for (int l = 0; l < 6; ++l) OZ_HIP(hipEventCreateWithFlags(&t->ev_dz[l], hipEventDisableTiming));
         OZ_HIP(hipEventCreateWithFlags(&t->ev_w, hipEventDisableTiming));
-        for (hipEvent_t* e : {&t->ev_pre, &t->ev_wt, &t->ev_wd}) OZ_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&t->ev_pre, &t->ev_wt, &t->ev_wd, &t->ev_wl[1], &t->ev_wl[2], &t->ev_wl[3]}) OZ_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         for (int l = 0; l < 6; ++l) T_ALLOC(t->bnb2[l], (size_t)OZ_BNB_MAX_RB * t->Co[l]);
         OZ_HIP(hipStreamSynchronize(t->s));
         return OZ_OK;
@@ -1163,8 +1164,10 @@ static int t_refresh(oz_trainer* t) {
         AbsMaxArgs am;
         for (int l = 1; l < 4; ++l) { am.p[l - 1] = t->param(6 * l); am.n[l - 1] = 9LL * C * C; }
         hipLaunchKernelGGL(k_t_absmax, dim3(192, 3), dim3(256), 0, r, am, t->wmax);      // (12 x 16-byte loads per thread cover 9 x 512 x 512 floats in one trip)
-        for (int l = 1; l < 4; ++l)
+        for (int l = 1; l < 4; ++l) {
             hipLaunchKernelGGL(k_t_w_to_h2<0>, dim3(h2_blocks), dim3(256), 0, r, t->param(6 * l), C, C, t->wmax + (l - 1), t->Wh[l], t->wscale[l], t->h2flag);
+            if (t->overlap) { OZ_HIP(hipEventRecord(t->ev_wl[l], r)); t->wait_wl[l] = true; }      // conv2's GEMM waits for ITS operand only (round 5: it waited
+        }                                                                                          // for all five forward operands, 64 us of an idle main stream per step)
         OZ_HIP(hipGetLastError());
     }
     for (int l = t->h2 ? 4 : 1; l < 6; ++l) {      // fp32 forward operands (the dense layers; the 3x3 layers too in f32 mode)
@@ -1237,11 +1240,13 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
       OZ_HIP(hipGetLastError()); }
     if (int rc = t_bn_forward(t, 0, B)) return rc;
     const int Hin[6] = {n, n, n, n - 2, 1, 1}, pad[6] = {1, 1, 0, 0, 0, 0}, Cin[6] = {t->cin, C, C, C, F, 1024}, taps[6] = {9, 9, 9, 9, 1, 1};
-    if (t->wait_wt) { OZ_HIP(hipStreamWaitEvent(s, t->ev_wt, 0)); t->wait_wt = false; }
+    if (t->wait_wt && !t->h2) { OZ_HIP(hipStreamWaitEvent(s, t->ev_wt, 0)); t->wait_wt = false; }
     for (int l = 1; l < 6; ++l) {
+        if (t->wait_wt && l == 4) { OZ_HIP(hipStreamWaitEvent(s, t->ev_wt, 0)); t->wait_wt = false; }      // f16x2: the fp32 operands of the dense layers
         if (t->h2 && l < 4) {      // f16x2: the previous layer's activation in the h2 layout, then the GEMM on the fp16 matrix cores
             const long long thr = (long long)B * t->P_[l - 1] * (C / 8);
             hipLaunchKernelGGL(k_t_act_to_h2, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, s, t->a[l - 1], t->d_count, t->P_[l - 1], C, t->a_h2[l - 1], t->h2flag);
+            if (t->wait_wl[l]) { OZ_HIP(hipStreamWaitEvent(s, t->ev_wl[l], 0)); t->wait_wl[l] = false; }
             if (int rc = oz_gemm_h2_launch(t->a_h2[l - 1], t->Wh[l], t->wscale[l], t->param(6 * l + 1), t->z[l], t->d_count, B, Hin[l], t->Hout[l], pad[l],
                                            Cin[l], 9, t->Co[l], s, t->gpartial, t->gpartial_floats, t->zeros, t->h2flag)) return rc;
         } else
@@ -1510,6 +1515,9 @@ static int t_apply_locked(oz_trainer* t) {
     for (int i = 0; i < 36; ++i)            // the staged moving statistics become the current ones (pointer swap, stream-ordered use)
         if (t->toff[i] < 0) { float* tmp = t->stats[i]; t->stats[i] = t->stats_new[i]; t->stats_new[i] = tmp; }
     t->dirty = true;
+    // the operands derived from the new weights are rebuilt now, on the second stream, behind the optimiser step -- not at the next forward's
+    // first launch: what the host does between two steps (the next batch's upload) no longer delays them
+    if (t->overlap) return t_refresh(t);
     return OZ_OK;
 }
 OZ_API int oz_trainer_apply(oz_trainer* t) {
