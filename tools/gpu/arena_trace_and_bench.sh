@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r24
+O=gpurun_out/arena_bench
 mkdir -p $O
 R=$GRAFT_REPO_ROOT
 cd /tmp
@@ -14,7 +14,7 @@ SECONDS=0; timeout -k 10 1000 python bench.py --gpus 1 --steps 20 --warmup 5 > $
 echo "bench wall: $SECONDS s"
 python - <<'PY'
 import json
-d=json.loads([l for l in open("gpurun_out/r24/bench.out") if l.startswith("{")][0])
+d=json.loads([l for l in open("gpurun_out/arena_bench/bench.out") if l.startswith("{")][0])
 print(json.dumps({k:d[k] for k in ("value","games_per_s","sims_per_s","ms_per_step","value_exact_fp32","games_per_s_exact_fp32","roofline_exact_fp32_frac","parity_max_err_f16x2","parity_max_err_f32","wall_breakdown")}))
 print("roofline", {k:d["roofline"][k] for k in ("achieved","frac","avg_launch_ms","traffic")}, d["device_calibration"]["f16"]["sustained_tflops"], d["device_calibration"]["f32"]["sustained_tflops"], d["device_calibration"]["dominant_kernel_share_of_sustained"])
 print("kernels", [(k["name"], round(k["ms_per_step"],2), round(k["frac"],3)) for k in d["kernels"]])
