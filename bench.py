@@ -19,13 +19,15 @@ process per GPU, RCCL rendezvous on 127.0.0.1) and relays rank 0's JSON line -- 
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks run directly.  A realised world
 size different from --gpus is an error (exit 2), never a silent 1-GPU run.
 
-Prints ONE JSON line on rank 0: value = node expansions per second over all GPUs (the BASELINE metric; the same line
-carries games/s and sims/s), `roofline` for the dominant kernel (HIP events on the launch stream, in the timed region),
-and -- at N = 1 -- `kernels` (every kernel of a step against its own roof), `exact_fp32` (the same workload in exact fp32
-arithmetic), `config4` (6x6 boards), `other_driver` (the lock-step driver), `cross_game_dedup`, `all_layers_as_gemm`, `dropin_config0` (configs[0] through the
-reference's Python surface), `parity_sample_max_err` and `cpu_baseline` (the CPU oracle -- the reference algorithm with
-batch-1 leaf evaluation -- timed on this host's cores on a bounded sample).  In the timed region the network evaluates
-EVERY expansion (cross-game de-duplication off).
+Prints ONE JSON line of <= 6 KB on rank 0 (strict JSON, contract keys first; bench_legs.compact_line): value = node expansions per second
+over all GPUs (the BASELINE metric; the same line carries games/s and sims/s) in the arithmetic `--precision` names -- default f32, exact fp32
+on the fp32 matrix cores, what the reference computes in (Net/NNet.py:85) -- `roofline` for the dominant kernel (HIP events on the launch
+stream, in the timed region; traffic from two rocprofv3 --pmc child passes of this run) and `cpu_baseline` (the CPU oracle -- the reference
+algorithm with batch-1 leaf evaluation -- timed on this host's cores on a bounded sample), then scalars: the same workload in the library's
+other precisions (value_f16x2, roofline_f16x2, ...), whole_path_frac, config4 / config5 / dropin_config0 figures, the parity sample.
+Everything else -- `kernels` (every kernel of a step against its own roof), the nested legs (`precisions`, `config4`, `config5`,
+`other_driver`, `cross_game_dedup`, `eval_cache`, `all_layers_as_gemm`, `dropin_config0`, `parity_sample`), notes, `wall_breakdown` -- is
+written to bench_detail.json next to this file.  In the timed region the network evaluates EVERY expansion (cross-game de-duplication off).
 """
 import argparse
 import json
@@ -39,8 +41,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RC
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from bench_legs import (FLOP_PER_EXPANSION, config5_arena, conv3_tile_rows, conv_flop_per_leaf, cpu_baseline, roofline, run_secondary,  # noqa: E402,F401
-                        tree_side)
+from bench_legs import (DTYPE_DETAIL, DTYPE_LABEL, FLOP_PER_EXPANSION, PRECISIONS, compact_line, config5_arena, conv3_tile_rows,  # noqa: E402,F401
+                        conv_flop_per_leaf, cpu_baseline, roofline, run_secondary, tree_side)
 
 # ---------------------------------------------------------------------------------------------------------------- launcher
 BENCH_TIMEOUT_S = float(os.environ.get("OZ_BENCH_TIMEOUT", "520"))          # below the driver's own 600 s limit: a hang is reported by us, with its phase
@@ -161,8 +163,10 @@ def main():
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--board", type=int, default=8)
     ap.add_argument("--channels", type=int, default=512)
-    ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x2"],
-                    help="conv arithmetic: exact fp32 matrix cores, or f32 via 2 x fp16 split (same 1e-5 parity tolerance)")
+    ap.add_argument("--precision", default="f32", choices=list(PRECISIONS),
+                    help="arithmetic of the timed region (top-level value / dtype / roofline): f32 (default) = exact fp32 matrix cores, what the reference "
+                         "computes in (Net/NNet.py:85); f16x2 = f32 via 2 x fp16 split; every other mode is measured after the timed region and rides beside it "
+                         "(value_<mode>, roofline_<mode>)")
     ap.add_argument("--stagger-sims", type=int, default=-1,
                     help="simulations per move of the untimed stagger phase that spreads the slots over the plies of a game "
                          "(-1 = --sims: the staggered plies are ordinary self-play at full strength; 0 = no stagger: all games start "
@@ -184,6 +188,7 @@ def main():
                          "lockstep: oz_selfplay_run (one simulation per game per step, moves aligned)")
     ap.add_argument("--arena-plies", type=int, default=0, help="config5 leg: 0 (default) = every arena game played to the end (512 games x 800 sims per move "
                                                                "and agent); a positive value bounds the games to that many plies (quick looks)")
+    ap.add_argument("--arena-precision", default="f16x2", choices=list(PRECISIONS), help="config5 leg: arithmetic of the two arena networks (reported as config5_precision)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     ap.add_argument("--no-c-abi-gather", action="store_true", help="N > 1: skip the post-line check of the C ABI's own RCCL exchange step")
@@ -217,6 +222,20 @@ def main():
         sys.stderr.flush()
         os._exit(1)                                            # (a rank blocked in a collective elsewhere is ended by its own watchdog / the launcher)
     _PHASE["done"] = True
+
+
+def write_detail(out):
+    """the full record of the run (everything the stdout line leaves out) as JSON next to bench.py; returns the path written (or None)"""
+    import tempfile
+    for d in (ROOT, tempfile.gettempdir()):
+        path = os.path.join(d, "bench_detail.json")
+        try:
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1)
+            return path
+        except OSError:
+            continue
+    return None
 
 
 def run_rank(args, rank, world, local_rank, t_proc):
@@ -395,6 +414,10 @@ def run_rank(args, rank, world, local_rank, t_proc):
                                                                   if args.driver == "free" else
                                                                   "one move round (100 lock-step simulations + one move per game), ") +
                             f"finished games refilled; leaf evaluator = the reference's OthelloNN ({args.channels} filters), random init seed 0",
+                "workload_short": f"BASELINE configs[1]: {G} concurrent {n}x{n} self-play games per GPU, {args.sims} sims/move, batched leaf eval, OthelloNN "
+                                  f"{args.channels} filters random init; step = " + (f"{args.sims} batches of <= {cap_main or G} leaves (free-running games, records = lock step)"
+                                                                                     if args.driver == "free" else "one lock-step move round"),
+                "precision": args.precision,
                 "games_per_gpu": G, "sims_per_move": args.sims, "board": n,
                 "q_mode": "float64 (NumPy 1.18.5 promotion)", "driver": args.driver, "batch_cap": cap_main or None,
                 "parallelism": f"games sharded x{world}, all-gather of move records",
@@ -432,9 +455,17 @@ def run_rank(args, rank, world, local_rank, t_proc):
             # the tree / rules side is latency-bound integer work, ~1.3 KB of algorithmic HBM bytes per simulation
             "tree_side_hbm": tree_side(sims_all / dt),
         }
-        out["dtype"] = "f32" if args.precision == "f32" else "f32 (2xf16 split)"
-        out["dtype_detail"] = ("fp32 operands and accumulators on v_mfma_f32_32x32x2_f32" if args.precision == "f32" else
-                               "fp32 values carried as two fp16 planes, 3 fp16 MFMA products per fp32 product, fp32 accumulate; pi, v within 1e-5 of float64")
+        out["dtype"] = DTYPE_LABEL[args.precision]
+        out["dtype_detail"] = DTYPE_DETAIL[args.precision]
+        out["roofline"]["leaves_per_launch"] = d["leaves_evaluated"] / max(dom_launches, 1)
+        # SURVEY 8(d)'s whole-path figure: expansions/s x FLOP per expansion / the matrix peak of the arithmetic the timed region ran in.  On the FLOP the GPU
+        # executes it is a fraction of the roof; on the reference network's FLOP it can exceed 1 by construction (conv1 + conv2 are exact table lookups)
+        peak_tf = out["roofline"]["peak"]
+        out["whole_path"] = {"frac_executed_flop": out["value"] / world * flop_exec / (peak_tf * 1e12),
+                             "frac_reference_flop": out["value"] / world * flop_ref / (peak_tf * 1e12), "peak_tflops": peak_tf,
+                             "per_gpu_expansions_per_s": out["value"] / world,
+                             "note": "per GPU; frac_reference_flop counts conv1 + conv2 as GEMM FLOP although they run as exact pattern-table gathers: > 1 by construction "
+                                     "when the tables are on (all_layers_as_gemm is the rate with every layer as a kernel / GEMM)"}
         wall = {"setup_s": round(t_setup, 2), "stagger_s": round(t_stagger, 2), "timed_region_s": round(dt, 2)}      # where this process's wall time goes
         out["wall_breakdown"] = wall
         # what THIS device's matrix pipes sustain right now, measured right after the timed region: a pure-MFMA loop (no LDS, no loads, no barriers) per
@@ -447,26 +478,28 @@ def run_rank(args, rank, world, local_rank, t_proc):
                         "clock_ghz_at_back_to_back_issue": cal["f16"]["clock_ghz"], "ms": cal["f16"]["ms"], "nominal_peak_tflops": 2500.0},
                 "f32": {"instruction": "v_mfma_f32_32x32x2_f32", "sustained_tflops": cal["f32"]["tflops"],
                         "clock_ghz_at_back_to_back_issue": cal["f32"]["clock_ghz"], "ms": cal["f32"]["ms"], "nominal_peak_tflops": 157.3},
-                "dominant_kernel_share_of_sustained": ((3.0 if args.precision == "f16x2" else 1.0) * achieved /
-                                                       max(cal["f16" if args.precision == "f16x2" else "f32"]["tflops"], 1e-9)),
+                "dominant_kernel_share_of_sustained": ({"f32": 1.0, "f16x2": 3.0, "bf16x3": 6.0}[args.precision] * achieved /
+                                                       max(cal["f32" if args.precision == "f32" else "f16"]["tflops"], 1e-9)),
                 "note": "oz_selftest_mfma_rate: one block per CU, one wave per SIMD, four independent accumulators back to back, ~50 ms each, rank 0, right "
                         "after the timed region; roofline.peak stays the nominal figure of MI355X_MICROARCH.md"}
         except Exception as e:                                   # noqa: BLE001 -- a diagnostic, never a reason to lose the line
             out["device_calibration"] = {"error": repr(e)}
         # ---- everything else of the line is measured AFTER the timed region, on fresh engines (bench_legs.py): kernels[] against their own roofs,
         # roofline.traffic from PMC child runs, the parity sample of both precisions, cross_game_dedup / eval_cache / other_driver /
-        # all_layers_as_gemm, exact_fp32 (also as top-level value_exact_fp32 ...), config4 (6x6), config5 (BASELINE configs[4], whole games),
+        # all_layers_as_gemm, precisions (the other arithmetic modes: value_<mode> ...), config4 (6x6), config5 (BASELINE configs[4], whole games),
         # dropin_config0, cpu_baseline
         if world == 1:
             run_secondary(dict(args=args, out=out, wall=wall, world=world, net=net, eng=eng, make_engine=make_engine, measure=measure, advance=advance,
                                layer=layer, n=n, G=G, cap_main=cap_main, d=d, dom_launches=dom_launches, flop_ref=flop_ref, batch_cap=batch_cap))
             del eng
-        # the whole metric once more as the LAST key of the line: a reader (or a log) that keeps only the tail of stdout still sees it
-        out["headline"] = {"node_expansions_per_s": out["value"], "games_per_s": out["games_per_s"], "sims_per_s": out["sims_per_s"],
-                           "ms_per_step": out["ms_per_step"], "n_gpus": world, "roofline_frac": out["roofline"]["frac"],
-                           "roofline_avg_launch_ms": out["roofline"]["avg_launch_ms"], "pooled_records": out["pooled_records"],
-                           "games_completed": out["games_completed"]}
-        print(json.dumps(out), flush=True)
+        # ---- output.  stdout: ONE line of <= 6 KB, contract keys first (bench_legs.compact_line) -- printed LAST, so that it is the tail of this
+        # process's output whatever a reader keeps.  Everything else (kernels[], the nested legs, notes, wall_breakdown) goes to bench_detail.json next
+        # to bench.py (a temporary directory if that is not writable) and, in a few lines, to stderr BEFORE the line.
+        detail_path = write_detail(out)
+        out["detail_file"] = detail_path
+        text = compact_line(out)
+        print(f"bench.py: detail -> {detail_path}; wall {json.dumps(wall)}", file=sys.stderr, flush=True)
+        print(text, flush=True)
     if world > 1 and args.backend == "nccl" and not args.no_c_abi_gather:
         # AFTER the line is out (nothing here can cost the measurement): the same exchange step through the C ABI's own RCCL communicator
         # (oz_comm_* / oz_selfplay_gather_records), checked against the torch.distributed pool; outcome on stderr.  Guarded by a

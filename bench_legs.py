@@ -16,7 +16,15 @@ PEAK_F32_MATRIX_TFLOPS = 157.3                             # MI355X_MICROARCH.md
 PEAK_F16_MATRIX_TFLOPS = 2500.0                            # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16 MFMA
 PEAK_HBM_GBPS = 8000.0                                     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_L2_GBPS = 34500.0                                     # MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s (8 XCDs x 4 MiB)
-TREE_BYTES_PER_SIM = 1300                                  # algorithmic HBM bytes per simulation on the tree side
+TREE_BYTES_PER_SIM = 1300
+PRECISIONS = ("f32", "f16x2")                              # oz_net_set_precision modes bench.py measures (bf16x3 is appended below once the library offers it)
+DTYPE_LABEL = {"f32": "f32", "f16x2": "f32 (2xf16 split)", "bf16x3": "f32 (3xbf16 split)"}
+DTYPE_DETAIL = {
+    "f32": "fp32 operands and accumulators on v_mfma_f32_32x32x2_f32 (conv1 + conv2 from exact-fp32 pattern tables): the reference's arithmetic (Net/NNet.py:85)",
+    "f16x2": "fp32 values carried as two fp16 planes (22 of 24 significand bits, placed per channel at commit), 3 fp16 MFMA products per fp32 product, fp32 "
+             "accumulate; pi, v within 1e-5 of float64 -- fp32-equivalent for this network, narrower than fp32",
+    "bf16x3": "fp32 values carried as three bf16 planes (8 + 8 + 8 significand bits: every normal fp32 value exactly, fp32's exponent range, no scaling), 6 bf16 MFMA "
+              "products per fp32 product (a2b3, a3b2, a3b3 <= 2^-24 relative dropped), fp32 accumulate"}                                  # algorithmic HBM bytes per simulation on the tree side
 
 
 def conv_flop_per_leaf(layer, n, C):
@@ -599,6 +607,93 @@ def config5_arena(channels, precision, plies=0, games=512, sims=800, sample=2, d
 
 
 
+def _sig(x, digits=6):
+    """a float with `digits` significant digits (the secondary scalars of the stdout line; the contract fields keep every digit)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def compact_line(out, limit=6000):
+    """THE stdout line: strict JSON, contract keys first, <= `limit` bytes whatever the rank count -- everything else of `out` lives in
+    bench_detail.json (written next to bench.py) and is never needed to read the metric.  VERDICT r5 item 1: the 33 KB line of round 5 did
+    not fit the driver's 8 KB tail and was recorded as unparsed."""
+    r = out["roofline"]
+    cfg = out["config"]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": cfg["workload_short"], "games_per_gpu": cfg["games_per_gpu"], "sims_per_move": cfg["sims_per_move"], "board": cfg["board"],
+                      "driver": cfg["driver"], "batch_cap": cfg["batch_cap"], "parallelism": cfg["parallelism"], "backend": cfg["backend"],
+                      "leaf_dedup": cfg["leaf_dedup"].split(":")[0], "precision": cfg["precision"]}
+    line["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "kernel",
+                                              "algorithmic_bytes_per_launch", "flop_per_leaf", "leaves_per_launch")}
+    line["roofline"]["kernel"] = r.get("kernel_short") or r.get("kernel")
+    if "matrix_pipe_frac" in r:
+        line["roofline"]["mfma_products_per_fp32_product"] = r["mfma_products_per_fp32_product"]
+        line["roofline"]["matrix_pipe_frac"] = _sig(r["matrix_pipe_frac"])
+    if isinstance(r.get("traffic_source"), str):
+        line["roofline"]["traffic_measured_in_this_run"] = r["traffic_source"].startswith("measured in this run")
+    c = out.get("cpu_baseline")
+    if c:
+        rp = c.get("reference_python") or {}
+        line["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "cpu_model": c.get("cpu_model"), "kind": c["kind"],
+                                "sample": c["sample"][:220],
+                                "one_game_per_thread": _sig((c.get("one_game_per_thread") or {}).get("value")), "one_thread": _sig(c.get("value_1_thread")),
+                                "reference_python": {"value": rp.get("value"), "cores": rp.get("cores"), "kind": rp.get("kind"),
+                                                     "where": "build container (the reference never travels)"} if "value" in rp else None}
+    for k in ("games_per_s", "sims_per_s", "games_completed", "expansions", "simulations", "pooled_records", "gather_ms"):
+        line[k] = _sig(out[k]) if isinstance(out.get(k), float) else out.get(k)
+    line["per_rank_records"] = out["per_rank_records"]
+    line["per_rank_ms_per_step"] = [_sig(x, 5) for x in out["per_rank"]["ms_per_step"]]
+    line["leaves_evaluated_rank0"] = out["leaves_evaluated_rank0"]
+    fe = out["flop_per_expansion"]
+    line["flop_per_expansion"] = {"reference_network": fe["reference_network"], "executed": fe["executed"]}
+    line["whole_path_frac"] = _sig(out["whole_path"]["frac_executed_flop"])
+    line["whole_path_frac_reference_flop"] = _sig(out["whole_path"]["frac_reference_flop"])
+    line["whole_path_note"] = "value x FLOP / roofline.peak; reference-FLOP figure may exceed 1 by construction (conv1 + conv2 are exact table lookups, no FLOP executed)"
+    # the other precisions of the same workload, same run (value_<mode>, roofline_<mode>{frac, avg_launch_ms, peak, achieved}, dtype_<mode>)
+    for p in PRECISIONS:
+        if ("value_" + p) in out:
+            line["value_" + p] = _sig(out["value_" + p])
+            line["games_per_s_" + p] = _sig(out["games_per_s_" + p])
+            line["roofline_" + p] = {k: _sig(v) for k, v in out["roofline_" + p].items()}
+            line["dtype_" + p] = out["dtype_" + p]
+        if ("parity_max_err_" + p) in out:
+            line["parity_max_err_" + p] = _sig(out["parity_max_err_" + p], 3)
+    if "parity_sample_max_err" in out:
+        line["parity_sample_max_err"] = _sig(out["parity_sample_max_err"], 3)
+        line["parity_tolerance"] = 1e-5
+    cal = out.get("device_calibration") or {}
+    if "f16" in cal:
+        line["device_calibration"] = {"f16_sustained_tflops": _sig(cal["f16"]["sustained_tflops"], 4), "f32_sustained_tflops": _sig(cal["f32"]["sustained_tflops"], 4),
+                                      "dominant_kernel_share_of_sustained": _sig(cal["dominant_kernel_share_of_sustained"], 4)}
+    if "config4" in out:
+        line["config4_value"] = _sig(out["config4"]["value"])
+        line["config4_games_per_s"] = _sig(out["config4"]["games_per_s"])
+        line["config4_roofline_frac"] = _sig(out["config4"]["roofline"]["frac"])
+    if "config5" in out:
+        c5 = out["config5"]
+        line["config5_games_per_s"] = _sig(c5.get("games_per_s"))
+        line["config5_sample_mismatches"] = c5.get("sample_mismatches")
+        line["config5_precision"] = c5.get("precision")
+        line["config5_us_per_sim_step"] = _sig(c5.get("us_per_sim_step"), 4)
+    if "dropin_config0" in out:
+        line["dropin_config0_s"] = _sig(out["dropin_config0"]["gpu_dropin"]["seconds"], 4)
+    for k, short in (("cross_game_dedup", "value_with_cross_game_dedup"), ("eval_cache", "value_with_eval_cache"), ("other_driver", "value_other_driver"),
+                     ("all_layers_as_gemm", "value_all_layers_as_gemm")):
+        if k in out:
+            line[short] = _sig(out[k]["value"])
+    line["tree_side_hbm_frac"] = _sig(out["tree_side_hbm"]["frac"], 3)
+    line["detail"] = out.get("detail_file")
+    text = json.dumps(line, allow_nan=False)
+    if len(text) > limit:                                        # cannot happen at N <= 8; never print a line the driver cannot keep whole
+        for k in ("whole_path_note", "per_rank_ms_per_step", "flop_per_expansion", "device_calibration"):
+            line.pop(k, None)
+        line["cpu_baseline"] = {k: v for k, v in (line.get("cpu_baseline") or {}).items() if k != "sample"} or None
+        text = json.dumps(line, allow_nan=False)
+    return text
+
+
 def run_secondary(ctx):
     """the secondary legs of the N = 1 line, after the timed region.  ctx: the timed region's objects (bench.py run_rank): args, out, wall, world,
     net, eng, make_engine, measure, advance, layer, n, G, cap_main, d (the timed region's counter deltas), dom_launches, flop_ref."""
@@ -712,44 +807,51 @@ def run_secondary(ctx):
                     "(pi, v) agree with the table form to 5e-7"}
         del eng3
         wall["gemm_compare_s"] = round(time.perf_counter() - t_sec, 2)
-    if secondary and args.precision == "f16x2":
-        # ---- exact fp32 arithmetic (what the reference computes in: Net/NNet.py:85), same workload, same run, same number of steps.  This is the
-        # like-for-like number under a strict reading of "fp32": its headline values are top-level keys of the line (value_exact_fp32, ...)
-        t_sec = time.perf_counter()
-        steps32 = args.steps
-        net32 = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0, precision="f32")
-        e32 = make_engine(args.dedup == "on", the_net=net32)
-        e32.stagger(cheap_pre)
-        q32, dt32 = measure(e32, steps32, net32)
-        ms32, l32 = net32.profile_read()
-        layer32 = net32.profiled_layer()
-        ach32 = q32["leaves_evaluated"] * conv_flop_per_leaf(layer32, n, args.channels) / max(ms32 * 1e-3, 1e-9) / 1e12
-        out["exact_fp32"] = {
-            "value": q32["expansions"] / dt32, "unit": "node-expansions/s", "ms_per_step": dt32 / steps32 * 1e3, "steps": steps32,
-            "games_per_s": q32["games_completed"] / dt32, "sims_per_s": q32["simulations"] / dt32, "dtype": "f32",
-            "dtype_detail": "fp32 operands and accumulators on v_mfma_f32_32x32x2_f32 (conv1 + conv2 from exact-fp32 pattern tables)",
-            "roofline": roofline("f32", layer32, ach32, ms32, l32, q32["leaves_evaluated"], n, args.channels),
-            "note": f"same workload and run as the headline (slots staggered at {cheap_pre} sims/move), precision='f32'"}
-        if psample is not None:
-            p32 = parity_rows(net32, psample)
-            out["exact_fp32"]["parity_sample"] = p32
-            out["parity_max_err_f32"] = max(p32["max_abs_err_pi"], p32["max_abs_err_v"])
-            out["parity_sample"]["same_rows_in_precision_f32"] = p32
-        del e32, net32
-        if not args.no_live_traffic:
-            byts, how = live_traffic(args, layer32, cap_main or G, precision="f32")
-            if byts is not None:
-                r32 = out["exact_fp32"]["roofline"]
-                r32["traffic_from_committed_profile"] = r32["traffic"]
-                r32["traffic"] = byts * (q32["leaves_evaluated"] / max(l32, 1)) / float(cap_main or G)
-                r32["traffic_source"] = how
-            else:
-                out["exact_fp32"]["roofline"]["live_traffic_error"] = how
-        out["value_exact_fp32"] = out["exact_fp32"]["value"]
-        out["games_per_s_exact_fp32"] = out["exact_fp32"]["games_per_s"]
-        out["ms_per_step_exact_fp32"] = out["exact_fp32"]["ms_per_step"]
-        out["roofline_exact_fp32_frac"] = out["exact_fp32"]["roofline"]["frac"]
-        wall["exact_fp32_s"] = round(time.perf_counter() - t_sec, 2)
+    if secondary:
+        # ---- the same workload, same run, same number of steps, in the library's OTHER precisions.  The line's top-level value is measured in
+        # args.precision (default f32: what the reference computes in, Net/NNet.py:85); every other mode rides beside it (value_<mode>, roofline_<mode>)
+        out["precisions"] = {}
+        for prec in [p for p in PRECISIONS if p != args.precision]:
+            t_sec = time.perf_counter()
+            try:
+                netp = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0, precision=prec)
+            except Exception as e:                                   # noqa: BLE001 -- a secondary leg never costs the line
+                out["precisions"][prec] = {"error": repr(e)}
+                continue
+            ep = make_engine(args.dedup == "on", the_net=netp)
+            ep.stagger(cheap_pre)
+            qp, dtp = measure(ep, args.steps, netp)
+            msp, lp = netp.profile_read()
+            layerp = netp.profiled_layer()
+            achp = qp["leaves_evaluated"] * conv_flop_per_leaf(layerp, n, args.channels) / max(msp * 1e-3, 1e-9) / 1e12
+            leg = {"value": qp["expansions"] / dtp, "unit": "node-expansions/s", "ms_per_step": dtp / args.steps * 1e3, "steps": args.steps,
+                   "games_per_s": qp["games_completed"] / dtp, "sims_per_s": qp["simulations"] / dtp, "dtype": DTYPE_LABEL[prec],
+                   "dtype_detail": DTYPE_DETAIL[prec],
+                   "roofline": roofline(prec, layerp, achp, msp, lp, qp["leaves_evaluated"], n, args.channels,
+                                        conv3_rows=netp.conv3_tile_rows() if prec != "f32" else 256),
+                   "note": f"same workload and run as the headline (slots staggered at {cheap_pre} sims/move), precision='{prec}'"}
+            if psample is not None:
+                pp_ = parity_rows(netp, psample)
+                leg["parity_sample"] = pp_
+                out["parity_max_err_" + prec] = max(pp_["max_abs_err_pi"], pp_["max_abs_err_v"])
+            del ep, netp
+            if not args.no_live_traffic and prec != "f16x2":            # (two more PMC child runs per mode: the exact-fp32 and bf16x3 legs get them)
+                byts, how = live_traffic(args, layerp, cap_main or G, precision=prec)
+                rp = leg["roofline"]
+                if byts is not None:
+                    rp["traffic_from_committed_profile"] = rp["traffic"]
+                    rp["traffic"] = byts * (qp["leaves_evaluated"] / max(lp, 1)) / float(cap_main or G)
+                    rp["traffic_source"] = how
+                else:
+                    rp["live_traffic_error"] = how
+            out["precisions"][prec] = leg
+            out["value_" + prec] = leg["value"]
+            out["games_per_s_" + prec] = leg["games_per_s"]
+            out["ms_per_step_" + prec] = leg["ms_per_step"]
+            out["roofline_" + prec] = {"frac": leg["roofline"]["frac"], "avg_launch_ms": leg["roofline"]["avg_launch_ms"], "peak": leg["roofline"]["peak"],
+                                       "achieved": leg["roofline"]["achieved"]}
+            out["dtype_" + prec] = leg["dtype"]
+            wall[prec + "_s"] = round(time.perf_counter() - t_sec, 2)
     if secondary and n == 8:
         # ---- BASELINE configs[3]: 6x6 boards, same network family, same engine -- with its own roofline (dominant launch: conv3 of the 6x6
         # network on the 256-row tile), kernels[], parity sample (both precisions, same rows) and exact-fp32 rate
@@ -784,28 +886,33 @@ def run_secondary(ctx):
             rep6, ps6 = parity_sample(net6, e6, 6, args.channels, G, check=256)
             out["config4"]["parity_sample"] = rep6
         del e6, net6
-        if args.precision == "f16x2":
-            n32 = NNetWrapper((6, 6), num_channels_1=args.channels, max_batch=G, seed=0, precision="f32")
-            e632 = make_engine(args.dedup == "on", the_net=n32, board=6)
-            e632.stagger(cheap_pre)
-            steps632 = max(args.steps // 2, 1)
-            q632, dt632 = measure(e632, steps632, n32)
-            ms632, l632 = n32.profile_read()
-            lay632 = n32.profiled_layer()
-            a632 = q632["leaves_evaluated"] * conv_flop_per_leaf(lay632, 6, args.channels) / max(ms632 * 1e-3, 1e-9) / 1e12
-            r632 = roofline("f32", lay632, a632, ms632, l632, q632["leaves_evaluated"], 6, args.channels)
-            r632["traffic"], r632["traffic_source"] = None, "not measured for the 6x6 network"
-            out["config4"]["exact_fp32"] = {"value": q632["expansions"] / dt632, "unit": "node-expansions/s", "ms_per_step": dt632 / steps632 * 1e3,
-                                            "steps": steps632, "games_per_s": q632["games_completed"] / dt632, "dtype": "f32", "roofline": r632,
-                                            "conv3_tile_rows": n32.conv3_tile_rows()}
+        out["config4"]["precisions"] = {}
+        for prec in [p for p in PRECISIONS if p != args.precision]:
+            try:
+                np_ = NNetWrapper((6, 6), num_channels_1=args.channels, max_batch=G, seed=0, precision=prec)
+            except Exception as e:                                   # noqa: BLE001
+                out["config4"]["precisions"][prec] = {"error": repr(e)}
+                continue
+            e6p = make_engine(args.dedup == "on", the_net=np_, board=6)
+            e6p.stagger(cheap_pre)
+            steps6p = max(args.steps // 2, 1)
+            q6p, dt6p = measure(e6p, steps6p, np_)
+            ms6p, l6p = np_.profile_read()
+            lay6p = np_.profiled_layer()
+            a6p = q6p["leaves_evaluated"] * conv_flop_per_leaf(lay6p, 6, args.channels) / max(ms6p * 1e-3, 1e-9) / 1e12
+            r6p = roofline(prec, lay6p, a6p, ms6p, l6p, q6p["leaves_evaluated"], 6, args.channels, conv3_rows=np_.conv3_tile_rows() if prec != "f32" else 256)
+            r6p["traffic"], r6p["traffic_source"] = None, "not measured for the 6x6 network"
+            out["config4"]["precisions"][prec] = {"value": q6p["expansions"] / dt6p, "unit": "node-expansions/s", "ms_per_step": dt6p / steps6p * 1e3,
+                                                  "steps": steps6p, "games_per_s": q6p["games_completed"] / dt6p, "dtype": DTYPE_LABEL[prec], "roofline": r6p,
+                                                  "conv3_tile_rows": np_.conv3_tile_rows()}
             if ps6 is not None:
-                out["config4"]["exact_fp32"]["parity_sample"] = parity_rows(n32, ps6)
-            del e632, n32
+                out["config4"]["precisions"][prec]["parity_sample"] = parity_rows(np_, ps6)
+            del e6p, np_
         wall["config4_s"] = round(time.perf_counter() - t_sec, 2)
     if secondary and n == 8 and not args.no_cpu_baseline:
         # ---- BASELINE configs[4]: arena evaluation with two real networks (bounded plies), sampled games replayed by the oracle
         t_sec = time.perf_counter()
-        out["config5"] = config5_arena(args.channels, args.precision, args.arena_plies)
+        out["config5"] = config5_arena(args.channels, args.arena_precision, args.arena_plies)
         if "games_per_s" in out["config5"]:
             out["config5_games_per_s"] = out["config5"]["games_per_s"]
             out["config5_sample_mismatches"] = out["config5"]["sample_mismatches"]

@@ -33,6 +33,9 @@ class _NetHandle:
             pass
 
 
+PRECISION_MODES = {"f32": 0, "f16x2": 1, "bf16x3": 2}      # oz_net_set_precision
+
+
 class NNetWrapper(_NetHandle):
     _models_built = 0          # Keras numbers layer names per process (conv2d, ..., conv2d_4, ...); checkpoints keep that
 
@@ -60,7 +63,9 @@ class NNetWrapper(_NetHandle):
         #  fp16 window by an exact power of two at commit, a commit-time self-check against the exact-fp32 kernels refuses networks that amplify
         #  rounding, and a position whose activations leave the calibrated range raises OzError(OZ_ERR_STATE) instead of returning a degraded answer)
         self.precision = precision
-        _lib.check(lib.oz_net_set_precision(self._h, {"f32": 0, "f16x2": 1}[precision]))
+        self.requested_precision = precision          # what the caller asked for: a refused f16x2 commit falls back for THAT set of weights only
+        self.f16x2_refusals = 0                       # commits precision f16x2 refused so far (train() reports it in its history)
+        _lib.check(lib.oz_net_set_precision(self._h, PRECISION_MODES[precision]))
         self.set_weights(weights if weights is not None else
                          init_weights(self.board_size_x, seed, self.num_channels, in_channels=self.in_channels))
 
@@ -72,6 +77,9 @@ class NNetWrapper(_NetHandle):
         precision f32 (exact fp32 kernels on the GPU, always valid) and commits again -- what train() uses, so that a long f16x2 run is not
         ended by the weights of one iteration."""
         lib = _lib.load()
+        if self.precision != self.requested_precision:        # an earlier set of weights was refused: THIS one gets the requested arithmetic again
+            _lib.check(lib.oz_net_set_precision(self._h, PRECISION_MODES[self.requested_precision]))
+            self.precision = self.requested_precision
         shapes = onn_shapes(self.board_size_x, self.num_channels, self.in_channels)
         assert len(weights) == len(shapes), f"expected {len(shapes)} arrays"
         for i, (w, shp) in enumerate(zip(weights, shapes)):
@@ -84,7 +92,9 @@ class NNetWrapper(_NetHandle):
             if not (on_refusal == "f32" and e.code == _lib.OZ_ERR_STATE and self.precision == "f16x2"):
                 raise
             import warnings
-            warnings.warn(f"othellozero_amd: precision f16x2 refused these weights at commit ({e}); this network continues in precision f32")
+            self.f16x2_refusals += 1
+            warnings.warn(f"othellozero_amd: precision f16x2 refused these weights at commit ({e}); THESE weights run in precision f32 "
+                          f"(refusal {self.f16x2_refusals}; the next set_weights tries f16x2 again)")
             _lib.check(lib.oz_net_set_precision(self._h, 0))
             self.precision = "f32"
             _lib.check(lib.oz_net_commit(self._h))
@@ -160,6 +170,18 @@ class NNetWrapper(_NetHandle):
             from .distributed import average_moving_statistics
             weights = average_moving_statistics(weights, getattr(allreduce, "group", None))
         self.set_weights(weights, on_refusal="f32")
+        if allreduce is not None:
+            # the replicas hold the same weights, so a refusal is the same decision everywhere; should one rank's commit still be refused alone
+            # (another calibration outcome on its device, say), EVERY rank evaluates these weights in precision f32 -- no rank decides by itself
+            from .distributed import any_rank
+            refused = self.precision != self.requested_precision
+            if any_rank(refused, getattr(allreduce, "group", None)) and not refused:
+                lib = _lib.load()
+                _lib.check(lib.oz_net_set_precision(self._h, PRECISION_MODES["f32"]))
+                self.precision = "f32"
+                _lib.check(lib.oz_net_commit(self._h))
+        hist.history["precision"] = self.precision          # the arithmetic these weights are evaluated in until the next set_weights
+        hist.history["f16x2_refusals"] = self.f16x2_refusals
         return hist
 
     # ---- checkpoints (Net/NNet.py:90-96): Keras HDF5 weight files, read and written by keras_h5.py (no h5py needed);

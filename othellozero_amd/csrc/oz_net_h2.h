@@ -955,6 +955,11 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        // every wave's prologue reads of B n0 (stage 0) are complete before ANY wave issues phase 1's Be(kbeg + 2) into that region: without this
+        // barrier wave row 0 would go straight into phase 1 while wave row 1 -- whose stagger barrier below pairs with row 0's l_end, AFTER row 0's
+        // DMA issue -- could still be reading those rows (a narrow window, one k-slice of >= 3 tiles; the loop's own rule, restored)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         if (wm == 1) __builtin_amdgcn_s_barrier();           // stagger: wave row 1 is one barrier behind
         for (int kt = kbeg; kt < nk; ++kt) {
             const int buf = (kt - kbeg) & 1;

@@ -1425,7 +1425,10 @@ OZ_API int oz_trainer_forward_backward(oz_trainer* t, const uint64_t* own, const
         memcpy(h + ((unsigned char*)t->d_count - t->d_in), &B, sizeof(int));
         OZ_HIP(hipMemcpyAsync(t->d_in, h, t->in_bytes, hipMemcpyHostToDevice, s));
     }
-    if (int rc = t_forward_backward_async(t, B)) return rc;
+    if (int rc = t_forward_backward_async(t, B)) {
+        hipStreamSynchronize(s);                   // the upload out of h_in may still be in flight: a retrying caller's next memcpy into it must not race with that DMA
+        return rc;
+    }
     float h[4];
     OZ_HIP(hipMemcpyAsync(h, t->losses, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     OZ_HIP(hipStreamSynchronize(s));

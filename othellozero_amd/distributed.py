@@ -266,3 +266,14 @@ def average_moving_statistics(weights, group=None):
         out[i] = flat[pos:pos + n].reshape(np.asarray(weights[i]).shape).copy()
         pos += n
     return out
+
+
+def any_rank(flag, group=None):
+    """True on every rank when `flag` is true on at least one (a MAX all-reduce of one integer; `flag` itself without a process group)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    if dist.get_backend(group) != "gloo":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t.item()))

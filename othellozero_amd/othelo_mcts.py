@@ -139,7 +139,9 @@ class OthelloMCTS:
     # ---- the game hooks MCTS/__init__.py:86-166 declares abstract and othelo_mcts.py:28-49,69-88 fills in.  The search never calls
     # them here (the kernels carry the rules); callers that use them directly get the LIBRARY's rules kernels through the C ABI
     # (oz_rules_status / oz_rules_apply_moves / oz_rules_legal_moves on the packed board), i.e. the same bit-parallel code the search runs.
+    # (no CPU fallback by design: without a GPU / the built library they raise OzLibraryError through require_gpu, like every compute call)
     def _rules_status(self, state):
+        _lib.require_gpu()
         c0, c1 = (np.array([x], np.uint64) for x in _lib.pack_board(state))
         fin, p0, p1, win = np.zeros(1, np.uint8), np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.int8)
         _lib.check(_lib.load().oz_rules_status(_lib.p_u64(c0), _lib.p_u64(c1), self._board_size, 1, _lib.p_u8(fin), _lib.p_i32(p0),
@@ -147,6 +149,7 @@ class OthelloMCTS:
         return bool(fin[0]), int(win[0])
 
     def _legal_mask(self, own, opp):
+        _lib.require_gpu()
         legal = np.zeros(1, np.uint64)
         _lib.check(_lib.load().oz_rules_legal_moves(_lib.p_u64(np.array([own], np.uint64)), _lib.p_u64(np.array([opp], np.uint64)),
                                                     self._board_size, 1, _lib.p_u64(legal)))
@@ -167,7 +170,8 @@ class OthelloMCTS:
         own, opp = int(o2[0]), int(p2[0])
         if self._legal_mask(opp, own):                         # the opponent can answer: it becomes the mover (channel 0); a pass keeps the orientation
             own, opp = opp, own
-        return _lib.unpack_board(own, opp, self._board_size)
+        nxt = _lib.unpack_board(own, opp, self._board_size)
+        return nxt.astype(state.dtype) if isinstance(state, np.ndarray) and nxt.dtype != state.dtype else nxt      # the reference returns the input's dtype (np.copy + in-place flips)
 
     def _neural_network_predict(self, state):
         """one evaluation per distinct board of this search (the reference's per-instance dict, keyed by the exact board)"""

@@ -1,8 +1,12 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# Run ON THE GPU BOX through gpurun (GRAFT_REPO_ROOT is set there): a missing variable or a failed step ends the script.
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}"
+cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 O=gpurun_out/arena_bench
 mkdir -p $O
-R=$GRAFT_REPO_ROOT
+R="$GRAFT_REPO_ROOT"
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/arena_trace -o arena -- python3 $R/tools/arena_real_bench.py --plies 2 > $R/$O/arena_trace.log 2>&1 || { tail -20 $R/$O/arena_trace.log; exit 1; }
 cd $R
