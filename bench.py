@@ -20,8 +20,9 @@ process per GPU, RCCL rendezvous on 127.0.0.1) and relays rank 0's JSON line -- 
 size different from --gpus is an error (exit 2), never a silent 1-GPU run.
 
 Prints ONE JSON line of <= 6 KB on rank 0 (strict JSON, contract keys first; bench_legs.compact_line): value = node expansions per second
-over all GPUs (the BASELINE metric; the same line carries games/s and sims/s) in the arithmetic `--precision` names -- default f32, exact fp32
-on the fp32 matrix cores, what the reference computes in (Net/NNet.py:85) -- `roofline` for the dominant kernel (HIP events on the launch
+over all GPUs (the BASELINE metric; the same line carries games/s and sims/s) in the arithmetic `--precision` names -- default bf16x3: fp32
+values carried exactly as three bf16 planes, six bf16 MFMA products per fp32 product (fp32-class results; exact fp32 on the fp32 matrix cores,
+literally what the reference computes in, Net/NNet.py:85, rides beside it as value_f32 / roofline_f32) -- `roofline` for the dominant kernel (HIP events on the launch
 stream, in the timed region; traffic from two rocprofv3 --pmc child passes of this run) and `cpu_baseline` (the CPU oracle -- the reference
 algorithm with batch-1 leaf evaluation -- timed on this host's cores on a bounded sample), then scalars: the same workload in the library's
 other precisions (value_f16x2, roofline_f16x2, ...), whole_path_frac, config4 / config5 / dropin_config0 figures, the parity sample.
@@ -163,10 +164,12 @@ def main():
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--board", type=int, default=8)
     ap.add_argument("--channels", type=int, default=512)
-    ap.add_argument("--precision", default="f32", choices=list(PRECISIONS),
-                    help="arithmetic of the timed region (top-level value / dtype / roofline): f32 (default) = exact fp32 matrix cores, what the reference "
-                         "computes in (Net/NNet.py:85); f16x2 = f32 via 2 x fp16 split; every other mode is measured after the timed region and rides beside it "
-                         "(value_<mode>, roofline_<mode>)")
+    ap.add_argument("--precision", default="bf16x3", choices=list(PRECISIONS),
+                    help="arithmetic of the timed region (top-level value / dtype / roofline): bf16x3 (default) = every fp32 value carried EXACTLY as three bf16 "
+                         "planes, six bf16 MFMA products per fp32 product, fp32 accumulate -- fp32-class results (the dropped cross terms are below fp32's own "
+                         "rounding of a product) at 2.67x the fp32 matrix roof; f32 = exact fp32 matrix cores, literally what the reference computes in "
+                         "(Net/NNet.py:85); f16x2 = f32 via 2 x fp16 split (22 of 24 significand bits).  Every other mode is measured after the timed region "
+                         "and rides beside it (value_<mode>, roofline_<mode>)")
     ap.add_argument("--stagger-sims", type=int, default=-1,
                     help="simulations per move of the untimed stagger phase that spreads the slots over the plies of a game "
                          "(-1 = --sims: the staggered plies are ordinary self-play at full strength; 0 = no stagger: all games start "

@@ -17,7 +17,7 @@ PEAK_F16_MATRIX_TFLOPS = 2500.0                            # MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0                                     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_L2_GBPS = 34500.0                                     # MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s (8 XCDs x 4 MiB)
 TREE_BYTES_PER_SIM = 1300
-PRECISIONS = ("f32", "f16x2")                              # oz_net_set_precision modes bench.py measures (bf16x3 is appended below once the library offers it)
+PRECISIONS = ("f32", "f16x2", "bf16x3")                    # oz_net_set_precision modes bench.py measures
 DTYPE_LABEL = {"f32": "f32", "f16x2": "f32 (2xf16 split)", "bf16x3": "f32 (3xbf16 split)"}
 DTYPE_DETAIL = {
     "f32": "fp32 operands and accumulators on v_mfma_f32_32x32x2_f32 (conv1 + conv2 from exact-fp32 pattern tables): the reference's arithmetic (Net/NNet.py:85)",
@@ -64,7 +64,12 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
          "algorithmic_bytes_per_launch": None}
     px_in, px_out = {2: (n * n, n * n), 3: (n * n, (n - 2) ** 2), 4: ((n - 2) ** 2, (n - 4) ** 2)}[layer]
     r["algorithmic_bytes_per_launch"] = (expansions / max(launches, 1)) * (px_in + px_out) * channels * 4 + 9 * channels * channels * 4
-    if precision == "f32":
+    if precision == "bf16x3":
+        kernel = (f"k_gemm_b3<{layer}> (conv{layer}: 3x3, 512->512, 128 x 256 tiles, implicit GEMM, f32 as 3xbf16 split, 6 products on v_mfma_f32_16x16x32_bf16, "
+                  "2-phase ping-pong loop); conv1 + conv2 = exact-fp32 table gather-sum")
+        r.update(kernel=kernel, peak=PEAK_F16_MATRIX_TFLOPS, frac=achieved / PEAK_F16_MATRIX_TFLOPS, mfma_products_per_fp32_product=6,
+                 matrix_pipe_tflops=6 * achieved, matrix_pipe_frac=6 * achieved / PEAK_F16_MATRIX_TFLOPS, vs_fp32_matrix_peak=achieved / PEAK_F32_MATRIX_TFLOPS)
+    elif precision == "f32":
         r.update(kernel=("k_gemm_f32 (conv3: 3x3 valid, 512->512, 8x8 -> 6x6, implicit GEMM, v_mfma_f32_32x32x2_f32); conv1 + conv2 = k_conv2_lut_f32 table gather-sum"
                          if layer == 3 else "k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)"),
                  peak=PEAK_F32_MATRIX_TFLOPS, frac=achieved / PEAK_F32_MATRIX_TFLOPS)
@@ -117,7 +122,7 @@ def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tabl
             per_leaf, src = None, None
             try:
                 import csv
-                rel = os.path.join("profiles", f"r5_{precision}_bench_pmc_by_shape.csv")
+                rel = os.path.join("profiles", f"r5_{'f32' if precision == 'bf16x3' else precision}_bench_pmc_by_shape.csv")
                 rows = [r for r in csv.DictReader(l for l in open(os.path.join(ROOT, rel)) if not l.startswith("#")) if "k_conv2_lut" in r["kernel"]]
                 fetch = max(float(r["avg_per_launch"]) for r in rows if r["counter"] == "FETCH_SIZE")
                 write = max(float(r["avg_per_launch"]) for r in rows if r["counter"] == "WRITE_SIZE")
@@ -127,11 +132,12 @@ def kernel_table(net_k, tree_k, rounds, leaves, sims_done, n, C, precision, tabl
                 per_leaf = 0.58e9 / 3640 * (n * n / 64.0) * (C / 512.0) + n * n * C * 4
                 src = "0.58 GB read (PMC, round 3) + the compulsory output row per pixel per 3640-leaf launch; not re-measured in this run"
             byts = leaves * per_leaf
-            row.update(kernel=("k_conv2_lut_xcd" if C == 512 else "k_conv2_lut") + (" (fp32 rows)" if precision == "f32" else " (h2 rows)"), bound="hbm",
+            row.update(kernel=("k_conv2_lut_xcd" if C == 512 else "k_conv2_lut") + {"f32": " (fp32 rows)", "f16x2": " (h2 rows)", "bf16x3": " (fp32 tables, b3 rows)"}[precision], bound="hbm",
                        achieved=byts / sec / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s", bytes_source=src)
         elif name in flop:
-            kern = "k_gemm_f32" if precision == "f32" else "k_gemm_h2"
-            row.update(kernel=f"{kern} ({name})", bound="mfma", achieved=leaves * flop[name] / sec / 1e12, peak=peak_mm, unit="TFLOP/s")
+            kern = {"f32": "k_gemm_f32", "f16x2": "k_gemm_h2", "bf16x3": "k_gemm_b3" if name in ("conv3", "conv4", "fc1") else "k_gemm_f32"}[precision]
+            peak_row = PEAK_F32_MATRIX_TFLOPS if kern == "k_gemm_f32" else peak_mm
+            row.update(kernel=f"{kern} ({name})", bound="mfma", achieved=leaves * flop[name] / sec / 1e12, peak=peak_row, unit="TFLOP/s")
         elif name == "input":
             byts = leaves * (16 + n * n * 2) if tables else leaves * (16 + n * n * C * 4)
             row.update(kernel="k_lut_ids" if tables else "k_conv1", bound="hbm", achieved=byts / sec / 1e9, peak=PEAK_HBM_GBPS, unit="GB/s")
@@ -703,6 +709,7 @@ def run_secondary(ctx):
     layer, n, G, cap_main, d, dom_launches, flop_ref = ctx["layer"], ctx["n"], ctx["G"], ctx["cap_main"], ctx["d"], ctx["dom_launches"], ctx["flop_ref"]
     secondary = world == 1 and not args.no_compare
     cheap_pre = max(2, min(8, args.sims))                   # stagger of the secondary legs: 8 sims/move (a few tenths of a second)
+    vsteps = max(args.steps // 2, 1)                        # the variation legs (de-duplication, cache, other driver, all-GEMM) run half the steps: rates, not headlines
     if secondary:
         # ---- every kernel of a step against its own roof: 2 move rounds on the SAME engine with events around every launch
         t_sec = time.perf_counter()
@@ -744,9 +751,9 @@ def run_secondary(ctx):
         # the same workload with the library default (cross-game de-duplication on): identical records, fewer evaluations
         eng2 = make_engine(True)
         eng2.stagger(cheap_pre)
-        q, dt2 = measure(eng2, args.steps)
+        q, dt2 = measure(eng2, vsteps)
         out["cross_game_dedup"] = {
-            "value": q["expansions"] / dt2, "unit": "node-expansions/s", "ms_per_step": dt2 / args.steps * 1e3,
+            "value": q["expansions"] / dt2, "unit": "node-expansions/s", "ms_per_step": dt2 / vsteps * 1e3, "steps": vsteps,
             "games_per_s": q["games_completed"] / dt2, "expansions": int(q["expansions"]), "leaves_evaluated": int(q["leaves_evaluated"]),
             "note": f"same workload (slots staggered at {cheap_pre} sims/move); concurrent games that reach the same board in a step share one "
                     "network evaluation (k_compact). Not the headline: `value` above evaluates every expansion"}
@@ -760,10 +767,10 @@ def run_secondary(ctx):
         engc = make_engine(True, eval_cache=True)
         engc.stagger(cheap_pre)
         c0 = net.eval_cache_stats()
-        qc, dtc = measure(engc, args.steps)
+        qc, dtc = measure(engc, vsteps)
         c1 = net.eval_cache_stats()
         out["eval_cache"] = {
-            "value": qc["expansions"] / dtc, "unit": "node-expansions/s", "ms_per_step": dtc / args.steps * 1e3,
+            "value": qc["expansions"] / dtc, "unit": "node-expansions/s", "ms_per_step": dtc / vsteps * 1e3, "steps": vsteps,
             "games_per_s": qc["games_completed"] / dtc, "sims_per_s": qc["simulations"] / dtc,
             "expansions": int(qc["expansions"]), "leaves_evaluated": int(qc["leaves_evaluated"]),
             "hit_rate": (c1["hits"] - c0["hits"]) / max(c1["lookups"] - c0["lookups"], 1), "cache_entries": c1["entries"],
@@ -780,11 +787,11 @@ def run_secondary(ctx):
         other = "free" if args.driver == "lockstep" else "lockstep"
         engo = make_engine(args.dedup == "on")
         engo.stagger(cheap_pre)
-        qo, dto = measure(engo, args.steps, driver=other)
+        qo, dto = measure(engo, vsteps, driver=other)
         out["other_driver"] = {
-            "driver": other, "value": qo["expansions"] / dto, "unit": "node-expansions/s", "ms_per_step": dto / args.steps * 1e3,
+            "driver": other, "value": qo["expansions"] / dto, "unit": "node-expansions/s", "ms_per_step": dto / vsteps * 1e3, "steps": vsteps,
             "games_per_s": qo["games_completed"] / dto, "sims_per_s": qo["simulations"] / dto,
-            "leaves_per_batch": qo["leaves_evaluated"] / (args.steps * args.sims),
+            "leaves_per_batch": qo["leaves_evaluated"] / (vsteps * args.sims),
             "note": ("oz_selfplay_run_steps: every game runs on by itself (network-free simulations and its move ride in the same launch), "
                      "so nearly every slot of a batch carries a leaf; a game's records are those of lock step bit for bit"
                      if other == "free" else "oz_selfplay_run: one simulation per game per batch, moves aligned")

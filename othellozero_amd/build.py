@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libothellozero_amd.so")
 SOURCES = ["oz_rules.hip", "oz_search.hip", "oz_net.hip", "oz_train.hip"]
-HEADERS = ["oz_common.h", "oz_internal.h", "oz_net_h2.h", "oz_train_fused.h", os.path.join("..", "..", "include", "othellozero_amd.h")]
+HEADERS = ["oz_common.h", "oz_internal.h", "oz_net_h2.h", "oz_net_b3.h", "oz_train_fused.h", os.path.join("..", "..", "include", "othellozero_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 

@@ -478,6 +478,9 @@ int oz_gemm_f32_launch(const float* in, const float* Wt, const float* scale, con
 }
 
 #include "oz_net_h2.h"
+#include "oz_net_b3.h"
+#define B3_MIN_BATCH 128       // precision bf16x3: networks of at least this capacity run conv3 / conv4 / fc1 on k_gemm_b3 (a per-network constant); below it the
+                               // layers are weight streams / 16-way split-K launches -- latency, not matrix rate -- and the exact-fp32 kernels serve them
 #define CONV3_LOW_COST 1.30     // a round of 128-row conv3 tiles against 128/192 of a 192-row round (forward_h2's tile choice)
 
 // k_gemm_h2 for callers outside the network object (the trainer's f16x2 mode): out[M][N] fp32 rows = (A . Wh^T) * scale + shift, A and Wh
@@ -821,6 +824,21 @@ struct OnnNet : oz_net {
     int* d_cal_count = nullptr;
     int cal_total = 0;
 
+    // precision 2 ("f32 via 3 x bf16 split", oz_net_b3.h): conv3, conv4 and fc1 on k_gemm_b3 (weights and activations in the b3 layout, 6 B per
+    // element); conv1 + conv2 from the exact-fp32 pattern tables, fc2 and the heads on the exact-fp32 kernels.  Networks below B3_MIN_BATCH
+    // positions of capacity run the exact-fp32 forward as it is (their layers are weight streams / split-K launches: latency, not matrix rate) --
+    // a per-network constant, so a position's result does not depend on the size of the call it sits in.
+    uint4* d_wb[3] = {nullptr, nullptr, nullptr};            // conv3, conv4, fc1
+    uint4 *b3a2 = nullptr, *b3a3 = nullptr, *b3a4 = nullptr; // conv2 / conv3 / conv4 outputs in the b3 layout
+    float* d_part_b3 = nullptr;                              // fc1's k-slices (fixed-order fp32 reduce)
+    bool use_b3() const { return precision == 2 && max_batch >= B3_MIN_BATCH; }
+    int fc1_b3_ksplit() const {                              // k-slices of fc1 (1024 columns = 4 column tiles): until the grid fills the chip, at most 8
+        const long long blocks = (((long long)max_batch + B3_BM - 1) / B3_BM) * 4;
+        int k = 1;
+        while (k < 8 && blocks * k < 192) k *= 2;
+        return k;
+    }
+
     template <typename T> int alloc(T** p, size_t count) {
         OZ_HIP(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
         allocs.push_back(*p);
@@ -963,7 +981,7 @@ struct OnnNet : oz_net {
     }
 
     // conv1 + conv2 as the table gather-sum: one table slice per XCD at 512 filters, the thread-per-(pixel, 8 channels) kernel otherwise
-    template <bool OUT_H2> void launch_conv2_lut(int max_count, const int* d_count, const float* scale, const float* shift, void* out, hipStream_t s,
+    template <int OUT_H2> void launch_conv2_lut(int max_count, const int* d_count, const float* scale, const float* shift, void* out, hipStream_t s,
                                                  H2Low low = H2Low(), float floor = 0.f) {
         const long long pixels = (long long)max_count * n * n;
         if (C == 512) {
@@ -1435,11 +1453,93 @@ struct OnnNet : oz_net {
         return OZ_OK;
     }
 
+    // layer: 2 = conv3, 3 = conv4 (3x3, Cin = N = C), 4 = fc1 (taps 1); the d_scale / d_shift of precision f32 (no power-of-two bookkeeping)
+    template <int TAG>
+    int launch_gemm_b3(const uint4* in, int layer, void* out, int out_b3, const int* d_count, int max_count, int Hin, int Hout, int pad,
+                       int Cin, int taps, int N, hipStream_t s, int ksplit = 1) {
+        B3Geom g;
+        g.Hin = Hin; g.Hout = Hout; g.pad = pad; g.Cin = Cin; g.taps = taps; g.N = N; g.K = taps * Cin; g.out_b3 = out_b3; g.relu = 1;
+        g.ksplit = ksplit; g.slab = (long long)max_batch * Hout * Hout * N;
+        OZ_REQUIRE(N % B3_BN == 0 && Cin % B3_BK == 0, "gemm_b3: N %% 256 and Cin %% 32 must be 0 (N=%d Cin=%d)", N, Cin);
+        const long long Mmax = (long long)max_count * Hout * Hout;
+        const int num_mt = (int)((Mmax + B3_BM - 1) / B3_BM);
+        const int per_mt = (N / B3_BN) * ksplit;
+        const int grid = num_mt < 8 ? ((per_mt + 7) / 8) * 8 * num_mt : ((num_mt + 7) / 8) * 8 * per_mt;   // (the kernel's two block mappings)
+        {
+            static bool attr_done[64] = {};
+            if (!attr_done[device & 63]) {
+                OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_b3<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS));
+                attr_done[device & 63] = true;
+            }
+        }
+        void* dst = ksplit > 1 ? (void*)d_part_b3 : out;
+        hipLaunchKernelGGL((k_gemm_b3<TAG>), dim3(grid), dim3(B3_NT), B3_LDS, s, in, (const uint4*)d_wb[layer - 2], d_scale[layer], d_shift[layer], dst,
+                           d_count, g, num_mt, d_zero);
+        if (ksplit > 1) {                         // fp32 rows out: the fp32 path's fixed-order reduce (BN + ReLU there)
+            OZ_REQUIRE(!out_b3, "gemm_b3: a split launch writes fp32 rows");
+            const long long quads = ((long long)max_count * Hout * Hout * N + 3) / 4;
+            hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float*)d_part_b3, g.slab, ksplit, N,
+                               Hout * Hout, d_count, d_scale[layer], d_shift[layer], 1, (float*)out);
+        }
+        OZ_HIP(hipGetLastError());
+        return OZ_OK;
+    }
+
+    // precision bf16x3, networks of >= B3_MIN_BATCH positions: gather (exact fp32 tables) -> b3 rows -> conv3 / conv4 / fc1 on k_gemm_b3 -> fc2 and heads in fp32
+    int forward_b3(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi, float* d_v, hipStream_t s) {
+        const bool use_t2f = (tables_mode < 0 || tables_mode >= 2) && t2f_ok;      // else (oz_net_set_tables 0 / 1): conv1 kernel + conv2 as the exact-fp32 GEMM
+        last_conv3_rows = B3_BM;
+        profiled_layer = use_t2f ? 3 : 2;            // the dominant launch: conv3 on k_gemm_b3, or the exact-fp32 conv2 GEMM when the tables are off
+        if (profile && timer.backlog() > 4096) timer.drain();
+        long long tidx = -1;
+        auto mark = [&](int slot, bool begin) {
+            if (!(profile == 2 || (profile == 1 && slot == profiled_layer - 1))) return;
+            if (begin) tidx = timer.begin(slot, s);
+            else { timer.end(tidx, s); tidx = -1; }
+        };
+        const long long cells = (long long)max_count * (n + 2) * (n + 2);
+        mark(0, true);
+        if (use_t2f)
+            hipLaunchKernelGGL(k_lut_ids, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, d_lut_ids,
+                               (const unsigned char*)nullptr, (int*)nullptr);
+        else {
+            const long long threads = (long long)max_count * n * n * (C / 4);
+            hipLaunchKernelGGL(k_conv1, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_own, d_opp, d_count, n, C, d_w1, d_scale[0], d_shift[0], act1);
+        }
+        mark(0, false);
+        mark(1, true);
+        if (use_t2f) launch_conv2_lut<2>(max_count, d_count, d_scale[1], d_shift[1], b3a2, s);      // the gather writes the b3 layout itself
+        else {
+            if (int rc = launch_gemm(act1, d_wt[0], 1, act2, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
+            const long long threads = (long long)max_count * n * n * (C / 8);
+            hipLaunchKernelGGL(k_f32_to_b3, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, act2, d_count, n * n, C, b3a2);
+        }
+        mark(1, false);
+        mark(2, true);
+        if (int rc = launch_gemm_b3<3>(b3a2, 2, b3a3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
+        mark(2, false);
+        mark(3, true);
+        if (int rc = launch_gemm_b3<4>(b3a3, 3, b3a4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
+        mark(3, false);
+        mark(4, true);
+        if (int rc = launch_gemm_b3<5>(b3a4, 4, f1, 0, d_count, max_count, 1, 1, 0, F, 1, 1024, s, fc1_b3_ksplit())) return rc;
+        mark(4, false);
+        mark(5, true);
+        if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, &fc2_defer)) return rc;
+        mark(5, false);
+        mark(6, true);
+        launch_heads(max_count, d_count, d_pi, d_v, s);
+        mark(6, false);
+        OZ_HIP(hipGetLastError());
+        return OZ_OK;
+    }
+
     int forward_device(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi,
                        float* d_v, hipStream_t s) override {
         if (!committed) { oz_set_error("network weights not committed (call oz_net_commit)"); return OZ_ERR_STATE; }
         if (max_count > max_batch) { oz_set_error("batch %d exceeds max_batch %d", max_count, max_batch); return OZ_ERR_ARG; }
         if (precision == 1) return forward_h2(d_own, d_opp, d_count, max_count, d_pi, d_v, s);
+        if (use_b3()) return forward_b3(d_own, d_opp, d_count, max_count, d_pi, d_v, s);
         return forward_f32(d_own, d_opp, d_count, max_count, d_pi, d_v, s);
     }
     // the exact-fp32 forward (precision f32; also the reference of precision f16x2's commit-time self-check, which keeps fp32 copies of
@@ -1705,7 +1805,7 @@ OZ_API int oz_net_commit(oz_net* net) {
         for (int i = 0; i < 5; ++i) raw_max = std::max(raw_max, (size_t)Ks[i] * Ns[i]);
         if (!o->d_raw) { if (int rc = o->alloc(&o->d_raw, raw_max)) return rc; }
     }
-    if (o->precision == 0 && !o->d_part32 && o->part32_mult() > 0) {
+    if (o->precision != 1 && !o->d_part32 && o->part32_mult() > 0) {
         if (int rc = o->alloc(&o->d_part32, o->part32_floats())) return rc;
     }
     if (!o->act1) {
@@ -1724,7 +1824,7 @@ OZ_API int oz_net_commit(oz_net* net) {
     if (int rc = upload(o, &o->d_bv, o->w[39])) return rc;
     o->t2f_ok = false;
     o->t2_ok = false;
-    if (o->precision == 0) {
+    if (o->precision != 1) {
         for (int i = 0; i < 5; ++i) {
             const auto& src = o->w[gl[i]];
             const int K = Ks[i], N = Ns[i];
@@ -1738,8 +1838,22 @@ OZ_API int oz_net_commit(oz_net* net) {
                     hipLaunchKernelGGL(k_w_transpose, dim3((C + 31) / 32, (C + 31) / 32), dim3(256), 0, 0, o->d_raw + (size_t)t * C * C, C, C,
                                        o->d_wtap32 + (size_t)t * C * C);
             }
+            if (o->use_b3() && i >= 1 && i <= 3) {     // conv3, conv4, fc1 once more in the b3 layout (three bf16 planes, the GEMM's tap-inner k order)
+                if (!o->d_wb[i - 1]) { if (int rc = o->alloc(&o->d_wb[i - 1], (size_t)N * (K / 32) * 12)) return rc; }
+                const long long threads = (long long)N * (K / 8);
+                hipLaunchKernelGGL(k_w_to_b3, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, o->d_raw, K, N, i < 3 ? 9 : 1, o->d_wb[i - 1]);
+            }
             OZ_HIP(hipGetLastError());
             OZ_HIP(hipDeviceSynchronize());                       // d_raw is reused by the next layer
+        }
+        if (o->use_b3() && !o->b3a2) {
+            const size_t B = (size_t)o->max_batch, rq = (size_t)C / 32 * 12;        // uint4 per pixel row
+            if (int rc = o->alloc(&o->b3a2, B * n * n * rq)) return rc;
+            if (int rc = o->alloc(&o->b3a3, B * (n - 2) * (n - 2) * rq)) return rc;
+            if (int rc = o->alloc(&o->b3a4, B * (n - 4) * (n - 4) * rq)) return rc;
+            if (int rc = o->alloc(&o->d_part_b3, (size_t)o->fc1_b3_ksplit() * B * 1024)) return rc;
+            if (!o->d_zero) { if (int rc = o->alloc(&o->d_zero, 16)) return rc; }
+            OZ_HIP(hipMemset(o->d_zero, 0, 256));
         }
         if (int rc = o->build_t2_f32()) return rc;
     } else {
@@ -1879,15 +1993,17 @@ OZ_API int oz_net_time_forward(oz_net* net, int count, int iters, float* ms_avg)
     return OZ_OK;
 }
 
-// precision: 0 = exact fp32 matrix cores (k_gemm_f32), 1 = f32 via 2 x fp16 split on the 16-bit matrix cores (oz_net_h2.h).
+// precision: 0 = exact fp32 matrix cores (k_gemm_f32), 1 = f32 via 2 x fp16 split on the 16-bit matrix cores (oz_net_h2.h),
+// 2 = f32 via 3 x bf16 split (oz_net_b3.h: every fp32 value exactly, six bf16 MFMA products per fp32 product; networks of fewer than
+// B3_MIN_BATCH positions run the exact-fp32 kernels).
 // Takes effect at the next oz_net_commit.
 OZ_API int oz_net_set_precision(oz_net* net, int mode) {
     OnnNet* o = as_onn(net);
     OZ_REQUIRE(o, "not an OthelloNN network");
-    OZ_REQUIRE(mode == 0 || mode == 1, "precision must be 0 (f32) or 1 (f16x2)");
-    OZ_REQUIRE(mode == 0 || o->C % 256 == 0, "precision f16x2 needs channels %% 256 == 0 (got %d)", o->C);
+    OZ_REQUIRE(mode == 0 || mode == 1 || mode == 2, "precision must be 0 (f32), 1 (f16x2) or 2 (bf16x3)");
+    OZ_REQUIRE(mode == 0 || o->C % 256 == 0, "precision f16x2 / bf16x3 needs channels %% 256 == 0 (got %d)", o->C);
     // the low-side guard counts a row's low 64-channel slices in 6 bits (h2_low_report): 64 slices or more would switch it off silently
-    OZ_REQUIRE(mode == 0 || o->C <= 2048, "precision f16x2 supports at most 2048 channels (got %d): use precision f32", o->C);
+    OZ_REQUIRE(mode != 1 || o->C <= 2048, "precision f16x2 supports at most 2048 channels (got %d): use precision f32", o->C);
     std::lock_guard<std::mutex> lk(o->mu);
     if (o->precision != mode) { o->precision = mode; o->committed = false; }
     return OZ_OK;

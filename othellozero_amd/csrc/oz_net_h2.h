@@ -552,7 +552,9 @@ __device__ __forceinline__ size_t t2_record(int slice, int t, unsigned id) {    
     return (((size_t)slice * 9 + t) * OZ_LUT_ROWS + id) * OZ_C2L_SLICE;
 }
 // one output row piece: BN + ReLU of 8 channel sums, then the h2 split (two 16-byte streaming stores) or fp32 (two 16-byte stores)
-template <bool OUT_H2>
+// OUT: 0 = fp32 rows, 1 = the h2 layout, 2 = the b3 layout (three bf16 planes, oz_net_b3.h)
+__device__ __forceinline__ void b3_split(float x, __bf16& b1, __bf16& b2, __bf16& b3);
+template <int OUT>
 __device__ __forceinline__ bool c2l_finish(const f32x4& lo, const f32x4& hi, const float* __restrict__ scale, const float* __restrict__ shift, int c8,
                                            void* __restrict__ out, size_t pixel, int C, float& vmax, float relu_floor) {
     const f32x4 sc0 = *reinterpret_cast<const f32x4*>(scale + c8), sc1 = *reinterpret_cast<const f32x4*>(scale + c8 + 4);
@@ -568,7 +570,21 @@ __device__ __forceinline__ bool c2l_finish(const f32x4& lo, const f32x4& hi, con
     for (int j = 0; j < 8; ++j) vmax = fmaxf(vmax, v[j]);
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     bool over = false;
-    if constexpr (OUT_H2) {
+    constexpr bool OUT_H2 = OUT == 1;
+    if constexpr (OUT == 2) {
+        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+        bf16x8_t p0, p1, p2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 a, b, c;
+            b3_split(v[j], a, b, c);
+            p0[j] = a; p1[j] = b; p2[j] = c;
+        }
+        v4u* dst = reinterpret_cast<v4u*>(reinterpret_cast<uint4*>(out) + pixel * (size_t)(C / 32 * 12) + (c8 >> 5) * 12 + ((c8 >> 3) & 3));
+        __builtin_nontemporal_store(*reinterpret_cast<v4u*>(&p0), dst);
+        __builtin_nontemporal_store(*reinterpret_cast<v4u*>(&p1), dst + 4);
+        __builtin_nontemporal_store(*reinterpret_cast<v4u*>(&p2), dst + 8);
+    } else if constexpr (OUT_H2) {
         f16x8 h1, h2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -613,12 +629,13 @@ __device__ __forceinline__ unsigned lut_id_of(uint64_t o, uint64_t p, int cy, in
 }
 // INLINE_IDS (few positions: the latency path of precision f32): the nine pattern ids of a pixel are computed from the bitboards here instead of
 // read from the padded id boards k_lut_ids writes -- one launch less in front of a forward that is all launch latency (same ids, same sums)
-template <int N, bool OUT_H2, bool INLINE_IDS = false>
+template <int N, int OUT, bool INLINE_IDS = false>
 __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restrict__ ids, const int* __restrict__ d_count,
                                                        const float* __restrict__ T2, const float* __restrict__ scale, const float* __restrict__ shift,
                                                        void* __restrict__ out, int* __restrict__ flag, H2Low low, float floor,
                                                        const uint64_t* __restrict__ own = nullptr, const uint64_t* __restrict__ opp = nullptr) {
     constexpr int P = N * N, W = N + 2, PW = W * W, C = 512;
+    constexpr bool OUT_H2 = OUT == 1, OUT_B3 = OUT == 2;
     const float relu_floor = OUT_H2 ? 0.f : floor;            // fp32 rows: 0 = ReLU, -inf = the BN output itself (calibration passes)
     const int slice = blockIdx.x & 7, j = threadIdx.x & 7;
     const long long total = (long long)(*d_count) * P;
@@ -692,6 +709,34 @@ __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restric
             v4u* dst = reinterpret_cast<v4u*>(reinterpret_cast<unsigned char*>(out) + (size_t)pixel * (C * 4) + slice * 256 + j * 16);
             __builtin_nontemporal_store(c0, dst);
             __builtin_nontemporal_store(c1, dst + 8);
+        } else if constexpr (OUT_B3) {
+            // b3 layout (oz_net_b3.h): the slice's 64 channels are k-tiles 2 slice (line 0: channels 4 j ..) and 2 slice + 1 (line 1) of the pixel's row, a k-tile
+            // = [plane 0 | plane 1 | plane 2] x 64 B; lane pair (2 g, 2 g + 1) holds the 8 channels of chunk g of every plane.  Six chunks per pair: the even
+            // lane ends up with (k-tile 0: planes 0, 1; k-tile 1: plane 0), the odd lane with (k-tile 0: plane 2; k-tile 1: planes 1, 2) -- each store
+            // instruction then writes two whole 64-byte segments per pixel (four lanes x 16 B each)
+            typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+            union Pk { bf16x4_t h; unsigned u[2]; };
+            Pk a[3], b[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __bf16 x1, x2, x3;
+                b3_split(va[q], x1, x2, x3); a[0].h[q] = x1; a[1].h[q] = x2; a[2].h[q] = x3;
+                b3_split(vb[q], x1, x2, x3); b[0].h[q] = x1; b[1].h[q] = x2; b[2].h[q] = x3;
+            }
+            const bool even = (j & 1) == 0;
+            const unsigned give[6] = {even ? a[2].u[0] : a[0].u[0], even ? a[2].u[1] : a[0].u[1], even ? b[1].u[0] : a[1].u[0], even ? b[1].u[1] : a[1].u[1],
+                                      even ? b[2].u[0] : b[0].u[0], even ? b[2].u[1] : b[0].u[1]};
+            unsigned got[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) got[q] = (unsigned)__shfl_xor((int)give[q], 1, 64);
+            v4u c0, c1, c2;      // a chunk = [even lane's 4 channels | odd lane's 4 channels]
+            c0[0] = even ? a[0].u[0] : got[0]; c0[1] = even ? a[0].u[1] : got[1]; c0[2] = even ? got[0] : a[2].u[0]; c0[3] = even ? got[1] : a[2].u[1];
+            c1[0] = even ? a[1].u[0] : got[2]; c1[1] = even ? a[1].u[1] : got[3]; c1[2] = even ? got[2] : b[1].u[0]; c1[3] = even ? got[3] : b[1].u[1];
+            c2[0] = even ? b[0].u[0] : got[4]; c2[1] = even ? b[0].u[1] : got[5]; c2[2] = even ? got[4] : b[2].u[0]; c2[3] = even ? got[5] : b[2].u[1];
+            unsigned char* base = reinterpret_cast<unsigned char*>(out) + (size_t)pixel * (C * 6) + slice * 384 + (j >> 1) * 16;
+            __builtin_nontemporal_store(c0, reinterpret_cast<v4u*>(base + (even ? 0 : 128)));             // k-tile 0: plane 0 | plane 2
+            __builtin_nontemporal_store(c1, reinterpret_cast<v4u*>(base + (even ? 64 : 192 + 64)));       // k-tile 0: plane 1 | k-tile 1: plane 1
+            __builtin_nontemporal_store(c2, reinterpret_cast<v4u*>(base + (even ? 192 : 192 + 128)));     // k-tile 1: plane 0 | plane 2
         } else {
             float* dst = reinterpret_cast<float*>(out) + (size_t)pixel * C + ca;
             __builtin_nontemporal_store(va, reinterpret_cast<f32x4*>(dst));
@@ -702,7 +747,7 @@ __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restric
 }
 
 // any channel count: one thread per (pixel, 8 channels); same sums in the same order
-template <bool OUT_H2>
+template <int OUT>
 __global__ __launch_bounds__(256) void k_conv2_lut(const unsigned* __restrict__ ids, const int* __restrict__ d_count, int n, int C,
                                                    const float* __restrict__ T2, const float* __restrict__ scale, const float* __restrict__ shift,
                                                    void* __restrict__ out, int* __restrict__ flag, H2Low low, float floor) {
@@ -728,7 +773,8 @@ __global__ __launch_bounds__(256) void k_conv2_lut(const unsigned* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 9; ++t) { lo += ra[t]; hi += rb[t]; }
     float vmax;
-    if (c2l_finish<OUT_H2>(lo, hi, scale, shift, c8, out, (size_t)pixel, C, vmax, OUT_H2 ? 0.f : floor)) atomicOr(flag, H2_FLAG_OVER);
+    constexpr bool OUT_H2 = OUT == 1;
+    if (c2l_finish<OUT>(lo, hi, scale, shift, c8, out, (size_t)pixel, C, vmax, OUT_H2 ? 0.f : floor)) atomicOr(flag, H2_FLAG_OVER);
     if (OUT_H2 && low.cnt) {                                 // cg % 8 == 0: a 64-channel slice = one lane octet of one pixel
         vmax = h2_octet_max(vmax);
         if ((threadIdx.x & 7) == 0 && vmax > 0.f && vmax < low.thr) h2_low_report(low, pixel, C >> 6);

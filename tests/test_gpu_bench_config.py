@@ -81,7 +81,7 @@ def _case(n):
     return _CACHE[n]
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+@pytest.mark.parametrize("precision", ["f16x2", "f32", "bf16x3"])
 @pytest.mark.parametrize("n", [8, 6])
 def test_network_at_bench_batch_vs_float64_oracle(oz, n, precision):
     """NNetWrapper(max_batch=4096), ONE call with 4096 positions == one forward of the kernels bench.py times"""
@@ -116,7 +116,7 @@ def test_network_at_bench_batch_vs_float64_oracle(oz, n, precision):
     assert np.abs(pt.reshape(sel.size, -1) - pi[sel]).max() <= TWIN_TOL and np.abs(vt - v[sel]).max() <= TWIN_TOL
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+@pytest.mark.parametrize("precision", ["f16x2", "f32", "bf16x3"])
 def test_network_at_the_timed_shape_vs_float64_oracle(oz, precision):
     """the exact launch bench.py's timed region makes: NNetWrapper(max_batch=4096), ONE call with preferred_batch_cap(8, 4096, 512) =
     3640 positions -- conv3 then runs on the 256-row tile (1024 tiles = 4.0 grid rounds), the kernel the roofline row is about.
@@ -137,6 +137,8 @@ def test_network_at_the_timed_shape_vs_float64_oracle(oz, precision):
     rows_full = net.conv3_tile_rows()
     if precision == "f16x2":
         assert (rows_cap, rows_full) == (256, 192)                       # the capped call IS the timed kernel; the full call is the other tile
+    elif precision == "bf16x3":
+        assert (rows_cap, rows_full) == (128, 128)                       # k_gemm_b3's one tile (128 x 256: 6 B per element, two stages of 72 KB)
     else:
         # exact fp32: the library reports what oz_gemm_f32_launch really launched -- k_gemm_f32<GmBig>, the 256 x 256 tile, for every
         # call of a max_batch = 4096 network (the tile is keyed on the capacity, not on the size of a call)
@@ -240,7 +242,7 @@ def test_config5_real_networks_whole_games_vs_oracle(oz):
     assert short["plies_per_game"] == 3 and short["moves"] == 512 * 3 and short["sample_mismatches"] == 0 and "games_per_s" not in short
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+@pytest.mark.parametrize("precision", ["f16x2", "f32", "bf16x3"])
 def test_network_at_bench_batch_gemm_form_vs_float64_oracle(oz, precision):
     """the same 4096-position forward with conv1 as a kernel and conv2 as an MFMA implicit GEMM (oz_net_set_tables 0: the
     `all_layers_as_gemm` leg of bench.py) -- the 256 x 256 ping-pong tile on conv2 at one k-slice"""
@@ -258,7 +260,8 @@ def test_network_at_bench_batch_gemm_form_vs_float64_oracle(oz, precision):
         assert np.array_equal(p1, pi) and np.array_equal(v1, v)          # documented bit-identical to mode 0
 
 
-@pytest.mark.parametrize("n,precision,dedup", [(8, "f16x2", False), (8, "f16x2", True), (8, "f32", False), (6, "f16x2", False), (6, "f32", False)])
+@pytest.mark.parametrize("n,precision,dedup", [(8, "f16x2", False), (8, "f16x2", True), (8, "f32", False), (6, "f16x2", False), (6, "f32", False),
+                                               (8, "bf16x3", False), (6, "bf16x3", False)])
 def test_config2_real_network_search_replay(oz, n, precision, dedup):
     """BASELINE configs[1] (8x8) and configs[3] (6x6) with the real network: 4096 concurrent games x 100 sims/move x 2 move rounds on the
     512-filter OthelloNN (max_batch 4096: the kernels bench.py times -- on 6x6 what its `config4` leg times); 16 sampled games are replayed by

@@ -1228,14 +1228,16 @@ def test_bench_single_rank_contract(tmp_path):
     assert keys[:13] == ["metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                          "dtype", "data"] and keys[13:15] == ["config", "roofline"]
     assert out["metric"] == "mcts_node_expansions_per_sec" and out["n_gpus"] == 1 and out["steps"] == 3 and out["vs_baseline"] is None
-    assert "workload" in out["config"] and "model" not in out["config"] and out["config"]["precision"] == "f32"
-    # the reference's arithmetic on top: exact fp32 on the fp32 matrix cores
-    assert out["dtype"] == "f32"
+    assert "workload" in out["config"] and "model" not in out["config"] and out["config"]["precision"] == "bf16x3"
+    # on top: fp32 values carried exactly as three bf16 planes, six bf16 MFMA products per fp32 product (fp32-class, 2.67x the fp32 matrix roof) ...
+    assert out["dtype"] == "f32 (3xbf16 split)"
     rf = out["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "kernel"):
         assert k in rf, k
-    assert rf["bound"] == "mfma" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["launches"] == 3 * 16
-    assert 0 < rf["frac"] < 1 and "k_gemm_f32" in rf["kernel"]
+    assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["launches"] == 3 * 16
+    assert 0 < rf["frac"] < 1 / 6 and "k_gemm_b3" in rf["kernel"] and rf["mfma_products_per_fp32_product"] == 6 and 0 < rf["matrix_pipe_frac"] < 1
+    # ... and the reference's literal arithmetic beside it: exact fp32 on the fp32 matrix cores, same workload, same run, same steps
+    assert out["value_f32"] > 0 and out["dtype_f32"] == "f32" and out["roofline_f32"]["peak"] == 157.3 and 0 < out["roofline_f32"]["frac"] < 1
     # roofline.traffic is measured in the run (two rocprofv3 --pmc child passes); the committed profile is only the fallback
     assert rf["traffic_measured_in_this_run"] is True and rf["traffic"] > 0
     # every expansion is evaluated in the timed region
@@ -1259,11 +1261,14 @@ def test_bench_single_rank_contract(tmp_path):
     assert det["slot_ply_spread_rank0"][1] - det["slot_ply_spread_rank0"][0] >= 40
     p16 = det["precisions"]["f16x2"]
     assert p16["value"] == pytest.approx(out["value_f16x2"], rel=1e-5) and p16["steps"] == 3 and p16["roofline"]["peak"] == 2500.0
+    p32 = det["precisions"]["f32"]
+    assert p32["value"] == pytest.approx(out["value_f32"], rel=1e-5) and p32["steps"] == 3 and p32["roofline"]["peak"] == 157.3 and "k_gemm_f32" in p32["roofline"]["kernel"]
+    assert "measured in this run" in (p32["roofline"]["traffic_source"] or ""), p32["roofline"].get("live_traffic_error")
     # the 6x6 config carries its own roofline (conv3 of the 6x6 network, HIP events in ITS timed steps), kernels[] and the other precisions' rates
     c4 = det["config4"]
     assert c4["roofline"]["bound"] == "mfma" and c4["roofline"]["launches"] == 3 * 16 and 0 < c4["roofline"]["frac"] < 1 and c4["roofline"]["flop_per_leaf"] == 2 * 16 * 4608 * 512
-    assert c4["roofline"]["peak"] == 157.3 and {"conv3", "conv4", "fc1", "select"} <= {k["name"] for k in c4["kernels"]}
-    assert c4["precisions"]["f16x2"]["value"] > 0 and c4["precisions"]["f16x2"]["roofline"]["peak"] == 2500.0
+    assert c4["roofline"]["peak"] == 2500.0 and {"conv3", "conv4", "fc1", "select"} <= {k["name"] for k in c4["kernels"]}
+    assert c4["precisions"]["f16x2"]["value"] > 0 and c4["precisions"]["f32"]["roofline"]["peak"] == 157.3
     pr = det["per_rank"]
     assert len(pr["ms_per_step"]) == 1 and pr["ms_per_step_min"] == pr["ms_per_step_max"] <= det["ms_per_step"] and pr["expansions"] == [det["expansions"]]
     assert det["config"]["driver"] == "free" and det["other_driver"]["driver"] == "lockstep" and det["other_driver"]["value"] > 0
