@@ -282,16 +282,16 @@ def run_rank(args, rank, world, local_rank, t_proc):
 
     from othellozero_amd.training import preferred_batch_cap
 
-    def batch_cap(board, games):
-        """leaves per network batch of the free-running driver (0: none)"""
-        return preferred_batch_cap(board, games, args.channels) if args.batch_cap < 0 else args.batch_cap
+    def batch_cap(board, games, the_precision=None):
+        """leaves per network batch of the free-running driver (0: none) for a network of `the_precision` (default: the timed region's)"""
+        return preferred_batch_cap(board, games, args.channels, the_precision or args.precision) if args.batch_cap < 0 else args.batch_cap
 
     def make_engine(dedup, the_net=net, board=n, games=G, steps=args.steps, eval_cache=False):
         # (oz_selfplay_config.dedup / .batch_cap; the cap is used by the free-running driver only)
         return SelfPlayEngine(the_net, board, games, args.sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=rank * games,
                               game_id_stride=world * games, q_mode=_lib.QMODE_F64, refill=True,
                               record_cap=int(games * (steps + args.warmup + board * board + 2) * 1.25),
-                              dedup=dedup, batch_cap=batch_cap(board, games), eval_cache=eval_cache)
+                              dedup=dedup, batch_cap=batch_cap(board, games, getattr(the_net, "precision", None)), eval_cache=eval_cache)
     eng = make_engine(args.dedup == "on")
     cap_main = batch_cap(n, G) if args.driver == "free" else 0
 

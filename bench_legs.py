@@ -63,7 +63,8 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
          "avg_launch_ms": layer_ms / max(launches, 1), "flop_per_leaf": conv_flop_per_leaf(layer, n, channels),
          "algorithmic_bytes_per_launch": None}
     px_in, px_out = {2: (n * n, n * n), 3: (n * n, (n - 2) ** 2), 4: ((n - 2) ** 2, (n - 4) ** 2)}[layer]
-    r["algorithmic_bytes_per_launch"] = (expansions / max(launches, 1)) * (px_in + px_out) * channels * 4 + 9 * channels * channels * 4
+    el = 6 if precision == "bf16x3" else 4                  # bytes per tensor element: three bf16 planes, or fp32 / two fp16 planes
+    r["algorithmic_bytes_per_launch"] = (expansions / max(launches, 1)) * (px_in + px_out) * channels * el + 9 * channels * channels * el
     if precision == "bf16x3":
         kernel = (f"k_gemm_b3<{layer}> (conv{layer}: 3x3, 512->512, 128 x 256 tiles, implicit GEMM, f32 as 3xbf16 split, 6 products on v_mfma_f32_16x16x32_bf16, "
                   "2-phase ping-pong loop); conv1 + conv2 = exact-fp32 table gather-sum")
@@ -425,7 +426,7 @@ def live_traffic(args, layer, grid_leaves, timeout_s=150, precision=None):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="oz_bench_pmc_")
-    vals = {}
+    vals, child_leaves = {}, {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out_dir = os.path.join(tmp, counter)
@@ -438,6 +439,11 @@ def live_traffic(args, layer, grid_leaves, timeout_s=150, precision=None):
             files = glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+            try:      # what the child's launches really held (its own line): the caller scales the bytes to ITS leaves per launch with this, not with the cap
+                cl = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                child_leaves[counter] = cl["leaves_evaluated_rank0"] / max(cl["roofline"]["launches"], 1)
+            except Exception:                                    # noqa: BLE001
+                child_leaves[counter] = float(grid_leaves)
             # the dominant launch of the timed step: the layer-th GEMM after each k_lut_ids, in the last `sims` forwards (launch order, as
             # tools/summarize_prof.py labels them)
             rows = sorted(csv.DictReader(open(files[0])), key=lambda x: int(x["Dispatch_Id"]))
@@ -459,10 +465,11 @@ def live_traffic(args, layer, grid_leaves, timeout_s=150, precision=None):
         return None, f"live PMC pass failed: {e!r}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    byts = vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024
+    # bytes per LEAF of the child's launches (each counter by its own pass's leaves per launch) x the leaves per launch the caller asks about
+    byts = (vals["FETCH_SIZE"] * 1024 * 2 / child_leaves["FETCH_SIZE"] + vals["WRITE_SIZE"] * 1024 / child_leaves["WRITE_SIZE"]) * float(grid_leaves)
     return byts, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate child runs of bench.py --steps 1 --stagger-sims 8 "
-                  f"--no-compare), average over the {args.sims} launches of the timed step at {grid_leaves} leaves per launch; FETCH_SIZE x2 (gfx950) "
-                  f"= {vals['FETCH_SIZE'] * 2048 / 1e9:.3f} GB read + {vals['WRITE_SIZE'] * 1024 / 1e9:.3f} GB written")
+                  f"--no-compare), average over the {args.sims} launches of the timed step ({child_leaves['FETCH_SIZE']:.0f} leaves per launch there); FETCH_SIZE x2 (gfx950) "
+                  f"= {vals['FETCH_SIZE'] * 2048 / 1e9:.3f} GB read + {vals['WRITE_SIZE'] * 1024 / 1e9:.3f} GB written per launch")
 
 
 def config5_arena(channels, precision, plies=0, games=512, sims=800, sample=2, dedup_compare_plies=6):
@@ -729,10 +736,10 @@ def run_secondary(ctx):
     if secondary and not args.no_live_traffic:
         # roofline.traffic: measured now (PMC passes in child processes), not taken from the committed profile
         t_sec = time.perf_counter()
-        byts, how = live_traffic(args, layer, cap_main or G)
+        byts, how = live_traffic(args, layer, d["leaves_evaluated"] / max(dom_launches, 1))      # scaled to the leaves per launch of the timed region
         if byts is not None:
             out["roofline"]["traffic_from_committed_profile"] = out["roofline"]["traffic"]
-            out["roofline"]["traffic"] = byts * (d["leaves_evaluated"] / max(dom_launches, 1)) / float(cap_main or G)
+            out["roofline"]["traffic"] = byts
             out["roofline"]["traffic_source"] = how
         else:
             out["roofline"]["live_traffic_error"] = how
@@ -843,11 +850,11 @@ def run_secondary(ctx):
                 out["parity_max_err_" + prec] = max(pp_["max_abs_err_pi"], pp_["max_abs_err_v"])
             del ep, netp
             if not args.no_live_traffic and prec != "f16x2":            # (two more PMC child runs per mode: the exact-fp32 and bf16x3 legs get them)
-                byts, how = live_traffic(args, layerp, cap_main or G, precision=prec)
+                byts, how = live_traffic(args, layerp, qp["leaves_evaluated"] / max(lp, 1), precision=prec)
                 rp = leg["roofline"]
                 if byts is not None:
                     rp["traffic_from_committed_profile"] = rp["traffic"]
-                    rp["traffic"] = byts * (qp["leaves_evaluated"] / max(lp, 1)) / float(cap_main or G)
+                    rp["traffic"] = byts
                     rp["traffic_source"] = how
                 else:
                     rp["live_traffic_error"] = how

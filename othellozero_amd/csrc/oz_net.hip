@@ -828,15 +828,18 @@ struct OnnNet : oz_net {
     // element); conv1 + conv2 from the exact-fp32 pattern tables, fc2 and the heads on the exact-fp32 kernels.  Networks below B3_MIN_BATCH
     // positions of capacity run the exact-fp32 forward as it is (their layers are weight streams / split-K launches: latency, not matrix rate) --
     // a per-network constant, so a position's result does not depend on the size of the call it sits in.
-    uint4* d_wb[3] = {nullptr, nullptr, nullptr};            // conv3, conv4, fc1
-    uint4 *b3a2 = nullptr, *b3a3 = nullptr, *b3a4 = nullptr; // conv2 / conv3 / conv4 outputs in the b3 layout
+    uint4* d_wb[4] = {nullptr, nullptr, nullptr, nullptr};   // conv3, conv4, fc1, fc2
+    uint4 *b3a2 = nullptr, *b3a3 = nullptr, *b3a4 = nullptr, *b3f1 = nullptr;   // conv2 / conv3 / conv4 / fc1 outputs in the b3 layout
     float* d_part_b3 = nullptr;                              // fc1's k-slices (fixed-order fp32 reduce)
     bool use_b3() const { return precision == 2 && max_batch >= B3_MIN_BATCH; }
     int fc1_b3_ksplit() const {                              // k-slices of fc1 (1024 columns = 4 column tiles): until the grid fills the chip, at most 8
         const long long blocks = (((long long)max_batch + B3_BM - 1) / B3_BM) * 4;
         int k = 1;
         while (k < 8 && blocks * k < 192) k *= 2;
-        return k;
+        return k < 2 ? 2 : k;                                // (always split: its fixed-order reduce is what writes fc2's b3 operand)
+    }
+    int fc2_b3_ksplit() const {                              // fc2 (512 columns = 2 column tiles, 32 k-tiles): 4 slices of 8 k-tiles; the heads kernel adds them
+        return 4;
     }
 
     template <typename T> int alloc(T** p, size_t count) {
@@ -1475,8 +1478,13 @@ struct OnnNet : oz_net {
         void* dst = ksplit > 1 ? (void*)d_part_b3 : out;
         hipLaunchKernelGGL((k_gemm_b3<TAG>), dim3(grid), dim3(B3_NT), B3_LDS, s, in, (const uint4*)d_wb[layer - 2], d_scale[layer], d_shift[layer], dst,
                            d_count, g, num_mt, d_zero);
-        if (ksplit > 1) {                         // fp32 rows out: the fp32 path's fixed-order reduce (BN + ReLU there)
-            OZ_REQUIRE(!out_b3, "gemm_b3: a split launch writes fp32 rows");
+        if (ksplit > 1 && layer == 5) {           // fc2: the heads kernel adds the slices in fixed order (launch_heads), BN + ReLU there
+            fc2_defer.partial = d_part_b3; fc2_defer.slab = g.slab; fc2_defer.ksplit = ksplit; fc2_defer.scale = d_scale[layer]; fc2_defer.shift = d_shift[layer];
+        } else if (ksplit > 1 && out_b3) {        // the consumer reads the b3 layout: fixed-order reduce + BN + ReLU + split
+            const long long threads = (long long)max_count * Hout * Hout * (N / 8);
+            hipLaunchKernelGGL(k_splitk_reduce_b3, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)d_part_b3, g.slab, ksplit, N,
+                               Hout * Hout, d_count, d_scale[layer], d_shift[layer], (uint4*)out);
+        } else if (ksplit > 1) {                  // fp32 rows out: the fp32 path's fixed-order reduce (BN + ReLU there)
             const long long quads = ((long long)max_count * Hout * Hout * N + 3) / 4;
             hipLaunchKernelGGL(k_splitk_reduce_f32, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float*)d_part_b3, g.slab, ksplit, N,
                                Hout * Hout, d_count, d_scale[layer], d_shift[layer], 1, (float*)out);
@@ -1522,10 +1530,10 @@ struct OnnNet : oz_net {
         if (int rc = launch_gemm_b3<4>(b3a3, 3, b3a4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
         mark(3, false);
         mark(4, true);
-        if (int rc = launch_gemm_b3<5>(b3a4, 4, f1, 0, d_count, max_count, 1, 1, 0, F, 1, 1024, s, fc1_b3_ksplit())) return rc;
+        if (int rc = launch_gemm_b3<5>(b3a4, 4, b3f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, fc1_b3_ksplit())) return rc;
         mark(4, false);
         mark(5, true);
-        if (int rc = launch_gemm(f1, d_wt[4], 5, f2, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, &fc2_defer)) return rc;
+        if (int rc = launch_gemm_b3<6>(b3f1, 5, f2, 0, d_count, max_count, 1, 1, 0, 1024, 1, 512, s, fc2_b3_ksplit())) return rc;
         mark(5, false);
         mark(6, true);
         launch_heads(max_count, d_count, d_pi, d_v, s);
@@ -1838,7 +1846,7 @@ OZ_API int oz_net_commit(oz_net* net) {
                     hipLaunchKernelGGL(k_w_transpose, dim3((C + 31) / 32, (C + 31) / 32), dim3(256), 0, 0, o->d_raw + (size_t)t * C * C, C, C,
                                        o->d_wtap32 + (size_t)t * C * C);
             }
-            if (o->use_b3() && i >= 1 && i <= 3) {     // conv3, conv4, fc1 once more in the b3 layout (three bf16 planes, the GEMM's tap-inner k order)
+            if (o->use_b3() && i >= 1) {               // conv3, conv4, fc1, fc2 once more in the b3 layout (three bf16 planes, the GEMM's tap-inner k order)
                 if (!o->d_wb[i - 1]) { if (int rc = o->alloc(&o->d_wb[i - 1], (size_t)N * (K / 32) * 12)) return rc; }
                 const long long threads = (long long)N * (K / 8);
                 hipLaunchKernelGGL(k_w_to_b3, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, o->d_raw, K, N, i < 3 ? 9 : 1, o->d_wb[i - 1]);
@@ -1851,7 +1859,8 @@ OZ_API int oz_net_commit(oz_net* net) {
             if (int rc = o->alloc(&o->b3a2, B * n * n * rq)) return rc;
             if (int rc = o->alloc(&o->b3a3, B * (n - 2) * (n - 2) * rq)) return rc;
             if (int rc = o->alloc(&o->b3a4, B * (n - 4) * (n - 4) * rq)) return rc;
-            if (int rc = o->alloc(&o->d_part_b3, (size_t)o->fc1_b3_ksplit() * B * 1024)) return rc;
+            if (int rc = o->alloc(&o->b3f1, B * (1024 / 32 * 12))) return rc;
+            if (int rc = o->alloc(&o->d_part_b3, (size_t)std::max(o->fc1_b3_ksplit() * 1024, o->fc2_b3_ksplit() * 512) * B)) return rc;
             if (!o->d_zero) { if (int rc = o->alloc(&o->d_zero, 16)) return rc; }
             OZ_HIP(hipMemset(o->d_zero, 0, 256));
         }

@@ -85,6 +85,36 @@ __global__ __launch_bounds__(256) void k_f32_to_b3(const float* __restrict__ x, 
     dst[8] = *reinterpret_cast<uint4*>(&p2);
 }
 
+// finishes a split-K layer whose consumer reads the b3 layout: out[m][n] = relu((sum_s slab[s][m][n]) * scale[n] + shift[n]), the slices added in a
+// FIXED order (s = 0, 1, ...: bit-reproducible), then split into the three planes.  One thread per (row, 8 channels).
+__global__ __launch_bounds__(256) void k_splitk_reduce_b3(const float* __restrict__ part, long long slab, int ksplit, int N, int P,
+                                                          const int* __restrict__ d_count, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, uint4* __restrict__ out) {
+    const int ng = N >> 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long m = idx / ng;
+    if (m >= (long long)(*d_count) * P) return;
+    const int c8 = (int)(idx % ng) * 8;
+    const float* p = part + (size_t)m * N + c8;
+    f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+    for (int s = 1; s < ksplit; ++s) {
+        lo += *reinterpret_cast<const f32x4*>(p + (size_t)s * slab);
+        hi += *reinterpret_cast<const f32x4*>(p + (size_t)s * slab + 4);
+    }
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = fmaxf(fmaf(j < 4 ? lo[j] : hi[j - 4], scale[c8 + j], shift[c8 + j]), 0.f);
+        __bf16 a, b, c;
+        b3_split(v, a, b, c);
+        p0[j] = a; p1[j] = b; p2[j] = c;
+    }
+    uint4* dst = out + (size_t)m * (size_t)(N / 32 * 12) + (c8 >> 5) * 12 + ((c8 >> 3) & 3);
+    dst[0] = *reinterpret_cast<uint4*>(&p0);
+    dst[4] = *reinterpret_cast<uint4*>(&p1);
+    dst[8] = *reinterpret_cast<uint4*>(&p2);
+}
+
 // weights as stored by Keras, [K][N] with k = tap * Cin + ci  ->  b3 rows [N][K / 32][3 planes][32] in the GEMM's k order
 // k' = (slice * taps + tap) * 32 + c32.  One thread per (output channel c, group of 8 k'); adjacent threads = adjacent c.
 __global__ __launch_bounds__(256) void k_w_to_b3(const float* __restrict__ src, int K, int N, int taps, uint4* __restrict__ out) {

@@ -609,6 +609,7 @@ __device__ __forceinline__ bool c2l_finish(const f32x4& lo, const f32x4& hi, con
 // C = 512: block b works on slice b & 7 (its XCD's eighth of the table) for pixels [(b >> 3) * 32 * PPT, ...): a wave = 8 pixels x 8 lanes
 // (lane j of a pixel: channels 64 * slice + 8 j .. + 7, two 16-byte loads per tap), OZ_C2L_PPT pixel groups per thread.
 #define OZ_C2L_PPT 2
+#define C2L_B3_PIX 448          // bytes per pixel of the b3 staging image: 384 + 64 (pixels 0..3 of a half wave start in four different bank quarters)
 // pattern id of cell (cy, cx) of an N x N board straight from the bitboards (k_lut_ids' arithmetic; off the board = the all-zero row)
 template <int N>
 __device__ __forceinline__ unsigned lut_id_of(uint64_t o, uint64_t p, int cy, int cx) {
@@ -636,6 +637,7 @@ __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restric
                                                        const uint64_t* __restrict__ own = nullptr, const uint64_t* __restrict__ opp = nullptr) {
     constexpr int P = N * N, W = N + 2, PW = W * W, C = 512;
     constexpr bool OUT_H2 = OUT == 1, OUT_B3 = OUT == 2;
+    __shared__ __attribute__((aligned(16))) unsigned char c2l_b3_stage[OUT_B3 ? 4 * 8 * C2L_B3_PIX : 16];      // b3 output: a wave's 8 pixels x 384 B (+ pad)
     const float relu_floor = OUT_H2 ? 0.f : floor;            // fp32 rows: 0 = ReLU, -inf = the BN output itself (calibration passes)
     const int slice = blockIdx.x & 7, j = threadIdx.x & 7;
     const long long total = (long long)(*d_count) * P;
@@ -711,11 +713,12 @@ __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restric
             __builtin_nontemporal_store(c1, dst + 8);
         } else if constexpr (OUT_B3) {
             // b3 layout (oz_net_b3.h): the slice's 64 channels are k-tiles 2 slice (line 0: channels 4 j ..) and 2 slice + 1 (line 1) of the pixel's row, a k-tile
-            // = [plane 0 | plane 1 | plane 2] x 64 B; lane pair (2 g, 2 g + 1) holds the 8 channels of chunk g of every plane.  Six chunks per pair: the even
-            // lane ends up with (k-tile 0: planes 0, 1; k-tile 1: plane 0), the odd lane with (k-tile 0: plane 2; k-tile 1: planes 1, 2) -- each store
-            // instruction then writes two whole 64-byte segments per pixel (four lanes x 16 B each)
+            // = [plane 0 | plane 1 | plane 2] x 64 B, so the slice is 384 contiguous bytes of the row.  A lane holds 4 channels (8 B) of each of the six
+            // (k-tile, plane) runs; the wave's 8 pixels are transposed through a private LDS image (6 x ds_write_b64, 3 x ds_read_b128 per lane) so that every
+            // store instruction writes whole 128-byte lines (8 lanes x 16 B per pixel).  Measured against the direct form (lane pairs exchange halves, two
+            // 64-byte runs per pixel and instruction): see docs/HISTORY.md, round 6.
             typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-            union Pk { bf16x4_t h; unsigned u[2]; };
+            union Pk { bf16x4_t h; uint2 u; };
             Pk a[3], b[3];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -723,20 +726,21 @@ __global__ __launch_bounds__(256) void k_conv2_lut_xcd(const unsigned* __restric
                 b3_split(va[q], x1, x2, x3); a[0].h[q] = x1; a[1].h[q] = x2; a[2].h[q] = x3;
                 b3_split(vb[q], x1, x2, x3); b[0].h[q] = x1; b[1].h[q] = x2; b[2].h[q] = x3;
             }
-            const bool even = (j & 1) == 0;
-            const unsigned give[6] = {even ? a[2].u[0] : a[0].u[0], even ? a[2].u[1] : a[0].u[1], even ? b[1].u[0] : a[1].u[0], even ? b[1].u[1] : a[1].u[1],
-                                      even ? b[2].u[0] : b[0].u[0], even ? b[2].u[1] : b[0].u[1]};
-            unsigned got[6];
+            unsigned char* img = c2l_b3_stage + (threadIdx.x >> 6) * (8 * C2L_B3_PIX) + ((threadIdx.x >> 3) & 7) * C2L_B3_PIX;     // this pixel's 384 B (+ 64 B pad: bank spread)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) got[q] = (unsigned)__shfl_xor((int)give[q], 1, 64);
-            v4u c0, c1, c2;      // a chunk = [even lane's 4 channels | odd lane's 4 channels]
-            c0[0] = even ? a[0].u[0] : got[0]; c0[1] = even ? a[0].u[1] : got[1]; c0[2] = even ? got[0] : a[2].u[0]; c0[3] = even ? got[1] : a[2].u[1];
-            c1[0] = even ? a[1].u[0] : got[2]; c1[1] = even ? a[1].u[1] : got[3]; c1[2] = even ? got[2] : b[1].u[0]; c1[3] = even ? got[3] : b[1].u[1];
-            c2[0] = even ? b[0].u[0] : got[4]; c2[1] = even ? b[0].u[1] : got[5]; c2[2] = even ? got[4] : b[2].u[0]; c2[3] = even ? got[5] : b[2].u[1];
-            unsigned char* base = reinterpret_cast<unsigned char*>(out) + (size_t)pixel * (C * 6) + slice * 384 + (j >> 1) * 16;
-            __builtin_nontemporal_store(c0, reinterpret_cast<v4u*>(base + (even ? 0 : 128)));             // k-tile 0: plane 0 | plane 2
-            __builtin_nontemporal_store(c1, reinterpret_cast<v4u*>(base + (even ? 64 : 192 + 64)));       // k-tile 0: plane 1 | k-tile 1: plane 1
-            __builtin_nontemporal_store(c2, reinterpret_cast<v4u*>(base + (even ? 192 : 192 + 128)));     // k-tile 1: plane 0 | plane 2
+            for (int p = 0; p < 3; ++p) {
+                *reinterpret_cast<uint2*>(img + p * 64 + j * 8) = a[p].u;
+                *reinterpret_cast<uint2*>(img + 192 + p * 64 + j * 8) = b[p].u;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's image is written (each wave owns its eight pixels: no block barrier)
+            __builtin_amdgcn_wave_barrier();
+            unsigned char* base = reinterpret_cast<unsigned char*>(out) + (size_t)pixel * (C * 6) + slice * 384 + j * 16;
+#pragma unroll
+            for (int k3 = 0; k3 < 3; ++k3) {
+                const v4u c = *reinterpret_cast<const v4u*>(img + k3 * 128 + j * 16);
+                __builtin_nontemporal_store(c, reinterpret_cast<v4u*>(base + k3 * 128));
+            }
+            __builtin_amdgcn_wave_barrier();
         } else {
             float* dst = reinterpret_cast<float*>(out) + (size_t)pixel * C + ca;
             __builtin_nontemporal_store(va, reinterpret_cast<f32x4*>(dst));

@@ -233,11 +233,13 @@ class SelfPlayEngine:
         return self.records()
 
 
-def preferred_batch_cap(board_size, num_games, channels=512):
+def preferred_batch_cap(board_size, num_games, channels=512, precision="f16x2"):
     """the batch cap at which conv3 -- the dominant launch -- is a whole number of rounds of 256 x 256 tiles on the chip's 256 CUs:
     the largest L <= num_games with ceil((n-2)^2 * L / 256) * (channels / 256) = 256 * r; 0 (no cap) when that is num_games itself or the
-    network does not use those tiles (4096 8x8 games, 512 filters: 3640 = 4.0 rounds; 6x6: no cap)"""
-    if channels % 256 or num_games < 1024:
+    network does not use those tiles (4096 8x8 games, 512 filters: 3640 = 4.0 rounds; 6x6: no cap).
+    precision "bf16x3": no cap -- k_gemm_b3's one tile is 128 x 256, on which 4096 leaves are 9.0 rounds of conv3 AND 4.0 of conv4 (3640: 8.0 and
+    3.55, paid as 4); measured 898 k against 886 k expansions/s with the cap (the free-running batches hold ~3900 leaves)"""
+    if channels % 256 or num_games < 1024 or precision == "bf16x3":
         return 0
     P, cols = (board_size - 2) ** 2, channels // 256
     rounds = (num_games * P // 256) * cols // 256

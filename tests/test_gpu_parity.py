@@ -541,9 +541,15 @@ def test_f16x2_range_guards_fail_loudly(oz):
     net.set_option(oz.NET_OPT_LOW_GUARD_LOG2, 12)
     with pytest.raises(oz.OzError):
         net.set_weights(w)                                       # default: the caller decides
-    with pytest.warns(UserWarning, match="continues in precision f32"):
+    with pytest.warns(UserWarning, match="THESE weights run in precision f32"):
         net.set_weights(w, on_refusal="f32")
-    assert net.precision == "f32" and oz.load().oz_net_get_precision(net._h) == 0
+    assert net.precision == "f32" and net.requested_precision == "f16x2" and net.f16x2_refusals == 1 and oz.load().oz_net_get_precision(net._h) == 0
+    pi, v = net.predict_batch(own, opp)
+    assert np.abs(pi.reshape(4, -1) - pi64).max() <= 1e-5 and np.abs(v - v64).max() <= 1e-5
+    # the fallback holds for THAT set of weights only: the next set_weights asks for f16x2 again -- accepted once the guard is back at its default
+    net.set_option(oz.NET_OPT_LOW_GUARD_LOG2, -17)
+    net.set_weights(w, on_refusal="f32")
+    assert net.precision == "f16x2" and net.f16x2_refusals == 1 and oz.load().oz_net_get_precision(net._h) == 1
     pi, v = net.predict_batch(own, opp)
     assert np.abs(pi.reshape(4, -1) - pi64).max() <= 1e-5 and np.abs(v - v64).max() <= 1e-5
 

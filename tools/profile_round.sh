@@ -3,7 +3,7 @@
 # command (secondary legs off), then the PMC passes, one counter group at a time (never combined with other trace domains).
 # Usage: tools/profile_round.sh [precision] [tag] [extra bench args]
 set -e
-PREC=${1:-f16x2}; TAG=${2:-r4}
+PREC=${1:-bf16x3}; TAG=${2:-r6}
 [ $# -ge 1 ] && shift
 [ $# -ge 1 ] && shift
 EXTRA="$*"

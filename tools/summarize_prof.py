@@ -44,7 +44,7 @@ def find(d, suffix):
     return hits[-1]
 
 
-PEAK = {"k_gemm_h2": 2500.0, "k_gemm_f32": 157.3}          # dense fp16 / fp32 matrix peaks, TFLOP/s (MI355X_MICROARCH.md)
+PEAK = {"k_gemm_h2": 2500.0, "k_gemm_b3": 2500.0, "k_gemm_f32": 157.3}          # dense fp16 / bf16 / fp32 matrix peaks, TFLOP/s (MI355X_MICROARCH.md)
 NET_ORDER_TABLES = ("conv3", "conv4", "fc1", "fc2")          # GEMM launches of one forward, in launch order, conv1 + conv2 from the tables
 NET_ORDER_GEMM = ("conv2", "conv3", "conv4", "fc1", "fc2")   # ... with conv2 as a GEMM (oz_net_set_tables 0 / 1)
 
@@ -115,7 +115,7 @@ def trace(d, out, header, leaves=LEAVES, last_n=0):
     with open(out, "w") as f:
         f.write(f"# {header}\n")
         f.write(f"# per (kernel, grid, layer) averages from the kernel trace; layer = position of the launch inside its forward (launch order); "
-                f"{leaves:g} leaves evaluated per launch in the timed window; TFLOP_per_s = ALGORITHMIC fp32 FLOP (precision f16x2 executes 3x that on "
+                f"{leaves:g} leaves evaluated per launch in the timed window; TFLOP_per_s = ALGORITHMIC fp32 FLOP (precision f16x2 executes 3x, bf16x3 6x that on "
                 "the matrix pipe); frac = TFLOP_per_s / the dense matrix peak of the kernel's arithmetic (2500 fp16, 157.3 fp32)\n")
         if last_n:
             f.write(f"# timed_* columns: the launches of the row inside the last {last_n} network batches of the run = bench.py's timed region (full batches); "
