@@ -161,6 +161,9 @@ int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int
  * instead of the one the forward picks for the call (fewest grid rounds x tile height).  All three add every output element's products in the
  * same order: bit-identical results -- test_conv3_tiles_bit_identical compares them.  Takes effect at the next forward. */
 #define OZ_NET_OPT_CONV3_TILE 8
+/* diagnostics switch, per network (default 1), precision f16x2: main loop of the 128 x 256 tile (conv3 of calls of <= 455 leaves, conv4 and fc1 of
+ * medium networks): 1 = one phase per k-tile on three LDS stages (round 6), 2 = the 2-phase loop on two stages (round 5).  Bit-identical results. */
+#define OZ_NET_OPT_LOW_LOOP_PHASES 9
 int oz_net_set_option(oz_net* net, int option, int value);
 int oz_net_self_check(oz_net* net, double* max_dpi, double* max_dv, int* positions);
 /* precision f16x2: the exponents chosen at the last commit.  which = 0 .. 4: per-channel activation exponents of the conv1, conv2, conv3,

@@ -180,8 +180,8 @@ class NNetWrapper(_NetHandle):
                 _lib.check(lib.oz_net_set_precision(self._h, PRECISION_MODES["f32"]))
                 self.precision = "f32"
                 _lib.check(lib.oz_net_commit(self._h))
-        hist.history["precision"] = self.precision          # the arithmetic these weights are evaluated in until the next set_weights
-        hist.history["f16x2_refusals"] = self.f16x2_refusals
+        hist.precision = self.precision                     # the arithmetic these weights are evaluated in until the next set_weights
+        hist.f16x2_refusals = self.f16x2_refusals           # (attributes, not history entries: Keras' history holds per-epoch number lists only)
         return hist
 
     # ---- checkpoints (Net/NNet.py:90-96): Keras HDF5 weight files, read and written by keras_h5.py (no h5py needed);

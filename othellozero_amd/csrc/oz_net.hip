@@ -498,7 +498,7 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
     if (!attr_set) {
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2BigPP::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2MidPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2MidPP::LDS));
-        OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2LowPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2LowPP::LDS));
+        OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2LowPP1>, hipFuncAttributeMaxDynamicSharedMemorySize, H2LowPP1::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small2::LDS));
         attr_set = true;
@@ -539,7 +539,7 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
         hipLaunchKernelGGL(k_gemm_h2<H2BigPP>, dim3(grid), dim3(H2BigPP::NT), H2BigPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
                            d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
     else if (low)
-        hipLaunchKernelGGL(k_gemm_h2<H2LowPP>, dim3(grid), dim3(H2LowPP::NT), H2LowPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
+        hipLaunchKernelGGL(k_gemm_h2<H2LowPP1>, dim3(grid), dim3(H2LowPP1::NT), H2LowPP1::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
                            d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
     else
         hipLaunchKernelGGL(k_gemm_h2<H2Small>, dim3(grid), dim3(H2Small::NT), H2Small::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
@@ -794,6 +794,7 @@ struct OnnNet : oz_net {
     int conv3_tile = 0;              // oz_net_set_option(OZ_NET_OPT_CONV3_TILE): 0 = the forward picks, 128 / 192 / 256 = that tile (bit-identity screen of the three)
     bool f32_std_tile = false;       // oz_net_set_option(OZ_NET_OPT_F32_STD_TILE): precision f32 never takes the 256 x 256 tile (bit-identity screen)
     bool simple_loop = false;        // oz_net_set_option(OZ_NET_OPT_SIMPLE_LOOP): one-barrier-per-k-tile loop for the 3x3 layers (race screen)
+    int low_loop_phases = 1;         // oz_net_set_option(OZ_NET_OPT_LOW_LOOP_PHASES): main loop of the 128 x 256 tile -- 1 (default) = one phase per k-tile, three LDS stages; 2 = round 5's 2-phase loop
     float* d_t2rows = nullptr;       // commit staging: one tap's T2 rows [OZ_LUT_PATTERNS][C] before the slice-major re-layout
     int last_conv3_rows = 0;         // row-tile height the last forward ran conv3 on (oz_net_get_info)
     int profiled_layer = 2;          // 2 = conv2 GEMM, 3 = conv3 GEMM (when conv2 runs as the table gather-sum)
@@ -1413,7 +1414,8 @@ struct OnnNet : oz_net {
         next_relu = h2o2;
         if (int rc = small ? launch_small<H2Small, H2Small2>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, 16)
                      : pp && conv3_big ? launch_gemm_h2<H2BigPP, 3>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
-                     : pp && conv3_low ? launch_gemm_h2<H2LowPP, 3>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
+                     : pp && conv3_low && low_loop_phases == 2 ? launch_gemm_h2<H2LowPP, 3>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
+                     : pp && conv3_low ? launch_gemm_h2<H2LowPP1, 3>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                      : pp  ? launch_gemm_h2<H2MidPP, 3>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)
                            : launch_gemm_h2<H2Mid>(act2, 2, act3, h2o2, d_count, max_count, n, n - 2, 0, C, 9, C, s, k3)) return rc;
         mark(2, false);
@@ -1422,7 +1424,8 @@ struct OnnNet : oz_net {
         next_low = low_of(3, guard);
         next_relu = h2o3;
         if (int rc = small ? launch_small<H2Small, H2Small2>(act3, 3, act4, h2o3, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, 16)
-                     : pp && conv4_low() ? launch_gemm_h2<H2LowPP, 4>(act3, 3, act4, h2o3, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
+                     : pp && conv4_low() && low_loop_phases == 2 ? launch_gemm_h2<H2LowPP, 4>(act3, 3, act4, h2o3, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
+                     : pp && conv4_low() ? launch_gemm_h2<H2LowPP1, 4>(act3, 3, act4, h2o3, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
                      : pp  ? launch_gemm_h2<H2BigPP, 4>(act3, 3, act4, h2o3, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)
                            : launch_gemm_h2<H2Big>(act3, 3, act4, h2o3, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, k4)) return rc;
         mark(3, false);
@@ -1439,7 +1442,8 @@ struct OnnNet : oz_net {
         const int kfc1 = sizing() >= 1024 ? 4 : 16;
         if (int rc = small ? launch_small<H2Small, H2Small2>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 16)
                      : (pp && sizing() >= 1024 && max_count >= 1024) ? launch_gemm_h2<H2BigPP, 5>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, 4)
-                     : pp ? launch_gemm_h2<H2LowPP, 5>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, kfc1)
+                     : pp && low_loop_phases == 2 ? launch_gemm_h2<H2LowPP, 5>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, kfc1)
+                     : pp ? launch_gemm_h2<H2LowPP1, 5>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, kfc1)
                           : launch_small<H2Small, H2Small2>(act4, 4, f1, h2o4, d_count, max_count, 1, 1, 0, F, 1, 1024, s, kfc1)) return rc;
         mark(4, false);
         if (calib == 4) { OZ_HIP(hipGetLastError()); return OZ_OK; }
@@ -2060,9 +2064,13 @@ OZ_API int oz_net_set_option(oz_net* net, int option, int value) {
     OZ_REQUIRE(o, "not an OthelloNN network");
     OZ_REQUIRE(option == OZ_NET_OPT_SIMPLE_LOOP || option == OZ_NET_OPT_ACT_TARGET_LOG2 || option == OZ_NET_OPT_LOW_GUARD_LOG2 ||
                option == OZ_NET_OPT_SELF_CHECK || option == OZ_NET_OPT_W_TARGET_LOG2 || option == OZ_NET_OPT_F32_STD_TILE ||
-               option == OZ_NET_OPT_LATENCY_SPLITS || option == OZ_NET_OPT_CONV3_TILE, "unknown network option %d", option);
+               option == OZ_NET_OPT_LATENCY_SPLITS || option == OZ_NET_OPT_CONV3_TILE || option == OZ_NET_OPT_LOW_LOOP_PHASES, "unknown network option %d", option);
     std::lock_guard<std::mutex> lk(o->mu);
     if (option == OZ_NET_OPT_SIMPLE_LOOP) o->simple_loop = value != 0;
+    else if (option == OZ_NET_OPT_LOW_LOOP_PHASES) {
+        OZ_REQUIRE(value == 1 || value == 2, "OZ_NET_OPT_LOW_LOOP_PHASES must be 1 or 2 (got %d)", value);
+        o->low_loop_phases = value;
+    }
     else if (option == OZ_NET_OPT_F32_STD_TILE) o->f32_std_tile = value != 0;
     else if (option == OZ_NET_OPT_CONV3_TILE) {
         OZ_REQUIRE(value == 0 || value == 128 || value == 192 || value == 256, "OZ_NET_OPT_CONV3_TILE must be 0, 128, 192 or 256 (got %d)", value);

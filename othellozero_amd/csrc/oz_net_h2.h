@@ -128,6 +128,11 @@ struct H2MidPP : H2Cfg<2, 4, 3, 2> { static constexpr bool PP = true; static con
 // 128 x 256: conv3 of a call whose rows fit one grid round on this tile but leave a third of the CUs idle on the 192-row one
 // (the arena's <= 512-leaf batches); same k order per output element as the other two: bit-identical
 struct H2LowPP : H2Cfg<2, 4, 2, 2> { static constexpr bool PP = true; static constexpr int PHASES = 2; };
+// the same tile with ONE phase per k-tile and three LDS stages (round 6): a 24-MFMA M section cannot cover an L section and its barrier (the 2-phase
+// loop on this tile runs at 0.63 of its MFMA time); here the whole k-tile is one M section of 48 MFMAs and one L section of 16 fragment reads + 6 DMA
+// instructions, i.e. half the barriers and half the fixed L-section costs per k-tile.  A tile is staged TWO k-tiles ahead (3 x 48 KB = 144 KB), so a
+// piece has a whole phase pair to land.  Same products in the same order per output element: bit-identical to every other tile.
+struct H2LowPP1 : H2Cfg<2, 4, 2, 2, 3> { static constexpr bool PP = true; static constexpr int PHASES = 1; };
 // conv2 with conv1 folded into a lookup: the conv1 + BN + ReLU output of a pixel depends only on the 3 x 3 neighbourhood
 // of the position (9 cells, each empty / own / opponent: 3^9 = 19683 patterns), so conv2's A rows are LDS-DMA'd straight
 // from a table of the 19683 possible rows (+ one zero row for taps outside the board) instead of from a conv1 output
@@ -959,7 +964,77 @@ __global__ __launch_bounds__(CF::NT, 2) void k_gemm_h2(const uint4* __restrict__
     const int swz = h2_swz(r16);                             // tile bases are multiples of 16 rows
     const int oh1 = ((2 * kg) ^ swz) * 16, oh2 = ((2 * kg + 1) ^ swz) * 16;
 
-    if constexpr (CF::PP && CF::PHASES == 2) {
+    if constexpr (CF::PP && CF::PHASES == 1) {
+        // ---- 1-phase ping-pong main loop (128 x 256 tile, three LDS stages): per k-tile t and wave
+        //   L: all fragments of tile t (8 + 8 ds_read_b128);  DMA [A, B of tile t + 2] (2 + 4 instructions);  vmcnt(6): this wave's pieces of tile t + 1 have
+        //      landed;  lgkmcnt(0);  barrier            M: 48 MFMAs (product-major);  barrier
+        // The two wave rows run one barrier apart (one in L while the other is in M).  Stage (t + 2) % 3 = stage (t - 1) % 3 was last read in L(t - 1),
+        // which every wave has closed (lgkmcnt(0) + barrier) before any wave enters L(t); a piece issued in L(t) is complete at the end of its wave's
+        // L(t + 1) and is read in L(t + 2), after a barrier both rows have passed.
+        static_assert(!CF::LUT && IA == 2 && IB == 4 && RI == 4 && RJ == 4 && CF::STAGES == 3, "1-phase ping-pong loop: 128 x 256 tile, 8 waves, 3 stages");
+        constexpr int KEEP = IA + IB;
+        auto put_tile = [&](int ktc, int slice, int tap, unsigned char* st) {
+            const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;                                      // tap / 3, tap % 3 for tap < 9
+            const long long toff = ((long long)dy * g.Hin + dx) * rowq + slice * 8;
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                const uint4* ga = ((amask[i] >> tap) & 1) ? in + (aidx[i] + toff) : zsrc;
+                __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(st + a_row0(i) * 128), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+                __builtin_amdgcn_global_load_lds((h2_gptr)(Wh + bidx[i] + ktc * 8), (h2_lptr)(st + CF::TILEA + b_row0(i) * 128), 16, 0, 0);
+        };
+        int k2 = kbeg + 2 < nk ? kbeg + 2 : nk - 1, slice2 = k2 / g.taps, tap2 = k2 - slice2 * g.taps;      // tile kt + 2 (past the end: the last again)
+        stage(kbeg, 0);
+        stage(kbeg + 1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory");      // tile kbeg has landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wm == 1) __builtin_amdgcn_s_barrier();           // stagger: wave row 1 is one barrier behind
+        f16x8 fa1[RI], fa2[RI], fb1[RJ], fb2[RJ];
+        int buf = 0;
+        for (int kt = kbeg; kt < nk; ++kt) {
+            unsigned char* la_cur = smem + (size_t)buf * CF::BUF;
+            const int buf2 = buf == 0 ? 2 : buf - 1;                         // (buf + 2) % 3
+            const unsigned char* At = la_cur + (wm * RI * 16 + r16) * 128;
+            const unsigned char* Bt = la_cur + CF::TILEA + (wn * RJ * 16 + r16) * 128;
+#pragma unroll
+            for (int i = 0; i < RI; ++i) {
+                fa1[i] = *reinterpret_cast<const f16x8*>(At + i * 16 * 128 + oh1);
+                fa2[i] = *reinterpret_cast<const f16x8*>(At + i * 16 * 128 + oh2);
+            }
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) {
+                fb1[j] = *reinterpret_cast<const f16x8*>(Bt + j * 16 * 128 + oh1);
+                fb2[j] = *reinterpret_cast<const f16x8*>(Bt + j * 16 * 128 + oh2);
+            }
+            put_tile(k2, slice2, tap2, smem + (size_t)buf2 * CF::BUF);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int i = 0; i < RI; ++i)
+#pragma unroll
+                    for (int j = 0; j < RJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? fa2[i] : fa1[i], p == 1 ? fb2[j] : fb1[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            buf = buf == 2 ? 0 : buf + 1;
+            if (k2 + 1 < nk) { ++k2; if (++tap2 == g.taps) { tap2 = 0; ++slice2; } }
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();           // re-align the two wave rows
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every piece has landed before the epilogue reuses the LDS
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else if constexpr (CF::PP && CF::PHASES == 2) {
         // ---- 2-phase ping-pong main loop (192 / 128 x 256 tiles): the same two wave rows half a phase apart, but a k-tile is two phases
         // instead of four -- (m0, m1) x n0, then (m0, m1) x n1 -- so the 12 / 18 MFMAs of a quadrant, too short to cover an L section and
         // its two barriers (the 4-phase loop on these tiles ran at 0.63 / 0.78 of its MFMA time), become 24 / 36:

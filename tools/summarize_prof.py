@@ -181,7 +181,7 @@ def tree(src, out, games):
     with open(src) as f:
         for r in csv.DictReader(l for l in f if not l.startswith("#")):
             vals[r["kernel"]][r["counter"]] = float(r["avg_per_launch"])
-    j = {"round": 5, "simulations_per_launch": float(games), "algorithmic_bytes_per_sim": 1300, "source": src, "kernels": {}}
+    j = {"round": 6, "simulations_per_launch": float(games), "algorithmic_bytes_per_sim": 1300, "source": src, "kernels": {}}
     tot_raw = tot_w = 0.0
     # (k_backup_select = expand + backup of the previous simulation fused with the descent: 99 of the 100 launches of a round;
     #  k_select / k_expand_backup = the first descent and the closing backup of a round, one launch each)
@@ -214,7 +214,7 @@ def traffic(src, out, precision, kernel_sub, grid, layer="conv2", leaves=LEAVES)
     alg = {"conv2": 64 * 2048 + 64 * 2048 + 9 * 512 * 512 * 4 / leaves, "conv3": 64 * 2048 + 36 * 2048 + 9 * 512 * 512 * 4 / leaves}[layer]
     if precision == "f32" and layer == "conv2":
         alg = 262144.0 + 18 * 512 * 512 * 4 / LEAVES           # as first committed: the transposed copy of the kernel counted too
-    j = {"round": 5, "precision": precision, "kernel": f"{kernel_sub} {layer}", "leaves_per_launch": leaves,
+    j = {"round": 6, "precision": precision, "kernel": f"{kernel_sub} {layer}", "leaves_per_launch": leaves,
          "fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
          "hbm_bytes_per_leaf": (fetch + write) / leaves,
          "algorithmic_bytes_per_leaf": alg,
