@@ -448,7 +448,7 @@ def run_rank(args, rank, world, local_rank, t_proc):
             "whole_net_tflops_rank0": d["leaves_evaluated"] * flop_exec / max(nn_ms * 1e-3, 1e-9) / 1e12,
             "flop_per_expansion": {"reference_network": flop_ref, "executed": flop_exec,
                                    "note": "executed < reference when conv1 + conv2 are evaluated as pattern-table lookups (exact refactoring, no GEMM)"},
-            "roofline": dict(roofline(args.precision, layer, achieved, dom_ms, dom_launches, d["leaves_evaluated"], n, args.channels,
+            "roofline": dict(roofline(net.arithmetic(), layer, achieved, dom_ms, dom_launches, d["leaves_evaluated"], n, args.channels,
                                       conv3_rows=conv3_tile_rows(n, cap_main or G, args.channels)),
                              all_launches={"launches": int(dom_all_launches), "avg_launch_ms": dom_all_ms / max(dom_all_launches, 1),
                                            "leaves_per_launch": s1["leaves_evaluated"] / max(dom_all_launches, 1),
@@ -458,8 +458,8 @@ def run_rank(args, rank, world, local_rank, t_proc):
             # the tree / rules side is latency-bound integer work, ~1.3 KB of algorithmic HBM bytes per simulation
             "tree_side_hbm": tree_side(sims_all / dt),
         }
-        out["dtype"] = DTYPE_LABEL[args.precision]
-        out["dtype_detail"] = DTYPE_DETAIL[args.precision]
+        out["dtype"] = DTYPE_LABEL[net.arithmetic()]
+        out["dtype_detail"] = DTYPE_DETAIL[net.arithmetic()]
         out["roofline"]["leaves_per_launch"] = d["leaves_evaluated"] / max(dom_launches, 1)
         # SURVEY 8(d)'s whole-path figure: expansions/s x FLOP per expansion / the matrix peak of the arithmetic the timed region ran in.  On the FLOP the GPU
         # executes it is a fraction of the roof; on the reference network's FLOP it can exceed 1 by construction (conv1 + conv2 are exact table lookups)
@@ -481,8 +481,8 @@ def run_rank(args, rank, world, local_rank, t_proc):
                         "clock_ghz_at_back_to_back_issue": cal["f16"]["clock_ghz"], "ms": cal["f16"]["ms"], "nominal_peak_tflops": 2500.0},
                 "f32": {"instruction": "v_mfma_f32_32x32x2_f32", "sustained_tflops": cal["f32"]["tflops"],
                         "clock_ghz_at_back_to_back_issue": cal["f32"]["clock_ghz"], "ms": cal["f32"]["ms"], "nominal_peak_tflops": 157.3},
-                "dominant_kernel_share_of_sustained": ({"f32": 1.0, "f16x2": 3.0, "bf16x3": 6.0}[args.precision] * achieved /
-                                                       max(cal["f32" if args.precision == "f32" else "f16"]["tflops"], 1e-9)),
+                "dominant_kernel_share_of_sustained": ({"f32": 1.0, "f16x2": 3.0, "bf16x3": 6.0}[net.arithmetic()] * achieved /
+                                                       max(cal["f32" if net.arithmetic() == "f32" else "f16"]["tflops"], 1e-9)),
                 "note": "oz_selftest_mfma_rate: one block per CU, one wave per SIMD, four independent accumulators back to back, ~50 ms each, rank 0, right "
                         "after the timed region; roofline.peak stays the nominal figure of MI355X_MICROARCH.md"}
         except Exception as e:                                   # noqa: BLE001 -- a diagnostic, never a reason to lose the line

@@ -663,6 +663,8 @@ def compact_line(out, limit=6000):
     line["flop_per_expansion"] = {"reference_network": fe["reference_network"], "executed": fe["executed"]}
     line["whole_path_frac"] = _sig(out["whole_path"]["frac_executed_flop"])
     line["whole_path_frac_reference_flop"] = _sig(out["whole_path"]["frac_reference_flop"])
+    if out["roofline"]["peak"] != PEAK_F32_MATRIX_TFLOPS:      # a split mode on the 16-bit pipes: the same rate against the fp32 matrix roof it is there to beat
+        line["whole_path_vs_fp32_matrix_peak"] = _sig(out["whole_path"]["frac_executed_flop"] * out["roofline"]["peak"] / PEAK_F32_MATRIX_TFLOPS)
     line["whole_path_note"] = "value x FLOP / roofline.peak; reference-FLOP figure may exceed 1 by construction (conv1 + conv2 are exact table lookups, no FLOP executed)"
     # the other precisions of the same workload, same run (value_<mode>, roofline_<mode>{frac, avg_launch_ms, peak, achieved}, dtype_<mode>)
     for p in PRECISIONS:

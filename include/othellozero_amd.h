@@ -180,6 +180,9 @@ int oz_net_get_scaling(oz_net* net, int which, int32_t* out, int64_t nelem);
  * last oz_net_commit -- 0 for a healthy network.  With OZ_NET_OPT_SELF_CHECK = 1 such a commit fails; with 2 (measure only) it succeeds and this
  * says what happened.  The device flag is cleared by the commit that reported it. */
 #define OZ_NET_INFO_SELF_CHECK_GUARD 2
+/* the arithmetic the network's GEMM layers really run in: the precision mode, except that a precision-2 (bf16x3) network of max_batch < 128 reports 0 --
+ * its layers are the exact-fp32 latency kernels (see oz_net_set_precision) */
+#define OZ_NET_INFO_ARITHMETIC 3
 int oz_net_get_info(oz_net* net, int what, int* value);
 
 /* ------------------------------------------------------------------ search

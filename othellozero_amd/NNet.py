@@ -297,6 +297,12 @@ class NNetWrapper(_NetHandle):
         _lib.check(_lib.load().oz_net_get_info(self._h, _lib.NET_INFO_CONV3_TILE_ROWS, C.byref(v)))
         return v.value
 
+    def arithmetic(self):
+        """the arithmetic the GEMM layers really run in: self.precision, except "f32" for a bf16x3 network of max_batch < 128 (latency kernels)"""
+        v = C.c_int()
+        _lib.check(_lib.load().oz_net_get_info(self._h, _lib.NET_INFO_ARITHMETIC, C.byref(v)))
+        return {0: "f32", 1: "f16x2", 2: "bf16x3"}[v.value]
+
     def profiled_layer(self):
         """which launch profile_read() timed: 2 = the conv2 GEMM, 3 = the conv3 GEMM (f16x2: conv1 + conv2 are a table gather-sum)"""
         layer = C.c_int()

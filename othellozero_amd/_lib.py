@@ -18,7 +18,7 @@ DEDUP_DEFAULT, DEDUP_ON, DEDUP_OFF = 0, 1, 2                                    
 NET_OPT_SIMPLE_LOOP, NET_OPT_ACT_TARGET_LOG2, NET_OPT_LOW_GUARD_LOG2, NET_OPT_SELF_CHECK, NET_OPT_W_TARGET_LOG2, NET_OPT_F32_STD_TILE, NET_OPT_LATENCY_SPLITS = 1, 2, 3, 4, 5, 6, 7      # oz_net_set_option
 NET_OPT_CONV3_TILE = 8
 NET_OPT_LOW_LOOP_PHASES = 9
-NET_INFO_CONV3_TILE_ROWS, NET_INFO_SELF_CHECK_GUARD = 1, 2                                                          # oz_net_get_info
+NET_INFO_CONV3_TILE_ROWS, NET_INFO_SELF_CHECK_GUARD, NET_INFO_ARITHMETIC = 1, 2, 3                                                          # oz_net_get_info
 LEAF_IDLE, LEAF_TERMINAL, LEAF_EVAL = 0, 1, 2
 VT_INT, VT_F32, VT_F64 = 0, 1, 2
 NET_KERNELS = ("input", "conv2", "conv3", "conv4", "fc1", "fc2", "heads")           # OZ_NET_KERNELS slots

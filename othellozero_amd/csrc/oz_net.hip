@@ -498,7 +498,7 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
     if (!attr_set) {
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2BigPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2BigPP::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2MidPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2MidPP::LDS));
-        OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2LowPP1>, hipFuncAttributeMaxDynamicSharedMemorySize, H2LowPP1::LDS));
+        OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2LowPP>, hipFuncAttributeMaxDynamicSharedMemorySize, H2LowPP::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small::LDS));
         OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_h2<H2Small2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2Small2::LDS));
         attr_set = true;
@@ -539,7 +539,9 @@ int oz_gemm_h2_launch(const void* in_h2, const void* Wh, const float* scale, con
         hipLaunchKernelGGL(k_gemm_h2<H2BigPP>, dim3(grid), dim3(H2BigPP::NT), H2BigPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
                            d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
     else if (low)
-        hipLaunchKernelGGL(k_gemm_h2<H2LowPP1>, dim3(grid), dim3(H2LowPP1::NT), H2LowPP1::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
+        // (round 6: the 1-phase / 3-stage loop of this tile, H2LowPP1, measured SLOWER here -- 1.00 against 0.93-0.96 ms per step at the reference's batch: the
+        //  trainer's k-slices are 8 .. 36 tiles and the deeper prologue, two tiles staged before the first MFMA, costs more than the halved barriers return)
+        hipLaunchKernelGGL(k_gemm_h2<H2LowPP>, dim3(grid), dim3(H2LowPP::NT), H2LowPP::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
                            d_count, g, num_mt, (const uint4*)zero_line, flag, (const unsigned*)nullptr);
     else
         hipLaunchKernelGGL(k_gemm_h2<H2Small>, dim3(grid), dim3(H2Small::NT), H2Small::LDS, s, (const uint4*)in_h2, (const uint4*)Wh, scale, shift, dst,
@@ -2121,9 +2123,9 @@ OZ_API int oz_net_get_scaling(oz_net* net, int which, int32_t* out, int64_t nele
 OZ_API int oz_net_get_info(oz_net* net, int what, int* value) {
     OnnNet* o = as_onn(net);
     OZ_REQUIRE(o && value, "not an OthelloNN network / null argument");
-    OZ_REQUIRE(what == OZ_NET_INFO_CONV3_TILE_ROWS || what == OZ_NET_INFO_SELF_CHECK_GUARD, "unknown network info %d", what);
+    OZ_REQUIRE(what == OZ_NET_INFO_CONV3_TILE_ROWS || what == OZ_NET_INFO_SELF_CHECK_GUARD || what == OZ_NET_INFO_ARITHMETIC, "unknown network info %d", what);
     std::lock_guard<std::mutex> lk(o->mu);
-    *value = what == OZ_NET_INFO_CONV3_TILE_ROWS ? o->last_conv3_rows : o->sc_guard;
+    *value = what == OZ_NET_INFO_CONV3_TILE_ROWS ? o->last_conv3_rows : what == OZ_NET_INFO_ARITHMETIC ? (o->precision == 2 && !o->use_b3() ? 0 : o->precision) : o->sc_guard;
     return OZ_OK;
 }
 
