@@ -457,3 +457,40 @@ def test_library_and_pytorch_share_one_hip_runtime():
         assert r.returncode == 0, r.stderr[-800:]
         libs = eval(r.stdout.strip().splitlines()[-1])
         assert len(libs) == 1, (head, libs)
+
+
+def test_bench_line_fits_the_drivers_tail_at_any_rank_count():
+    """bench_legs.compact_line on the committed round-6 record (profiles/r6_bench_detail_driver_style.json), also blown up to 8 ranks with every
+    optional leg present: strict JSON, contract keys first, < 6000 bytes (the driver keeps an 8 KB tail; round 5's 33 KB line was unparsed)"""
+    import copy
+    import json
+    import bench_legs
+    det = json.load(open(os.path.join(ROOT, "profiles", "r6_bench_detail_driver_style.json")))
+    for world in (1, 8):
+        d = copy.deepcopy(det)
+        d["n_gpus"] = d["rccl_ranks"] = world
+        d["per_rank_records"] = [81234 + r for r in range(world)]
+        d["per_rank"]["ms_per_step"] = [423.0320192 + r for r in range(world)]
+        d["detail_file"] = "/some/long/scratch/path/of/the/driver/box/repo/bench_detail.json"
+        text = bench_legs.compact_line(d)
+        assert len(text) < 6000, len(text)
+
+        def no_constants(name):
+            raise ValueError(name)
+        line = json.loads(text, parse_constant=no_constants)
+        keys = list(line)
+        assert keys[:15] == ["metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                             "dtype", "data", "config", "roofline"]
+        assert keys[15] == "cpu_baseline" and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+        rf = line["roofline"]
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["bound"] == "mfma" and rf["traffic"] > rf["algorithmic_bytes_per_launch"]
+        assert line["value"] == det["value"] and line["dtype"] == "f32 (3xbf16 split)" and line["roofline_f32"]["peak"] == 157.3
+        assert len(line["per_rank_records"]) == world and "kernels" not in line and "config5" not in line and "precisions" not in line
+
+
+def test_precision_modes_and_batch_cap():
+    from othellozero_amd.NNet import PRECISION_MODES
+    from othellozero_amd.training import preferred_batch_cap
+    assert PRECISION_MODES == {"f32": 0, "f16x2": 1, "bf16x3": 2}
+    # bf16x3's one tile is 128 x 256: 4096 leaves are whole rounds of conv3 AND conv4 -> no cap; the other precisions cap at 4.0 rounds of 256-row tiles
+    assert preferred_batch_cap(8, 4096, 512, "bf16x3") == 0 and preferred_batch_cap(8, 4096, 512, "f32") == 3640 and preferred_batch_cap(8, 4096, 512) == 3640

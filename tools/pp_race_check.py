@@ -45,6 +45,27 @@ for n, C, B, reps, cin in CASES:
             bad.append((n, C, B, cin, rep, GROUP_B[1]))
         gap = max(gap, float(np.abs(ref_a[0] - ref_b[0]).max()), float(np.abs(ref_a[1] - ref_b[1]).max()))
     del net
+# precision bf16x3 (k_gemm_b3: one tile, one loop -- no alternative schedule to compare with): the SAME call repeated must reproduce its own bits, and a
+# position's (pi, v) must not depend on where it sits in the batch; an LDS-DMA visibility race in the 2-phase schedule would show up as a rare mismatch
+b3_compared = 0
+for n, C, B, reps in ((8, 512, 4096, 10), (8, 512, 3640, 10), (8, 256, 777, 10), (6, 512, 4096, 10), (8, 512, 130, 10)):
+    net = NNetWrapper((n, n), num_channels_1=C, max_batch=max(B, 128), precision="bf16x3", weights=init_weights(n, seed=4, channels=C, randomize_all=True))
+    rs = np.random.RandomState(n * 77 + B)
+    valid = np.uint64(sum(1 << (r * 8 + c) for r in range(n) for c in range(n)))
+    own = rs.randint(0, 2**63, size=B, dtype=np.uint64) & valid
+    opp = rs.randint(0, 2**63, size=B, dtype=np.uint64) & valid & ~own
+    ref = net.predict_batch(own, opp)
+    for rep in range(reps):
+        perm = rs.permutation(B)
+        a = net.predict_batch(own, opp)
+        b = net.predict_batch(own[perm], opp[perm])
+        b3_compared += 2
+        if not (np.array_equal(a[0], ref[0]) and np.array_equal(a[1], ref[1])):
+            bad.append((n, C, B, "bf16x3", rep, "repeat"))
+        if not (np.array_equal(b[0], ref[0][perm]) and np.array_equal(b[1], ref[1][perm])):
+            bad.append((n, C, B, "bf16x3", rep, "permuted"))
+    del net
+print(f"bf16x3: {b3_compared} repeated / permuted calls over 5 networks compared with their first call")
 print(f"{compared} comparisons over {len(CASES)} networks x {len(GROUP_A) + len(GROUP_B)} loop / table configurations, {len(bad)} differ", bad[:5])
 print(f"gather-sum vs GEMM conv2: max |difference| of (pi, v) = {gap:.3g}")
 sys.exit(1 if bad or gap > 2e-6 else 0)
