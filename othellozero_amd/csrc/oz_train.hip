@@ -715,6 +715,8 @@ __global__ __launch_bounds__(256) void k_t_dz_to_h2(const float* __restrict__ dz
 // fp16 products per fp32 product (x2*z1 + x1*z2 + x1*z1), 2^-ez folded into the epilogue.  Octet ranges split over blockIdx.y until every CU
 // has a block (raw slabs + k_t_sum_partials, fixed order).  Rows of fewer than 8 real pixels (conv3: 6, conv4: 4) pay for the zero columns
 // (+24 % MFMA work over the three layers) -- the price of one uniform step shape.
+#define WH_MIN_BATCH 32     // batches from here on take this kernel (round 6: was 128; at the reference's batch of 32 the fp32 weight gradients on the second stream -- 52 + 82 +
+                            // 151 us -- WERE the critical path of the backward pass)
 #define WH_CI 64
 #define WH_CO 128
 #define WH_XW 10           // pixel slots of an X row (columns >= Hin + 2 pad hold zeros)
@@ -1338,7 +1340,7 @@ static int t_forward_backward_async(oz_trainer* t, int B) {
             }
             // (measured on one MI355X, 8x8 / 512 filters: the board-resident kernel wins from batch 256 on -- 6.01 vs 6.36 ms per step, 17.0 vs
             //  19.9 at 1024 -- and loses 3-4 % at 32 .. 128, where the tap-per-block kernel's 144 x 4 short blocks finish sooner)
-            if (taps[l] == 9 && t->h2 && have_dzmax && l >= 1 && B >= 128 && Cin[l] % WH_CI == 0 && Cc % WH_CO == 0) {
+            if (taps[l] == 9 && t->h2 && have_dzmax && l >= 1 && B >= WH_MIN_BATCH && Cin[l] % WH_CI == 0 && Cc % WH_CO == 0) {
                 // f16x2: octet images of a[l - 1] and of the scaled dz[l], then the MFMA kernel on the fp16 matrix cores (three products per fp32 product)
                 const int noct = (B + 7) / 8, XR = t->Hout[l] + 2;
                 const int tiles = (Cin[l] / WH_CI) * (Cc / WH_CO);
