@@ -487,6 +487,48 @@ def test_network_vs_float64_oracle(oz, n, channels, batch, precision):
     assert np.array_equal(pc, pi[:4]) and np.array_equal(vc, v[:4])
 
 
+@pytest.mark.parametrize("n,channels,batch,network", [(8, 256, 37, "ONN"), (6, 256, 200, "ONN"), (8, 512, 130, "ONN"), (6, 512, 9, "BNN"), (8, 768, 21, "ONN")])
+def test_bf16x3_network_vs_float64_oracle(oz, n, channels, batch, network):
+    """precision bf16x3 (every fp32 value as three bf16 planes, six MFMA products; oz_net_b3.h) on networks of max_batch >= 128 -- the k_gemm_b3 path --
+    at channel counts other than the bench's (256 / 768: the thread-per-pixel gather with its own b3 output, one / three column tiles), both boards,
+    both network types, every parameter kind random: pi, v within 1e-5 of the float64 oracle AND within 2e-6 of the exact-fp32 kernels (fp32-class:
+    the two differ by rounding only); a position's bits do not depend on its place in the batch, on the size of the call or on the tables mode's GEMM
+    twin being built in another object; a max_batch = 64 network of the same precision runs the exact-fp32 latency kernels and says so"""
+    from othellozero_amd.NNet import NNetWrapper, NeuralNets
+    from othellozero_amd.weights import init_weights
+    cin = 2 if network == "ONN" else 1
+    w = init_weights(n, seed=13, channels=channels, randomize_all=True, in_channels=cin)
+    for i in (36, 38):
+        w[i] = w[i] * 4.0
+    kind = NeuralNets.ONN if cin == 2 else NeuralNets.BNN
+    net = NNetWrapper((n, n), num_channels_1=channels, max_batch=160, weights=w, precision="bf16x3", network=kind)
+    assert net.arithmetic() == "bf16x3"
+    own, opp = _boards(n, batch, seed=n + channels)
+    pi, v = net.predict_batch(own, opp)                        # batch > max_batch exercises the chunking too
+    assert net.conv3_tile_rows() == 128
+    pi64, v64 = nn_numpy.forward(w, own, opp, n)
+    assert np.abs(pi.reshape(batch, -1) - pi64).max() <= 1e-5 and np.abs(v - v64).max() <= 1e-5
+    assert np.abs(pi.reshape(batch, -1).sum(axis=1) - 1).max() < 1e-5
+    exact = NNetWrapper((n, n), num_channels_1=channels, max_batch=160, weights=w, precision="f32", network=kind)
+    pe, ve = exact.predict_batch(own, opp)
+    assert np.abs(pi - pe).max() <= 2e-6 and np.abs(v - ve).max() <= 2e-6
+    perm = np.random.RandomState(0).permutation(batch)
+    pi2, v2 = net.predict_batch(own[perm], opp[perm])
+    assert np.array_equal(pi2, pi[perm]) and np.array_equal(v2, v[perm])
+    p1, v1 = net.predict_batch(own[3:4], opp[3:4])
+    assert np.array_equal(p1[0], pi[3]) and v1[0] == v[3]
+    small = NNetWrapper((n, n), num_channels_1=channels, max_batch=64, weights=w, precision="bf16x3", network=kind)
+    assert small.arithmetic() == "f32"
+    ps, vs = small.predict_batch(own[:8], opp[:8])
+    assert np.abs(ps - pi[:8]).max() <= 2e-6 and np.abs(vs - v[:8]).max() <= 2e-6
+
+
+def test_bf16x3_needs_channels_multiple_of_256(oz):
+    from othellozero_amd.NNet import NNetWrapper
+    with pytest.raises(oz.OzError):
+        NNetWrapper((8, 8), num_channels_1=128, precision="bf16x3")
+
+
 def test_f16x2_range_guards_fail_loudly(oz):
     """precision f16x2 must refuse (not silently mis-compute) positions whose activations leave the window the 2 x fp16 split carries:
     HIGH side (an activation above 65504) and LOW side (a pixel row whose largest scaled activation is non-zero and below the threshold).
