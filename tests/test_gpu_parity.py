@@ -491,7 +491,7 @@ def test_network_vs_float64_oracle(oz, n, channels, batch, precision):
 def test_bf16x3_network_vs_float64_oracle(oz, n, channels, batch, network):
     """precision bf16x3 (every fp32 value as three bf16 planes, six MFMA products; oz_net_b3.h) on networks of max_batch >= 128 -- the k_gemm_b3 path --
     at channel counts other than the bench's (256 / 768: the thread-per-pixel gather with its own b3 output, one / three column tiles), both boards,
-    both network types, every parameter kind random: pi, v within 1e-5 of the float64 oracle AND within 2e-6 of the exact-fp32 kernels (fp32-class:
+    both network types, every parameter kind random: pi, v within 1e-5 of the float64 oracle AND within 4e-6 of the exact-fp32 kernels (fp32-class:
     the two differ by rounding only); a position's bits do not depend on its place in the batch, on the size of the call or on the tables mode's GEMM
     twin being built in another object; a max_batch = 64 network of the same precision runs the exact-fp32 latency kernels and says so"""
     from othellozero_amd.NNet import NNetWrapper, NeuralNets
@@ -511,7 +511,9 @@ def test_bf16x3_network_vs_float64_oracle(oz, n, channels, batch, network):
     assert np.abs(pi.reshape(batch, -1).sum(axis=1) - 1).max() < 1e-5
     exact = NNetWrapper((n, n), num_channels_1=channels, max_batch=160, weights=w, precision="f32", network=kind)
     pe, ve = exact.predict_batch(own, opp)
-    assert np.abs(pi - pe).max() <= 2e-6 and np.abs(v - ve).max() <= 2e-6
+    # two differently ROUNDED fp32 evaluations of the same network (each ~1e-6 from float64 on this all-parameters-random, heads x 4 network)
+    assert np.abs(pi - pe).max() <= 4e-6 and np.abs(v - ve).max() <= 4e-6
+    assert abs(np.abs(v - v64).max() - np.abs(ve - v64).max()) <= 2e-6        # ... and neither is further from float64 than the other by more than rounding
     perm = np.random.RandomState(0).permutation(batch)
     pi2, v2 = net.predict_batch(own[perm], opp[perm])
     assert np.array_equal(pi2, pi[perm]) and np.array_equal(v2, v[perm])
@@ -520,7 +522,7 @@ def test_bf16x3_network_vs_float64_oracle(oz, n, channels, batch, network):
     small = NNetWrapper((n, n), num_channels_1=channels, max_batch=64, weights=w, precision="bf16x3", network=kind)
     assert small.arithmetic() == "f32"
     ps, vs = small.predict_batch(own[:8], opp[:8])
-    assert np.abs(ps - pi[:8]).max() <= 2e-6 and np.abs(vs - v[:8]).max() <= 2e-6
+    assert np.abs(ps - pi[:8]).max() <= 4e-6 and np.abs(vs - v[:8]).max() <= 4e-6
 
 
 def test_bf16x3_needs_channels_multiple_of_256(oz):
