@@ -475,14 +475,17 @@ def run_rank(args, rank, world, local_rank, t_proc):
         # instruction the two precisions run on.  The GEMM kernels' rate moves with it from box to box (and with a power cap), so a reader can
         # tell a slow box from a regression: roofline.achieved x 3 / device_calibration.f16.tflops is the kernel's share of what the pipe gives HERE.
         try:
-            cal = {k: _lib.mfma_rate(k, 50.0) for k in ("f16", "f32")}
+            cal = {k: _lib.mfma_rate(k, 50.0) for k in ("f16", "bf16", "f32")}
             out["device_calibration"] = {
                 "f16": {"instruction": "v_mfma_f32_16x16x32_f16, operands with busy mantissas in [2^-3, 2^-2)", "sustained_tflops": cal["f16"]["tflops"],
                         "clock_ghz_at_back_to_back_issue": cal["f16"]["clock_ghz"], "ms": cal["f16"]["ms"], "nominal_peak_tflops": 2500.0},
+                "bf16": {"instruction": "v_mfma_f32_16x16x32_bf16, operands with random 7-bit mantissas in [2^-3, 2^-2) (what the planes of bf16x3 hold)",
+                         "sustained_tflops": cal["bf16"]["tflops"], "clock_ghz_at_back_to_back_issue": cal["bf16"]["clock_ghz"], "ms": cal["bf16"]["ms"],
+                         "nominal_peak_tflops": 2500.0},
                 "f32": {"instruction": "v_mfma_f32_32x32x2_f32", "sustained_tflops": cal["f32"]["tflops"],
                         "clock_ghz_at_back_to_back_issue": cal["f32"]["clock_ghz"], "ms": cal["f32"]["ms"], "nominal_peak_tflops": 157.3},
                 "dominant_kernel_share_of_sustained": ({"f32": 1.0, "f16x2": 3.0, "bf16x3": 6.0}[net.arithmetic()] * achieved /
-                                                       max(cal["f32" if net.arithmetic() == "f32" else "f16"]["tflops"], 1e-9)),
+                                                       max(cal[{"f32": "f32", "f16x2": "f16", "bf16x3": "bf16"}[net.arithmetic()]]["tflops"], 1e-9)),
                 "note": "oz_selftest_mfma_rate: one block per CU, one wave per SIMD, four independent accumulators back to back, ~50 ms each, rank 0, right "
                         "after the timed region; roofline.peak stays the nominal figure of MI355X_MICROARCH.md"}
         except Exception as e:                                   # noqa: BLE001 -- a diagnostic, never a reason to lose the line

@@ -681,6 +681,7 @@ def compact_line(out, limit=6000):
     cal = out.get("device_calibration") or {}
     if "f16" in cal:
         line["device_calibration"] = {"f16_sustained_tflops": _sig(cal["f16"]["sustained_tflops"], 4), "f32_sustained_tflops": _sig(cal["f32"]["sustained_tflops"], 4),
+                                      "bf16_sustained_tflops": _sig((cal.get("bf16") or {}).get("sustained_tflops"), 4),
                                       "dominant_kernel_share_of_sustained": _sig(cal["dominant_kernel_share_of_sustained"], 4)}
     if "config4" in out:
         line["config4_value"] = _sig(out["config4"]["value"])

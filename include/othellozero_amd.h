@@ -164,6 +164,9 @@ int oz_net_eval_cache_stats(oz_net* net, int64_t* entries, int64_t* lookups, int
 /* diagnostics switch, per network (default 1), precision f16x2: main loop of the 128 x 256 tile (conv3 of calls of <= 455 leaves, conv4 and fc1 of
  * medium networks): 1 = one phase per k-tile on three LDS stages (round 6), 2 = the 2-phase loop on two stages (round 5).  Bit-identical results. */
 #define OZ_NET_OPT_LOW_LOOP_PHASES 9
+/* diagnostics switch, per network (default 0), precision bf16x3: the tile of conv3 / conv4 -- 0 = the launcher picks (256 x 256 where the network's
+ * capacity fills the chip on it, else 128 x 256), 128 / 256 = that tile.  Bit-identical results: the screen of the two tiles. */
+#define OZ_NET_OPT_B3_TILE 10
 int oz_net_set_option(oz_net* net, int option, int value);
 int oz_net_self_check(oz_net* net, double* max_dpi, double* max_dv, int* positions);
 /* precision f16x2: the exponents chosen at the last commit.  which = 0 .. 4: per-channel activation exponents of the conv1, conv2, conv3,
@@ -421,10 +424,14 @@ int oz_selftest_arith(const double* a, const double* b, int count, double* sqrt_
                       float* fchain);
 /* what the matrix pipe of the current device sustains right now: a pure-MFMA loop (no LDS, no loads, no barriers, one wave per SIMD) for
  * about target_ms milliseconds.  kind 0 = v_mfma_f32_32x32x2_f32 (precision f32's instruction), 1 = v_mfma_f32_16x16x32_f16 on operands with
- * busy mantissas (precision f16x2's).  tflops = issued FLOP / HIP-event time; clock_ghz (optional) = the clock at which back-to-back issue
+ * busy mantissas (precision f16x2's), 2 = v_mfma_f32_16x16x32_bf16 on operands with random 7-bit mantissas (precision bf16x3's planes).  tflops = issued FLOP / HIP-event time; clock_ghz (optional) = the clock at which back-to-back issue
  * gives that rate; ms_measured (optional).  bench.py reports both kinds as `device_calibration`: the number that separates a slow or
  * power-capped box from a regression of the kernels. */
 int oz_selftest_mfma_rate(int kind, double target_ms, double* tflops, double* clock_ghz, double* ms_measured);
+/* the three-plane split of precision bf16x3 as the device evaluates it (oz_net_b3.h, b3_split): for x[i], planes[3 i .. 3 i + 2] (optional) = (b1, b2, b3)
+ * widened to fp32 and sum[i] = (b1 + b2) + b3 in fp32 -- equal to x[i] bit for bit for every finite x with |x| >= 2^-100 (the claim the mode rests on;
+ * tests/test_gpu_parity.py::test_bf16x3_split_is_exact).  Host buffers; count <= 2^28. */
+int oz_selftest_b3_split(const float* x, int64_t count, float* planes, float* sum);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ DEDUP_DEFAULT, DEDUP_ON, DEDUP_OFF = 0, 1, 2                                    
 NET_OPT_SIMPLE_LOOP, NET_OPT_ACT_TARGET_LOG2, NET_OPT_LOW_GUARD_LOG2, NET_OPT_SELF_CHECK, NET_OPT_W_TARGET_LOG2, NET_OPT_F32_STD_TILE, NET_OPT_LATENCY_SPLITS = 1, 2, 3, 4, 5, 6, 7      # oz_net_set_option
 NET_OPT_CONV3_TILE = 8
 NET_OPT_LOW_LOOP_PHASES = 9
+NET_OPT_B3_TILE = 10
 NET_INFO_CONV3_TILE_ROWS, NET_INFO_SELF_CHECK_GUARD, NET_INFO_ARITHMETIC = 1, 2, 3                                                          # oz_net_get_info
 LEAF_IDLE, LEAF_TERMINAL, LEAF_EVAL = 0, 1, 2
 VT_INT, VT_F32, VT_F64 = 0, 1, 2
@@ -124,6 +125,7 @@ SIGNATURES = {
     "oz_symmetry_table": [C.c_int, _i32p],
     "oz_selftest_arith": [_f64p, _f64p, C.c_int, _f64p, _f64p, _f32p, _f32p],
     "oz_selftest_mfma_rate": [C.c_int, C.c_double, _f64p, _f64p, _f64p],
+    "oz_selftest_b3_split": [_f32p, C.c_int64, _f32p, _f32p],
     "oz_trainer_arena_size": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)],
     "oz_trainer_create": [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                           C.c_uint64, _vp],
@@ -272,9 +274,9 @@ def require_gpu():
 
 
 def mfma_rate(kind, target_ms=50.0):
-    """oz_selftest_mfma_rate: {"tflops", "clock_ghz", "ms"} of a pure-MFMA loop on the current device; kind "f32" / "f16" """
+    """oz_selftest_mfma_rate: {"tflops", "clock_ghz", "ms"} of a pure-MFMA loop on the current device; kind "f32" / "f16" / "bf16" """
     t, g, m = C.c_double(), C.c_double(), C.c_double()
-    check(require_gpu().oz_selftest_mfma_rate({"f32": 0, "f16": 1}[kind], float(target_ms), C.byref(t), C.byref(g), C.byref(m)))
+    check(require_gpu().oz_selftest_mfma_rate({"f32": 0, "f16": 1, "bf16": 2}[kind], float(target_ms), C.byref(t), C.byref(g), C.byref(m)))
     return {"tflops": t.value, "clock_ghz": g.value, "ms": m.value}
 
 

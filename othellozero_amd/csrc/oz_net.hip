@@ -796,6 +796,7 @@ struct OnnNet : oz_net {
     int conv3_tile = 0;              // oz_net_set_option(OZ_NET_OPT_CONV3_TILE): 0 = the forward picks, 128 / 192 / 256 = that tile (bit-identity screen of the three)
     bool f32_std_tile = false;       // oz_net_set_option(OZ_NET_OPT_F32_STD_TILE): precision f32 never takes the 256 x 256 tile (bit-identity screen)
     bool simple_loop = false;        // oz_net_set_option(OZ_NET_OPT_SIMPLE_LOOP): one-barrier-per-k-tile loop for the 3x3 layers (race screen)
+    int b3_tile = 0;                 // oz_net_set_option(OZ_NET_OPT_B3_TILE): 0 = the launcher picks (256 x 256 where its grid fills the chip), 128 / 256 = that tile (bit-identity screen)
     int low_loop_phases = 1;         // oz_net_set_option(OZ_NET_OPT_LOW_LOOP_PHASES): main loop of the 128 x 256 tile -- 1 (default) = one phase per k-tile, three LDS stages; 2 = round 5's 2-phase loop
     float* d_t2rows = nullptr;       // commit staging: one tap's T2 rows [OZ_LUT_PATTERNS][C] before the slice-major re-layout
     int last_conv3_rows = 0;         // row-tile height the last forward ran conv3 on (oz_net_get_info)
@@ -1471,19 +1472,37 @@ struct OnnNet : oz_net {
         g.ksplit = ksplit; g.slab = (long long)max_batch * Hout * Hout * N;
         OZ_REQUIRE(N % B3_BN == 0 && Cin % B3_BK == 0, "gemm_b3: N %% 256 and Cin %% 32 must be 0 (N=%d Cin=%d)", N, Cin);
         const long long Mmax = (long long)max_count * Hout * Hout;
-        const int num_mt = (int)((Mmax + B3_BM - 1) / B3_BM);
+        // the 256 x 256 tile (two thirds of the operand bytes per MFMA: the small tile is bound by its LDS-DMA stream out of the L2s) for unsplit 'valid'
+        // layers whose grid fills the chip on it -- keyed on the CAPACITY of the network (max_batch), like every tile / split choice, so that a position's
+        // bits do not depend on the call (they would not anyway: both tiles add the same products in the same order; OZ_NET_OPT_B3_TILE screens that)
+        // Which tile: the one whose grid pays fewer tile-rows at the network's capacity (rounds of the 256 CUs x tile height), the 256-row tile priced at
+        // 0.96 of its rows (measured at equal fill: 3.59 us per k-tile against 2 x 1.87).  4096 positions of 8x8: conv3 = 9 rounds of 128 rows against 5 (4.5
+        // paid as 5) of 256 -> the small tile; conv4 = 4 rounds of 128 against 2.0 of 256 -> the big one (974 against 1048 us at 3916 leaves).  The tile does not
+        // dissolve the kernel's real bound, which turned out to be the clock under load, not the L2 stream (docs/HISTORY.md, round 6).
+        const long long rows_cap = (long long)max_batch * Hout * Hout;
+        auto paid = [&](int bm) { return (double)(((((rows_cap + bm - 1) / bm) * (N / B3_BN)) + 255) / 256) * bm; };
+        const long long big_blocks = ((rows_cap + B3B_BM - 1) / B3B_BM) * (N / B3B_BN);
+        const bool big = b3_tile != 128 && pad == 0 && ksplit == 1 && (b3_tile == 256 || (big_blocks >= 192 && 0.96 * paid(B3B_BM) <= paid(B3_BM)));
+        if (layer == 2) last_conv3_rows = big ? B3B_BM : B3_BM;
+        const int BMt = big ? B3B_BM : B3_BM;
+        const int num_mt = (int)((Mmax + BMt - 1) / BMt);
         const int per_mt = (N / B3_BN) * ksplit;
-        const int grid = num_mt < 8 ? ((per_mt + 7) / 8) * 8 * num_mt : ((num_mt + 7) / 8) * 8 * per_mt;   // (the kernel's two block mappings)
+        const int grid = num_mt < 8 ? ((per_mt + 7) / 8) * 8 * num_mt : ((num_mt + 7) / 8) * 8 * per_mt;   // (the kernels' two block mappings)
         {
             static bool attr_done[64] = {};
             if (!attr_done[device & 63]) {
                 OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_b3<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS));
+                OZ_HIP(hipFuncSetAttribute((const void*)k_gemm_b3_big<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, B3B_LDS));
                 attr_done[device & 63] = true;
             }
         }
         void* dst = ksplit > 1 ? (void*)d_part_b3 : out;
-        hipLaunchKernelGGL((k_gemm_b3<TAG>), dim3(grid), dim3(B3_NT), B3_LDS, s, in, (const uint4*)d_wb[layer - 2], d_scale[layer], d_shift[layer], dst,
-                           d_count, g, num_mt, d_zero);
+        if (big)
+            hipLaunchKernelGGL((k_gemm_b3_big<TAG>), dim3(grid), dim3(B3_NT), B3B_LDS, s, in, (const uint4*)d_wb[layer - 2], d_scale[layer], d_shift[layer], dst,
+                               d_count, g, num_mt, d_zero);
+        else
+            hipLaunchKernelGGL((k_gemm_b3<TAG>), dim3(grid), dim3(B3_NT), B3_LDS, s, in, (const uint4*)d_wb[layer - 2], d_scale[layer], d_shift[layer], dst,
+                               d_count, g, num_mt, d_zero);
         if (ksplit > 1 && layer == 5) {           // fc2: the heads kernel adds the slices in fixed order (launch_heads), BN + ReLU there
             fc2_defer.partial = d_part_b3; fc2_defer.slab = g.slab; fc2_defer.ksplit = ksplit; fc2_defer.scale = d_scale[layer]; fc2_defer.shift = d_shift[layer];
         } else if (ksplit > 1 && out_b3) {        // the consumer reads the b3 layout: fixed-order reduce + BN + ReLU + split
@@ -1502,7 +1521,7 @@ struct OnnNet : oz_net {
     // precision bf16x3, networks of >= B3_MIN_BATCH positions: gather (exact fp32 tables) -> b3 rows -> conv3 / conv4 / fc1 on k_gemm_b3 -> fc2 and heads in fp32
     int forward_b3(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi, float* d_v, hipStream_t s) {
         const bool use_t2f = (tables_mode < 0 || tables_mode >= 2) && t2f_ok;      // else (oz_net_set_tables 0 / 1): conv1 kernel + conv2 as the exact-fp32 GEMM
-        last_conv3_rows = B3_BM;
+        last_conv3_rows = B3_BM;                     // (set by conv3's launch below)
         profiled_layer = use_t2f ? 3 : 2;            // the dominant launch: conv3 on k_gemm_b3, or the exact-fp32 conv2 GEMM when the tables are off
         if (profile && timer.backlog() > 4096) timer.drain();
         long long tidx = -1;
@@ -2008,6 +2027,35 @@ OZ_API int oz_net_time_forward(oz_net* net, int count, int iters, float* ms_avg)
     return OZ_OK;
 }
 
+// the three-plane split of precision bf16x3 on the device, for the test that holds "every normal fp32 value exactly" to its word: planes[3 i ..] =
+// (b1, b2, b3) of x[i] widened to fp32, sum[i] = (b1 + b2) + b3 evaluated in fp32 (each partial sum is exactly representable when the split is exact)
+__global__ __launch_bounds__(256) void k_selftest_b3_split(const float* __restrict__ x, long long count, float* __restrict__ planes, float* __restrict__ sum) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    __bf16 b1, b2, b3;
+    b3_split(x[i], b1, b2, b3);
+    const float f1 = (float)b1, f2 = (float)b2, f3 = (float)b3;
+    if (planes) { planes[3 * i] = f1; planes[3 * i + 1] = f2; planes[3 * i + 2] = f3; }
+    sum[i] = (f1 + f2) + f3;
+}
+OZ_API int oz_selftest_b3_split(const float* x, int64_t count, float* planes, float* sum) {
+    OZ_REQUIRE(x && sum && count > 0 && count <= (1ll << 28), "oz_selftest_b3_split: null argument or count outside (0, 2^28]");
+    float *d_x = nullptr, *d_p = nullptr, *d_s = nullptr;
+    OZ_HIP(hipMalloc((void**)&d_x, sizeof(float) * (size_t)count));
+    OZ_HIP(hipMalloc((void**)&d_s, sizeof(float) * (size_t)count));
+    if (planes) OZ_HIP(hipMalloc((void**)&d_p, sizeof(float) * 3 * (size_t)count));
+    hipError_t e = hipMemcpy(d_x, x, sizeof(float) * (size_t)count, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_selftest_b3_split, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, d_x, (long long)count, d_p, d_s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(sum, d_s, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && planes) e = hipMemcpy(planes, d_p, sizeof(float) * 3 * (size_t)count, hipMemcpyDeviceToHost);
+    hipFree(d_x); hipFree(d_s); if (d_p) hipFree(d_p);
+    OZ_HIP(e);
+    return OZ_OK;
+}
+
 // precision: 0 = exact fp32 matrix cores (k_gemm_f32), 1 = f32 via 2 x fp16 split on the 16-bit matrix cores (oz_net_h2.h),
 // 2 = f32 via 3 x bf16 split (oz_net_b3.h: every fp32 value exactly, six bf16 MFMA products per fp32 product; networks of fewer than
 // B3_MIN_BATCH positions run the exact-fp32 kernels).
@@ -2066,9 +2114,13 @@ OZ_API int oz_net_set_option(oz_net* net, int option, int value) {
     OZ_REQUIRE(o, "not an OthelloNN network");
     OZ_REQUIRE(option == OZ_NET_OPT_SIMPLE_LOOP || option == OZ_NET_OPT_ACT_TARGET_LOG2 || option == OZ_NET_OPT_LOW_GUARD_LOG2 ||
                option == OZ_NET_OPT_SELF_CHECK || option == OZ_NET_OPT_W_TARGET_LOG2 || option == OZ_NET_OPT_F32_STD_TILE ||
-               option == OZ_NET_OPT_LATENCY_SPLITS || option == OZ_NET_OPT_CONV3_TILE || option == OZ_NET_OPT_LOW_LOOP_PHASES, "unknown network option %d", option);
+               option == OZ_NET_OPT_LATENCY_SPLITS || option == OZ_NET_OPT_CONV3_TILE || option == OZ_NET_OPT_LOW_LOOP_PHASES || option == OZ_NET_OPT_B3_TILE, "unknown network option %d", option);
     std::lock_guard<std::mutex> lk(o->mu);
     if (option == OZ_NET_OPT_SIMPLE_LOOP) o->simple_loop = value != 0;
+    else if (option == OZ_NET_OPT_B3_TILE) {
+        OZ_REQUIRE(value == 0 || value == 128 || value == 256, "OZ_NET_OPT_B3_TILE must be 0, 128 or 256 (got %d)", value);
+        o->b3_tile = value;
+    }
     else if (option == OZ_NET_OPT_LOW_LOOP_PHASES) {
         OZ_REQUIRE(value == 1 || value == 2, "OZ_NET_OPT_LOW_LOOP_PHASES must be 1 or 2 (got %d)", value);
         o->low_loop_phases = value;

@@ -5,8 +5,8 @@
 // which is what its commit-time placement, guards and self-check are for.  This mode carries an fp32 value EXACTLY:
 //     x = b1 + b2 + b3,   b1 = bf16(x), b2 = bf16(x - b1), b3 = bf16(x - b1 - b2)
 // bf16 has fp32's exponent range and 8 significand bits, so three planes hold all 24 bits of every normal fp32 value (round to
-// nearest: |x - b1| <= 2^-9 |x|, |x - b1 - b2| <= 2^-18 |x|, the third residual is exact; the only loss is a residual below bf16's
-// smallest subnormal 2^-133, i.e. for |x| < 2^-109) -- no scaling, no calibration, no guards, no refusal path.  A product keeps six of
+// nearest: |x - b1| <= 2^-8 |x|, |x - b1 - b2| <= 2^-17 |x|, the third residual is exact; the only loss is a residual below the smallest
+// normal fp32 / bf16's subnormal step, i.e. for |x| < 2^-100: absolute error < 2^-120) -- no scaling, no calibration, no guards, no refusal path.  A product keeps six of
 // the nine cross terms,
 //     a b ~= a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1          (dropped: a2 b3, a3 b2 <= 2^-26 |a b| each, a3 b3 <= 2^-36 |a b|)
 // each an exact bf16 x bf16 product accumulated in fp32 on v_mfma_f32_16x16x32_bf16, small terms first.  Per product the dropped
@@ -59,6 +59,9 @@ struct B3Geom {
 
 __device__ __forceinline__ void b3_split(float x, __bf16& b1, __bf16& b2, __bf16& b3) {
     b1 = (__bf16)x;
+    // the top 0.4 % of fp32's range (|x| > 0x7F7F8000 = bf16's largest value + half an ulp) would ROUND to infinity: take bf16's largest value instead --
+    // the residual (< 2^120) still fits the other two planes exactly
+    if (__builtin_isinf((float)b1) && !__builtin_isinf(x)) b1 = __builtin_bit_cast(__bf16, (unsigned short)(x < 0.f ? 0xFF7Fu : 0x7F7Fu));
     const float r1 = x - (float)b1;               // exact
     b2 = (__bf16)r1;
     b3 = (__bf16)(r1 - (float)b2);                // exact difference, at most 8 significant bits: the cast is exact
@@ -383,6 +386,249 @@ __global__ __launch_bounds__(B3_NT, 2) void k_gemm_b3(const uint4* __restrict__ 
         for (int c = 0; c < 12; ++c) {                       // 32 rows x 24 chunks of 16 B
             const int q = c * 64 + lane, lr = q / 24, cq = q - lr * 24;
             const long long m = (long long)mt * BM + wm * 64 + hh * 32 + lr;
+            const uint4 val = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(slice) + lr * 384 + cq * 16);
+            if (m < M) o[(size_t)m * nq + ((nt * BN + wn * 64) >> 5) * 12 + cq] = val;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------- the 256 x 256 tile (round 6, second half)
+// Why: the 128 x 256 tile moves 72 KB of operands per 96 MFMAs of a wave pair; with every CU holding a block that is ~10 TB/s of LDS-DMA out of
+// the L2s -- measured: a k-tile takes 1.90 us at 256 resident blocks and 1.55 us at 130 (tools/b3_probe.py), while the MFMAs alone would take
+// 1.48 us at the 2.07 GHz a pure bf16 MFMA loop sustains (oz_selftest_mfma_rate kind 2).  The kernel is bound by the operand stream, not by the
+// matrix pipe.  A 256 x 256 tile needs 96 KB per 192 MFMAs: two thirds of the bytes per MFMA.
+// LDS: two whole stages (192 KB) do not exist.  Five 24 KB regions do (120 KB): A m0, A m1, B n1 and TWO B n0 -- every region is refilled by LDS-DMA
+// in the phase right after its last ds_read (each L section closes with lgkmcnt(0) BEFORE its barrier, so every wave's reads of a phase are complete
+// before any wave issues the next phase's DMA), and is read three phases (B n0: four) after its issue.
+// Registers: 128 accumulators leave room for ONE half of each operand's fragments (48 + 24 VGPRs), so the four quadrants of the 128 x 64 wave tile
+// are walked (m0,n0) (m0,n1) (m1,n1) (m1,n0) -- one operand half changes per phase -- and B n0 is read twice per k-tile (phases 1 and 4), which is why
+// it is the double-buffered region.  Per k-tile and wave: 42 ds_read_b128, 12 DMA instructions, 192 MFMAs in four sections of 48.
+//   phase 1  L: A m0(t), B n0(t);  DMA [B n0(t+1)] -> the other B n0 buffer;   M: (m0, n0)
+//   phase 2  L: B n1(t);           DMA [A m0(t+1)];                             M: (m0, n1)
+//   phase 3  L: A m1(t);           DMA [B n1(t+1)];                             M: (m1, n1)
+//   phase 4  L: B n0(t) again;     DMA [A m1(t+1)];                             M: (m1, n0)
+// vmcnt(6) at the end of every L section: all but the two youngest groups of three pieces have landed -- exactly what the next phase reads.
+// Every output element receives the same products in the same order as on the 128 x 256 tile: bit-identical (OZ_NET_OPT_B3_TILE screens it).
+// Requires pad == 0 (the 'valid' convolutions and the dense layers: a row's taps are all inside the image), rows beyond M read the zero line.
+#define B3B_BM 256
+#define B3B_BN 256
+#define B3B_REG (8 * B3_BLK)                      // 24 KB: one half (8 blocks of 16 rows) of an operand tile
+#define B3B_LDS (5 * B3B_REG)                     // 120 KB: A m0 | A m1 | B n0 [2] | B n1
+template <int TAG = 0>
+__global__ __launch_bounds__(B3_NT, 2) void k_gemm_b3_big(const uint4* __restrict__ in, const uint4* __restrict__ Wb,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          void* __restrict__ out, const int* __restrict__ d_count, B3Geom g,
+                                                          int num_mt, const uint4* __restrict__ zero_line) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = B3B_BM, BN = B3B_BN, HA = 4, RJ = 4;
+    unsigned char* const rA0 = smem;
+    unsigned char* const rA1 = smem + B3B_REG;
+    unsigned char* const rB0 = smem + 2 * B3B_REG;           // two buffers: + B3B_REG for odd tiles
+    unsigned char* const rB1 = smem + 4 * B3B_REG;
+    const int nnt = g.N / BN, per_mt = nnt * g.ksplit;
+    const int id = blockIdx.x, xcd = id & 7, jb = id >> 3;
+    int mt, nt, ks;
+    if (num_mt < 8) {
+        mt = jb % num_mt;
+        const int q = (jb / num_mt) * 8 + xcd;
+        if (q >= per_mt) return;
+        nt = q / g.ksplit; ks = q - nt * g.ksplit;
+    } else {
+        const int rem = jb % per_mt;
+        mt = (jb / per_mt) * 8 + xcd; nt = rem / g.ksplit; ks = rem - nt * g.ksplit;
+    }
+    const int P = g.Hout * g.Hout;
+    const long long M = (long long)(*d_count) * P;
+    if (mt >= num_mt || (long long)mt * BM >= M) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int rowq = g.Cin / 32 * 12, wrowq = g.K / 32 * 12;
+
+    // staging map: wave w fills block w (of 8) of each region -- A halves: block (w >> 2, w & 3) = rows (w >> 2) * 128 + half * 64 + (w & 3) * 16;
+    // B halves: block (w >> 1, w & 1) = columns (w >> 1) * 64 + half * 32 + (w & 1) * 16.  ~0u = a row beyond M: the zero line.
+    unsigned aoff[2][3], boff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int cidx = 64 * i + lane, r = cidx / 12, pos = cidx - 12 * r, src_chunk = (pos >> 2) * 4 + ((pos & 3) ^ ((4 - (r >> 2)) & 3));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long m = (long long)mt * BM + (wave >> 2) * 128 + h * 64 + (wave & 3) * 16 + r;
+            aoff[h][i] = ~0u;
+            if (m < M) {
+                const int b = (int)(m / P), pix = (int)(m % P), oy = pix / g.Hout, ox = pix % g.Hout;
+                aoff[h][i] = (unsigned)((((long long)b * g.Hin + oy) * g.Hin + ox) * rowq + src_chunk);
+            }
+        }
+        boff[i] = (unsigned)(nt * BN + (wave >> 1) * 64 + (wave & 1) * 16 + r) * (unsigned)wrowq + (unsigned)src_chunk;
+    }
+    const unsigned bhalf = 32u * (unsigned)wrowq;            // B n1 rows = B n0 rows + 32
+    const uint4* zsrc = zero_line + (lane & 7);
+    const int nk_all = g.K / B3_BK, kbeg = (int)((long long)nk_all * ks / g.ksplit), nk = (int)((long long)nk_all * (ks + 1) / g.ksplit);
+
+    auto put_a = [&](int h, int slice, int tap, unsigned char* reg) {
+        const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
+        const unsigned toff = (unsigned)((dy * g.Hin + dx) * rowq + slice * 12);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint4* ga = aoff[h][i] != ~0u ? in + (aoff[h][i] + toff) : zsrc;
+            __builtin_amdgcn_global_load_lds((h2_gptr)ga, (h2_lptr)(reg + wave * B3_BLK + i * 1024), 16, 0, 0);
+        }
+    };
+    auto put_b = [&](int h, int ktc, unsigned char* reg) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds((h2_gptr)(Wb + (boff[i] + (h ? bhalf : 0u) + (unsigned)ktc * 12u)), (h2_lptr)(reg + wave * B3_BLK + i * 1024), 16, 0, 0);
+    };
+
+    f32x4v acc[2 * HA][RJ];
+#pragma unroll
+    for (int i = 0; i < 2 * HA; ++i)
+#pragma unroll
+        for (int j = 0; j < RJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int lofs = r16 * B3_ROWB + ((kg ^ ((4 - (r16 >> 2)) & 3)) * 16);
+    const unsigned char* const At0 = rA0 + wm * HA * B3_BLK + lofs;
+    const unsigned char* const At1 = rA1 + wm * HA * B3_BLK + lofs;
+    const unsigned char* const Bt1 = rB1 + wn * 2 * B3_BLK + lofs;
+
+    constexpr int KEEP = 6;
+    int ktn = kbeg + 1 < nk ? kbeg + 1 : nk - 1, slice_n = ktn / g.taps, tap_n = ktn - slice_n * g.taps;      // the tile being staged (past the end: the last again)
+    {   // tile kbeg in the loop's issue order: [B n0] [A m0] [B n1] [A m1]
+        const int slice0 = kbeg / g.taps, tap0 = kbeg - slice0 * g.taps;
+        put_b(0, kbeg, rB0); put_a(0, slice0, tap0, rA0); put_b(1, kbeg, rB1); put_a(1, slice0, tap0, rA1);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory");     // B n0 and A m0 of tile kbeg have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // stagger: wave row 1 is one barrier behind
+    bf16x8 fa[3][HA], fb[3][2];
+    for (int kt = kbeg; kt < nk; ++kt) {
+        const int par = (kt - kbeg) & 1;
+        unsigned char* const rB0cur = rB0 + par * B3B_REG;
+        unsigned char* const rB0nxt = rB0 + (par ^ 1) * B3B_REG;
+        const unsigned char* const Bt0 = rB0cur + wn * 2 * B3_BLK + lofs;
+        auto lda = [&](const unsigned char* base) {
+#pragma unroll
+            for (int i = 0; i < HA; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fa[p][i] = *reinterpret_cast<const bf16x8*>(base + i * B3_BLK + p * 64);
+        };
+        auto ldb = [&](const unsigned char* base) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fb[p][j] = *reinterpret_cast<const bf16x8*>(base + j * B3_BLK + p * 64);
+        };
+        auto l_end = [&]() {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mma = [&](int mh, int nh) {                     // quadrant (mh, nh): 6 products x 4 x 2 tiles, product-major, small terms first
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int i = 0; i < HA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4v& c = acc[mh * HA + i][nh * 2 + j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA[q]][i], fb[PB[q]][j], c, 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto m_end = [&]() {
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        lda(At0); ldb(Bt0); put_b(0, ktn, rB0nxt); l_end(); mma(0, 0); m_end();             // phase 1
+        ldb(Bt1); put_a(0, slice_n, tap_n, rA0); l_end(); mma(0, 1); m_end();               // phase 2
+        lda(At1); put_b(1, ktn, rB1); l_end(); mma(1, 1); m_end();                          // phase 3
+        ldb(Bt0); put_a(1, slice_n, tap_n, rA1); l_end(); mma(1, 0); m_end();               // phase 4
+        if (ktn + 1 < nk) { ++ktn; if (++tap_n == g.taps) { tap_n = 0; ++slice_n; } }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // re-align the two wave rows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every piece has landed before the epilogue reuses the LDS
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // ---- epilogue (as k_gemm_b3's; the wave tile is 128 x 64).  C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+    if (g.ksplit > 1) {
+        float* o = reinterpret_cast<float*>(out) + (size_t)ks * g.slab;
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) {
+            const int col = nt * BN + wn * 64 + j * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < 2 * HA; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long m = (long long)mt * BM + wm * 128 + i * 16 + kg * 4 + r;
+                    if (m < M) o[(size_t)m * g.N + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+    if (!g.out_b3) {
+        float* o = reinterpret_cast<float*>(out);
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) {
+            const int col = nt * BN + wn * 64 + j * 16 + r16;
+            const float sc = scale[col], sh = shift[col];
+#pragma unroll
+            for (int i = 0; i < 2 * HA; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long m = (long long)mt * BM + wm * 128 + i * 16 + kg * 4 + r;
+                    float v = fmaf(acc[i][j][r], sc, sh);
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (m < M) o[(size_t)m * g.N + col] = v;
+                }
+        }
+        return;
+    }
+    __bf16* slice = reinterpret_cast<__bf16*>(smem + wave * B3_SLICE);
+    uint4* o = reinterpret_cast<uint4*>(out);
+    const int nq = g.N / 32 * 12;
+#pragma unroll
+    for (int hh = 0; hh < HA; ++hh) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = hh * 2 + ii;
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) {
+                const int lc = j * 16 + r16;
+                const int col = nt * BN + wn * 64 + lc;
+                const float sc = scale[col], sh = shift[col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lr = ii * 16 + kg * 4 + r;
+                    float v = fmaf(acc[i][j][r], sc, sh);
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    __bf16 b1, b2, b3;
+                    b3_split(v, b1, b2, b3);
+                    __bf16* p = slice + lr * 192 + (lc >> 5) * 96 + (lc & 31);
+                    p[0] = b1; p[32] = b2; p[64] = b3;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            const int q = c * 64 + lane, lr = q / 24, cq = q - lr * 24;
+            const long long m = (long long)mt * BM + wm * 128 + hh * 32 + lr;
             const uint4 val = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(slice) + lr * 384 + cq * 16);
             if (m < M) o[(size_t)m * nq + ((nt * BN + wn * 64) >> 5) * 12 + cq] = val;
         }

@@ -2073,8 +2073,30 @@ __global__ __launch_bounds__(256) void k_diag_mfma_f16(float* out, int iters, un
     for (int i = 0; i < 4; ++i) for (int r2 = 0; r2 < 4; ++r2) s += acc[i][r2];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+typedef __bf16 dg_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_diag_mfma_bf16(float* out, int iters, unsigned seed) {
+    dg_f32x4 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    dg_bf16x8 a, b;
+    uint64_t r = oz_sm64(seed + 977u * (blockIdx.x * blockDim.x + threadIdx.x));
+    for (int j = 0; j < 8; ++j) {                            // values in [2^-3, 2^-2) with random 7-bit mantissas and signs: what the planes of precision bf16x3 hold
+        r = oz_sm64(r);
+        const unsigned short ha = (unsigned short)(0x3E00u | (r & 0x7Fu) | ((r >> 10) & 1u) << 15);
+        const unsigned short hb = (unsigned short)(0x3E00u | ((r >> 16) & 0x7Fu) | ((r >> 26) & 1u) << 15);
+        a[j] = __builtin_bit_cast(__bf16, ha); b[j] = __builtin_bit_cast(__bf16, hb);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int r2 = 0; r2 < 4; ++r2) s += acc[i][r2];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 OZ_API int oz_selftest_mfma_rate(int kind, double target_ms, double* tflops, double* clock_ghz, double* ms_measured) {
-    OZ_REQUIRE((kind == 0 || kind == 1) && tflops, "oz_selftest_mfma_rate: kind must be 0 (f32) or 1 (f16), tflops non-null");
+    OZ_REQUIRE((kind == 0 || kind == 1 || kind == 2) && tflops, "oz_selftest_mfma_rate: kind must be 0 (f32), 1 (f16) or 2 (bf16), tflops non-null");
     OZ_REQUIRE(target_ms > 0 && target_ms <= 2000, "oz_selftest_mfma_rate: target_ms %.1f outside (0, 2000]", target_ms);
     const int dev = oz_current_device();
     hipDeviceProp_t prop;
@@ -2088,7 +2110,8 @@ OZ_API int oz_selftest_mfma_rate(int kind, double target_ms, double* tflops, dou
     const double cycles_per_mfma = kind == 0 ? 64.0 : 16.0;  // back-to-back issue on one SIMD
     auto launch = [&](int iters) {
         if (kind == 0) hipLaunchKernelGGL(k_diag_mfma_f32, dim3(cus), dim3(256), 0, 0, out, iters, 0.5f, 0.25f);
-        else hipLaunchKernelGGL(k_diag_mfma_f16, dim3(cus), dim3(256), 0, 0, out, iters, 12345u);
+        else if (kind == 1) hipLaunchKernelGGL(k_diag_mfma_f16, dim3(cus), dim3(256), 0, 0, out, iters, 12345u);
+        else hipLaunchKernelGGL(k_diag_mfma_bf16, dim3(cus), dim3(256), 0, 0, out, iters, 12345u);
     };
     // a short run sizes the long one (and warms the clocks up)
     int iters = kind == 0 ? 400 : 1600;

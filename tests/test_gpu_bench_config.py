@@ -207,6 +207,32 @@ def test_conv3_tiles_bit_identical(oz):
         del net
 
 
+@pytest.mark.parametrize("n", [8, 6])
+def test_bf16x3_tiles_bit_identical(oz, n):
+    """precision bf16x3: k_gemm_b3's two tiles -- 128 x 256 (two 72 KB LDS stages, 2-phase ping-pong loop) and 256 x 256 (five 24 KB regions, each refilled in
+    the phase after its last read, 4-phase loop with B n0 read twice) -- add every output element's six-product sums in the same order: (pi, v) must be
+    BIT-identical whichever tile conv3 / conv4 run on (OZ_NET_OPT_B3_TILE forces one), at the bench's call sizes and at ragged ones (rows beyond M read
+    the zero line; the last row tile partly filled); every result within 1e-5 of float64.  Also the screen for the region schedule of the big tile."""
+    from othellozero_amd.NNet import NNetWrapper
+    w, own, opp, pi64, v64 = _case(n)
+    net = NNetWrapper((n, n), num_channels_1=C, max_batch=B, weights=w, precision="bf16x3")
+    for count in (B, 3916, 3640, 777, 1):
+        net.set_option(oz.NET_OPT_B3_TILE, 0)
+        p0, v0 = net.predict_batch(own[:count], opp[:count])
+        picked = net.conv3_tile_rows()
+        assert picked == (128 if n == 8 else 256)                 # conv3 at capacity 4096: 9 rounds of 128 rows against 5 of 256 (8x8); 4 against 2.0 (6x6)
+        assert np.abs(p0.reshape(count, -1) - pi64[:count]).max() <= TOL and np.abs(v0 - v64[:count]).max() <= TOL
+        for tile in (128, 256):
+            net.set_option(oz.NET_OPT_B3_TILE, tile)
+            for rep in range(3):                                  # (repeated: a DMA visibility race would be intermittent)
+                pt, vt = net.predict_batch(own[:count], opp[:count])
+                assert net.conv3_tile_rows() == tile
+                assert np.array_equal(pt, p0) and np.array_equal(vt, v0), (count, tile, rep)
+    net.set_option(oz.NET_OPT_B3_TILE, 0)
+    with pytest.raises(oz.OzError):
+        net.set_option(oz.NET_OPT_B3_TILE, 192)
+
+
 def test_config5_real_networks_whole_games_vs_oracle(oz):
     """bench.py's config5 leg (BASELINE configs[4] with REAL networks): 512 arena games x 800 sims per move and agent on two 512-filter
     networks (seeds 0 / 1), every game played TO THE END; two sampled WHOLE games are replayed by the oracle's arena (agents.py:44-84

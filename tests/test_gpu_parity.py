@@ -525,6 +525,39 @@ def test_bf16x3_network_vs_float64_oracle(oz, n, channels, batch, network):
     assert np.abs(ps - pi[:8]).max() <= 4e-6 and np.abs(vs - v[:8]).max() <= 4e-6
 
 
+def test_bf16x3_split_is_exact(oz):
+    """what precision bf16x3 rests on, on the device: x == (b1 + b2) + b3 BIT FOR BIT for every finite fp32 x with |x| >= 2^-100 (bf16 has fp32's
+    exponent range, the three planes carry 8 + 8 + 8 significand bits; round to nearest makes the residuals small enough), |b2| <= 2^-8 |b1| and
+    |b3| <= 2^-16 |b1| (the order of the six kept cross terms), zero stays zero with its sign; below 2^-100 a residual can fall under the smallest
+    normal fp32 / bf16's subnormal step and the ABSOLUTE error stays below 2^-120 (1e-36: nothing a network's activations or weights resolve)"""
+    rs = np.random.RandomState(7)
+    bits = rs.randint(0, 2**32, size=1 << 20, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32).copy()
+    x = x[np.isfinite(x)]
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 1.0 + 2.0**-23, 1.0 - 2.0**-24, 3.4028235e38, -3.4028235e38, 2.0**-109, 2.0**-126, 65504.0, 1.0 / 3.0,
+                     np.float32(2.0**-8) * np.float32(1.0 + 2.0**-23), 255.99998], np.float32)
+    x = np.concatenate([edge, x]).astype(np.float32)
+    planes, total = np.zeros(3 * x.size, np.float32), np.zeros(x.size, np.float32)
+    oz.check(oz.load().oz_selftest_b3_split(oz.p_f32(x), x.size, oz.p_f32(planes), oz.p_f32(total)))
+    planes = planes.reshape(-1, 3)
+    big = np.abs(x) >= np.float32(2.0**-100)
+    # the three planes add up to x EXACTLY (float64 on the host holds the 3 x 8 bits without rounding) over fp32's whole finite range ...
+    assert np.array_equal(planes[big].astype(np.float64).sum(axis=1), x[big].astype(np.float64)), int((planes[big].astype(np.float64).sum(axis=1) != x[big]).sum())
+    assert np.isfinite(planes).all()                                # ... including its top 0.4 %, where bf16(x) would round to infinity (b1 = bf16's largest value there)
+    # ... and so does the device's own fp32 evaluation (b1 + b2) + b3, wherever b1 + b2 cannot overflow on the way
+    inner = big & (np.abs(x) < np.float32(2.0**126))
+    assert np.array_equal(total[inner].view(np.uint32), x[inner].view(np.uint32)), int((total[inner].view(np.uint32) != x[inner].view(np.uint32)).sum())
+    small = ~big
+    assert np.abs(total[small].astype(np.float64) - x[small].astype(np.float64)).max() <= 2.0**-120
+    assert np.array_equal(total[:2].view(np.uint32), x[:2].view(np.uint32))                       # +0.0 and -0.0
+    # every plane is a bf16 value (16 low bits of the fp32 pattern clear) and the planes fall off by 2^-8 each (in magnitude, up to rounding to even)
+    assert not (planes.view(np.uint32) & 0xFFFF).any()
+    b1, b2, b3 = (np.abs(planes[big, k].astype(np.float64)) for k in range(3))
+    assert (b2 <= b1 / 255.0).all() and (b3 <= b1 * 2.0**-16).all()        # (1 / 255 exactly at the clamped top of the range: b1 = 255 * 2^120, b2 = 2^120; 2^-8 elsewhere)
+    top = np.abs(x[big]) < np.float32(3.0e38)
+    assert (b2[top] <= b1[top] * 2.0**-8).all()
+
+
 def test_bf16x3_needs_channels_multiple_of_256(oz):
     from othellozero_amd.NNet import NNetWrapper
     with pytest.raises(oz.OzError):

@@ -30,6 +30,17 @@ for seed, rand_all in ((0, False), (5, True)):
         print(f"seed {seed} {prec:7s}", {a: round(ms / c * 1e3, 1) for a, (ms, c) in k.items() if c}, "sum us", round(sum(ms / c for ms, c in k.values() if c) * 1e3, 1),
               "err vs f64", f"{err:.2e}", "tile", net.conv3_tile_rows(), flush=True)
         if prec == "bf16x3":
+            # the two tiles of k_gemm_b3 (OZ_NET_OPT_B3_TILE): same products in the same order -> the same bits; per-kernel times of each
+            from othellozero_amd import _lib
+            for tile in (128, 256):
+                net.set_option(_lib.NET_OPT_B3_TILE, tile)
+                for _ in range(2): pt, vt = net.predict_batch(own, opp)
+                net.profile(2); net.profile_kernels(reset=True)
+                for _ in range(20): net.predict_batch(own, opp)
+                kk = net.profile_kernels(); net.profile(0)
+                print(f"   tile {tile}:", {a: round(ms / c * 1e3, 1) for a, (ms, c) in kk.items() if c and a in ("conv3", "conv4", "fc1")}, "conv3 rows", net.conv3_tile_rows(),
+                      "| same bits as the default:", bool(np.array_equal(pt, pi) and np.array_equal(vt, v)), flush=True)
+            net.set_option(_lib.NET_OPT_B3_TILE, 0)
             # a position's (pi, v) must not depend on the call it sits in: a shorter call, and the same positions in another order
             p2, v2 = net.predict_batch(own[:300], opp[:300])
             perm = rs.permutation(cap)
