@@ -191,6 +191,7 @@ def main():
                          "lockstep: oz_selfplay_run (one simulation per game per step, moves aligned)")
     ap.add_argument("--arena-plies", type=int, default=0, help="config5 leg: 0 (default) = every arena game played to the end (512 games x 800 sims per move "
                                                                "and agent); a positive value bounds the games to that many plies (quick looks)")
+    ap.add_argument("--b3-tile", type=int, default=0, choices=[0, 128, 256], help="precision bf16x3: force k_gemm_b3's tile for conv3 / conv4 (0 = the launcher picks; bit-identical results -- an A/B switch)")
     ap.add_argument("--arena-precision", default="f16x2", choices=list(PRECISIONS), help="config5 leg: arithmetic of the two arena networks (reported as config5_precision)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
@@ -278,6 +279,8 @@ def run_rank(args, rank, world, local_rank, t_proc):
     stagger_sims = args.sims if args.stagger_sims < 0 else args.stagger_sims
     period = n * n - 4
     net = NNetWrapper((n, n), num_channels_1=args.channels, max_batch=G, seed=0, precision=args.precision)   # same weights on every rank
+    if args.b3_tile:
+        net.set_option(_lib.NET_OPT_B3_TILE, args.b3_tile)
     net.profile(1)          # HIP events around the dominant launch from the first launch on; the timed region is the difference of two readings
 
     from othellozero_amd.training import preferred_batch_cap

@@ -549,7 +549,7 @@ def test_bf16x3_split_is_exact(oz):
     assert np.array_equal(total[inner].view(np.uint32), x[inner].view(np.uint32)), int((total[inner].view(np.uint32) != x[inner].view(np.uint32)).sum())
     small = ~big
     assert np.abs(total[small].astype(np.float64) - x[small].astype(np.float64)).max() <= 2.0**-120
-    assert np.array_equal(total[:2].view(np.uint32), x[:2].view(np.uint32))                       # +0.0 and -0.0
+    assert np.array_equal(planes[:2, 0].copy().view(np.uint32), x[:2].view(np.uint32)) and not planes[:2, 1:].any()      # +0.0 and -0.0: the first plane keeps the sign
     # every plane is a bf16 value (16 low bits of the fp32 pattern clear) and the planes fall off by 2^-8 each (in magnitude, up to rounding to even)
     assert not (planes.view(np.uint32) & 0xFFFF).any()
     b1, b2, b3 = (np.abs(planes[big, k].astype(np.float64)) for k in range(3))
