@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Whole games at the bench configuration (4096 x 8x8 x 100 sims, 512-filter OthelloNN, max_batch 4096) replayed by the oracle's search fed
-with the GPU network's own (pi, v): `--sample` games of the first generation, move for move.   python tools/soak_real_net.py [--precision f16x2]"""
+with the GPU network's own (pi, v): `--sample` games of the first generation, move for move.   python tools/soak_real_net.py [--precision f16x2 | f32 | bf16x3]"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,7 +23,7 @@ if args.driver == "free":
     from othellozero_amd.training import preferred_batch_cap
     eng = SelfPlayEngine(net, n, G, sims, 1.0, 1.0, 0.9, seed=1234, first_game_id=0, game_id_stride=G, q_mode=1, refill=True, record_cap=G * 140,
                          dedup=False)                                # the bench headline: one evaluation per expansion
-    cap = preferred_batch_cap(n, G, 512) if args.batch_cap < 0 else args.batch_cap
+    cap = preferred_batch_cap(n, G, 512, args.precision) if args.batch_cap < 0 else args.batch_cap
     eng.set_batch_cap(cap)
     eng.stagger(8)
     pre_plies = (np.arange(G) * (n * n - 4)) // G            # slot g played its first pre_plies[g] plies at 8 simulations each
