@@ -2041,17 +2041,19 @@ __global__ __launch_bounds__(256) void k_selftest_b3_split(const float* __restri
 OZ_API int oz_selftest_b3_split(const float* x, int64_t count, float* planes, float* sum) {
     OZ_REQUIRE(x && sum && count > 0 && count <= (1ll << 28), "oz_selftest_b3_split: null argument or count outside (0, 2^28]");
     float *d_x = nullptr, *d_p = nullptr, *d_s = nullptr;
-    OZ_HIP(hipMalloc((void**)&d_x, sizeof(float) * (size_t)count));
-    OZ_HIP(hipMalloc((void**)&d_s, sizeof(float) * (size_t)count));
-    if (planes) OZ_HIP(hipMalloc((void**)&d_p, sizeof(float) * 3 * (size_t)count));
-    hipError_t e = hipMemcpy(d_x, x, sizeof(float) * (size_t)count, hipMemcpyHostToDevice);
+    hipError_t e = hipMalloc((void**)&d_x, sizeof(float) * (size_t)count);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_s, sizeof(float) * (size_t)count);
+    if (e == hipSuccess && planes) e = hipMalloc((void**)&d_p, sizeof(float) * 3 * (size_t)count);
+    if (e == hipSuccess) e = hipMemcpy(d_x, x, sizeof(float) * (size_t)count, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_selftest_b3_split, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, d_x, (long long)count, d_p, d_s);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(sum, d_s, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost);
     if (e == hipSuccess && planes) e = hipMemcpy(planes, d_p, sizeof(float) * 3 * (size_t)count, hipMemcpyDeviceToHost);
-    hipFree(d_x); hipFree(d_s); if (d_p) hipFree(d_p);
+    if (d_x) hipFree(d_x);
+    if (d_s) hipFree(d_s);
+    if (d_p) hipFree(d_p);                         // (every buffer is released on the error paths too)
     OZ_HIP(e);
     return OZ_OK;
 }

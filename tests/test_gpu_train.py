@@ -79,7 +79,7 @@ def test_forward_backward_matches_autograd(n, C, cin, B):
     _check_grads(ref, gpu)
 
 
-@pytest.mark.parametrize("n,C,cin,B", [(8, 256, 2, 32), (8, 512, 2, 6), (6, 256, 1, 40), (8, 256, 2, 192)])
+@pytest.mark.parametrize("n,C,cin,B", [(8, 256, 2, 32), (8, 512, 2, 6), (6, 256, 1, 40), (8, 256, 2, 192), (8, 512, 2, 37)])      # (>= 32: the f16x2 weight-gradient kernel; 37, 40: a partly filled octet)
 def test_forward_backward_f16x2_matches_autograd(n, C, cin, B):
     """precision "f16x2" (3x3 layers' forward and data gradient on the fp16 matrix cores, fp32 values as two fp16 planes, per-tensor
     power-of-two scaling): the same tolerances against the float64 oracle as the fp32 kernels"""
