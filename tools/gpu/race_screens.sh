@@ -5,6 +5,11 @@ set -euo pipefail
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r30
-for i in 1 2 3 4 5 6; do timeout -k 10 300 python tools/pp_race_check.py 2>/dev/null | grep -v amdgpu | head -1 >> gpurun_out/r30/race.txt || exit 1; done
+rm -f gpurun_out/r30/race.txt
+for i in 1 2 3; do timeout -k 10 400 python tools/pp_race_check.py 2>/dev/null | grep -v amdgpu | tail -3 >> gpurun_out/r30/race.txt || { echo "pp_race_check run $i FAILED"; cat gpurun_out/r30/race.txt; exit 1; }; done
 cat gpurun_out/r30/race.txt
-timeout -k 10 400 python tools/conv3_tile_probe.py 300 2>/dev/null | grep -c '"bit_identical": false' > gpurun_out/r30/tile_mismatch_lines.txt; echo "tile probe lines with a mismatch: $(cat gpurun_out/r30/tile_mismatch_lines.txt)"
+n=$(timeout -k 10 400 python tools/conv3_tile_probe.py 300 2>/dev/null | grep -c '"bit_identical": false' || true)
+echo "conv3 tile probe lines with a mismatch: $n"
+m=$(timeout -k 10 300 python tools/low_loop_probe.py 100 2>/dev/null | grep -c '"same_bits": false' || true)
+echo "128-row tile loop probe lines with a mismatch: $m"
+[ "$n" = 0 ] && [ "$m" = 0 ]
