@@ -75,10 +75,11 @@ def roofline(precision, layer, achieved, layer_ms, launches, expansions, n, chan
                          if layer == 3 else "k_gemm_f32 (conv2: 3x3 same, 512->512, implicit GEMM, v_mfma_f32_32x32x2_f32)"),
                  peak=PEAK_F32_MATRIX_TFLOPS, frac=achieved / PEAK_F32_MATRIX_TFLOPS)
     else:
-        loop = "4-phase ping-pong loop" if (layer != 3 or conv3_rows == 256) else "2-phase ping-pong loop"
+        loop = ("4-phase ping-pong loop" if (layer != 3 or conv3_rows == 256) else "2-phase ping-pong loop" if conv3_rows == 192 else
+                "1-phase ping-pong loop on three LDS stages")
         tail = f"implicit GEMM, f32 as 2xfp16 split, v_mfma_f32_16x16x32_f16, {loop}"
         if layer == 3:
-            cfg = {256: "H2BigPP", 192: "H2MidPP", 128: "H2LowPP"}.get(conv3_rows, "H2MidPP")
+            cfg = {256: "H2BigPP", 192: "H2MidPP", 128: "H2LowPP1"}.get(conv3_rows, "H2MidPP")
             kernel = (f"k_gemm_h2<{cfg}, 3> (conv3: 3x3 valid, 512->512, {n}x{n} -> {n - 2}x{n - 2}, {conv3_rows} x 256 tiles, {tail}); "
                       "conv1 + conv2 = k_conv2_lut table gather-sum")
         else:
