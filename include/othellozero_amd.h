@@ -91,7 +91,7 @@ int oz_net_init_random(oz_net* net, uint64_t seed);
  * 2 = "f32 via 3 x bf16 split" (fp32-class): x = b1 + b2 + b3 with b1 = bf16(x), b2 = bf16(x - b1), b3 = bf16(x - b1 - b2) -- bf16 has fp32's
  * exponent range and 8 significand bits, so the three planes hold every normal fp32 value EXACTLY: no scaling, no calibration, no guards, no
  * refusal path.  A product keeps six of the nine cross terms (a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1 on v_mfma_f32_16x16x32_bf16, fp32
- * accumulation, small terms first); the dropped ones are <= 2^-26 of the product each, below fp32's own rounding of it.  conv3, conv4, fc1 and
+ * accumulation, small terms first); the dropped ones are <= 2^-25 of the product each, within fp32's own rounding of it.  conv3, conv4, fc1 and
  * fc2 run this way on k_gemm_b3 (oz_net_b3.h), conv1 + conv2 from the exact-fp32 pattern tables, the heads in fp32; networks with max_batch < 128
  * (the latency path: weight streams and split-K launches, not matrix rate) run precision 0's kernels unchanged.  Needs channels % 256 == 0.
  * Cost 6 MFMAs at 16x the fp32 rate: 2.67x the fp32 matrix roof.

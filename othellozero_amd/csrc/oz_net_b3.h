@@ -8,9 +8,10 @@
 // nearest: |x - b1| <= 2^-8 |x|, |x - b1 - b2| <= 2^-17 |x|, the third residual is exact; the only loss is a residual below the smallest
 // normal fp32 / bf16's subnormal step, i.e. for |x| < 2^-100: absolute error < 2^-120) -- no scaling, no calibration, no guards, no refusal path.  A product keeps six of
 // the nine cross terms,
-//     a b ~= a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1          (dropped: a2 b3, a3 b2 <= 2^-26 |a b| each, a3 b3 <= 2^-36 |a b|)
+//     a b ~= a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1          (dropped: a2 b3, a3 b2 <= 2^-25 |a b| each, a3 b3 <= 2^-34 |a b|)
 // each an exact bf16 x bf16 product accumulated in fp32 on v_mfma_f32_16x16x32_bf16, small terms first.  Per product the dropped
-// terms are below fp32's own rounding of that product (2^-24); what remains is the fp32 accumulation order, as in k_gemm_f32.
+// terms stay within fp32's own rounding of that product (half an ulp, 2^-24, in the worst case; a quarter of it typically); what remains is the fp32
+// accumulation order, as in k_gemm_f32.
 // Cost: 6 MFMAs at 16x the fp32 rate = 2.67x the fp32 matrix roof (cap 2500 / 6 = 417 TFLOP/s fp32-equivalent).
 //
 // Storage ("b3 layout"): a row (pixel or output channel) is cut into k-tiles of 32 channels; a k-tile is 192 bytes =
