@@ -494,3 +494,52 @@ def test_precision_modes_and_batch_cap():
     assert PRECISION_MODES == {"f32": 0, "f16x2": 1, "bf16x3": 2}
     # bf16x3's one tile is 128 x 256: 4096 leaves are whole rounds of conv3 AND conv4 -> no cap; the other precisions cap at 4.0 rounds of 256-row tiles
     assert preferred_batch_cap(8, 4096, 512, "bf16x3") == 0 and preferred_batch_cap(8, 4096, 512, "f32") == 3640 and preferred_batch_cap(8, 4096, 512) == 3640
+
+
+def test_lds_swizzles_are_conflict_free_for_the_16x16x32_operand_map():
+    """the two XOR swizzles of the GEMM kernels' LDS images, checked as arithmetic: a ds_read_b128 is served in 16-lane groups
+    {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32 for the upper half, MI355X_MICROARCH.md); with the 16x16x32 operand map -- lane l reads row l & 15,
+    k-group l >> 4 -- the 16 lanes of a group must hit 16 different 16-byte bank quads (address / 16 mod 16).
+    h2 layout (oz_net_h2.h): rows of 8 chunks, chunk (2 kg + plane) ^ h2_swz(row), h2_swz(r) = bit1(r) | 6 bit3(r);
+    b3 layout (oz_net_b3.h): rows of 12 chunks, chunk 4 plane + (kg ^ g(row)), g(r) = (-(r >> 2)) & 3."""
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+    groups += [[l + 32 for l in g] for g in groups]
+
+    def h2_chunk(lane, plane):
+        r, kg = lane & 15, lane >> 4
+        return 8 * r + ((2 * kg + plane) ^ (((r >> 1) & 1) | (((r >> 3) & 1) * 6)))
+
+    def b3_chunk(lane, plane):
+        r, kg = lane & 15, lane >> 4
+        return 12 * r + 4 * plane + (kg ^ ((4 - (r >> 2)) & 3))
+    for g in groups:
+        assert len(g) == 16
+        for plane in (0, 1):
+            assert len({h2_chunk(l, plane) % 16 for l in g}) == 16, ("h2", plane, g)
+        for plane in (0, 1, 2):
+            assert len({b3_chunk(l, plane) % 16 for l in g}) == 16, ("b3", plane, g)
+        # (what the swizzle is for: without it the b3 image would put rows r and r + 4 k of a group on the same quad)
+        assert len({(12 * (l & 15) + (l >> 4)) % 16 for l in g}) < 16
+    # every (row, k-group) chunk of a 16-row block stays inside its plane's four slots: the image is a permutation of the 192 chunks
+    assert sorted(b3_chunk(l, p) for l in range(64) for p in range(3)) == list(range(192))
+    assert sorted(h2_chunk(l, p) for l in range(64) for p in range(2)) == list(range(128))
+
+
+def test_b3_staging_map_matches_the_fragment_reads():
+    """k_gemm_b3's LDS-DMA staging map against its fragment reads, as arithmetic: DMA instruction i of a 16-row block, lane l, writes LDS chunk
+    64 i + l of the block and fetches the source chunk (plane, k-group) the kernel computes for it; the MFMA fragment read of lane (row, k-group) for
+    plane p must find exactly (p, k-group) of that row there.  (A DMA instruction spans 5.3 rows of 12 chunks: the map is per lane, not per row.)"""
+    holds = {}
+    for i in range(3):
+        for lane in range(64):
+            cidx = 64 * i + lane
+            r, pos = divmod(cidx, 12)
+            plane, kg_src = pos >> 2, (pos & 3) ^ ((4 - (r >> 2)) & 3)
+            assert cidx not in holds
+            holds[cidx] = (r, plane, kg_src)                  # what the kernel's src_chunk = plane * 4 + kg_src of row r denotes
+    assert len(holds) == 192 and {v[0] for v in holds.values()} == set(range(16))
+    for r16 in range(16):
+        for kg in range(4):
+            for p in range(3):
+                lofs_chunks = 12 * r16 + (kg ^ ((4 - (r16 >> 2)) & 3))        # lofs / 16
+                assert holds[lofs_chunks + 4 * p] == (r16, p, kg)
