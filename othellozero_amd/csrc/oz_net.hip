@@ -832,7 +832,8 @@ struct OnnNet : oz_net {
     // element); conv1 + conv2 from the exact-fp32 pattern tables, fc2 and the heads on the exact-fp32 kernels.  Networks below B3_MIN_BATCH
     // positions of capacity run the exact-fp32 forward as it is (their layers are weight streams / split-K launches: latency, not matrix rate) --
     // a per-network constant, so a position's result does not depend on the size of the call it sits in.
-    uint4* d_wb[4] = {nullptr, nullptr, nullptr, nullptr};   // conv3, conv4, fc1, fc2
+    uint4* d_wb[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // conv2 (the all-GEMM form only), conv3, conv4, fc1, fc2
+    uint4* b3a1 = nullptr;           // conv1's output in the b3 layout (the all-GEMM form only: allocated at its first use)
     uint4 *b3a2 = nullptr, *b3a3 = nullptr, *b3a4 = nullptr, *b3f1 = nullptr;   // conv2 / conv3 / conv4 / fc1 outputs in the b3 layout
     float* d_part_b3 = nullptr;                              // fc1's k-slices (fixed-order fp32 reduce)
     bool use_b3() const { return precision == 2 && max_batch >= B3_MIN_BATCH; }
@@ -841,6 +842,14 @@ struct OnnNet : oz_net {
         int k = 1;
         while (k < 8 && blocks * k < 192) k *= 2;
         return k < 2 ? 2 : k;                                // (always split: its fixed-order reduce is what writes fc2's b3 operand)
+    }
+    // medium networks (128 <= max_batch < ~1000): a 3x3 layer whose grid would leave most CUs idle splits its k loop -- the smallest power of two <= 8 that
+    // brings the grid of 128-row tiles to >= 192 blocks, from max_batch (a per-network constant); 1 from 1024 positions of 8x8 on (the bench)
+    int conv_b3_ksplit(int pixels) const {
+        const long long blocks = (((long long)max_batch * pixels + B3_BM - 1) / B3_BM) * (C / B3_BN);
+        int k = 1;
+        while (k < 8 && blocks * k < 192) k *= 2;
+        return k;
     }
     int fc2_b3_ksplit() const {                              // fc2 (512 columns = 2 column tiles, 32 k-tiles): 4 slices of 8 k-tiles; the heads kernel adds them
         return 4;
@@ -1463,7 +1472,7 @@ struct OnnNet : oz_net {
         return OZ_OK;
     }
 
-    // layer: 2 = conv3, 3 = conv4 (3x3, Cin = N = C), 4 = fc1 (taps 1); the d_scale / d_shift of precision f32 (no power-of-two bookkeeping)
+    // layer: 1 = conv2 (the all-GEMM form), 2 = conv3, 3 = conv4 (3x3, Cin = N = C), 4 = fc1, 5 = fc2 (taps 1); the d_scale / d_shift of precision f32 (no power-of-two bookkeeping)
     template <int TAG>
     int launch_gemm_b3(const uint4* in, int layer, void* out, int out_b3, const int* d_count, int max_count, int Hin, int Hout, int pad,
                        int Cin, int taps, int N, hipStream_t s, int ksplit = 1) {
@@ -1498,10 +1507,10 @@ struct OnnNet : oz_net {
         }
         void* dst = ksplit > 1 ? (void*)d_part_b3 : out;
         if (big)
-            hipLaunchKernelGGL((k_gemm_b3_big<TAG>), dim3(grid), dim3(B3_NT), B3B_LDS, s, in, (const uint4*)d_wb[layer - 2], d_scale[layer], d_shift[layer], dst,
+            hipLaunchKernelGGL((k_gemm_b3_big<TAG>), dim3(grid), dim3(B3_NT), B3B_LDS, s, in, (const uint4*)d_wb[layer - 1], d_scale[layer], d_shift[layer], dst,
                                d_count, g, num_mt, d_zero);
         else
-            hipLaunchKernelGGL((k_gemm_b3<TAG>), dim3(grid), dim3(B3_NT), B3_LDS, s, in, (const uint4*)d_wb[layer - 2], d_scale[layer], d_shift[layer], dst,
+            hipLaunchKernelGGL((k_gemm_b3<TAG>), dim3(grid), dim3(B3_NT), B3_LDS, s, in, (const uint4*)d_wb[layer - 1], d_scale[layer], d_shift[layer], dst,
                                d_count, g, num_mt, d_zero);
         if (ksplit > 1 && layer == 5) {           // fc2: the heads kernel adds the slices in fixed order (launch_heads), BN + ReLU there
             fc2_defer.partial = d_part_b3; fc2_defer.slab = g.slab; fc2_defer.ksplit = ksplit; fc2_defer.scale = d_scale[layer]; fc2_defer.shift = d_shift[layer];
@@ -1520,9 +1529,9 @@ struct OnnNet : oz_net {
 
     // precision bf16x3, networks of >= B3_MIN_BATCH positions: gather (exact fp32 tables) -> b3 rows -> conv3 / conv4 / fc1 on k_gemm_b3 -> fc2 and heads in fp32
     int forward_b3(const uint64_t* d_own, const uint64_t* d_opp, const int* d_count, int max_count, float* d_pi, float* d_v, hipStream_t s) {
-        const bool use_t2f = (tables_mode < 0 || tables_mode >= 2) && t2f_ok;      // else (oz_net_set_tables 0 / 1): conv1 kernel + conv2 as the exact-fp32 GEMM
+        const bool use_t2f = (tables_mode < 0 || tables_mode >= 2) && t2f_ok;      // else (oz_net_set_tables 0 / 1): conv1 kernel + conv2 as a b3 GEMM
         last_conv3_rows = B3_BM;                     // (set by conv3's launch below)
-        profiled_layer = use_t2f ? 3 : 2;            // the dominant launch: conv3 on k_gemm_b3, or the exact-fp32 conv2 GEMM when the tables are off
+        profiled_layer = use_t2f ? 3 : 2;            // the dominant launch: conv3 on k_gemm_b3, or conv2 on it when the tables are off
         if (profile && timer.backlog() > 4096) timer.drain();
         long long tidx = -1;
         auto mark = [&](int slot, bool begin) {
@@ -1542,17 +1551,18 @@ struct OnnNet : oz_net {
         mark(0, false);
         mark(1, true);
         if (use_t2f) launch_conv2_lut<2>(max_count, d_count, d_scale[1], d_shift[1], b3a2, s);      // the gather writes the b3 layout itself
-        else {
-            if (int rc = launch_gemm(act1, d_wt[0], 1, act2, d_count, max_count, n, n, 1, C, 9, C, s)) return rc;
+        else {      // every layer as a kernel / GEMM: conv1's rows split into the three planes, conv2 on k_gemm_b3 like the rest ('same' padding: the 128-row tile)
+            if (!b3a1) { if (int rc = alloc(&b3a1, (size_t)max_batch * n * n * (C / 32 * 12))) return rc; }
             const long long threads = (long long)max_count * n * n * (C / 8);
-            hipLaunchKernelGGL(k_f32_to_b3, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, act2, d_count, n * n, C, b3a2);
+            hipLaunchKernelGGL(k_f32_to_b3, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, act1, d_count, n * n, C, b3a1);
+            if (int rc = launch_gemm_b3<2>(b3a1, 1, b3a2, 1, d_count, max_count, n, n, 1, C, 9, C, s, conv_b3_ksplit(n * n))) return rc;
         }
         mark(1, false);
         mark(2, true);
-        if (int rc = launch_gemm_b3<3>(b3a2, 2, b3a3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s)) return rc;
+        if (int rc = launch_gemm_b3<3>(b3a2, 2, b3a3, 1, d_count, max_count, n, n - 2, 0, C, 9, C, s, conv_b3_ksplit((n - 2) * (n - 2)))) return rc;
         mark(2, false);
         mark(3, true);
-        if (int rc = launch_gemm_b3<4>(b3a3, 3, b3a4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s)) return rc;
+        if (int rc = launch_gemm_b3<4>(b3a3, 3, b3a4, 1, d_count, max_count, n - 2, n - 4, 0, C, 9, C, s, conv_b3_ksplit((n - 4) * (n - 4)))) return rc;
         mark(3, false);
         mark(4, true);
         if (int rc = launch_gemm_b3<5>(b3a4, 4, b3f1, 1, d_count, max_count, 1, 1, 0, F, 1, 1024, s, fc1_b3_ksplit())) return rc;
@@ -1871,10 +1881,10 @@ OZ_API int oz_net_commit(oz_net* net) {
                     hipLaunchKernelGGL(k_w_transpose, dim3((C + 31) / 32, (C + 31) / 32), dim3(256), 0, 0, o->d_raw + (size_t)t * C * C, C, C,
                                        o->d_wtap32 + (size_t)t * C * C);
             }
-            if (o->use_b3() && i >= 1) {               // conv3, conv4, fc1, fc2 once more in the b3 layout (three bf16 planes, the GEMM's tap-inner k order)
-                if (!o->d_wb[i - 1]) { if (int rc = o->alloc(&o->d_wb[i - 1], (size_t)N * (K / 32) * 12)) return rc; }
+            if (o->use_b3()) {                         // conv2 .. fc2 once more in the b3 layout (three bf16 planes, the GEMM's tap-inner k order)
+                if (!o->d_wb[i]) { if (int rc = o->alloc(&o->d_wb[i], (size_t)N * (K / 32) * 12)) return rc; }
                 const long long threads = (long long)N * (K / 8);
-                hipLaunchKernelGGL(k_w_to_b3, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, o->d_raw, K, N, i < 3 ? 9 : 1, o->d_wb[i - 1]);
+                hipLaunchKernelGGL(k_w_to_b3, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, o->d_raw, K, N, i < 3 ? 9 : 1, o->d_wb[i]);
             }
             OZ_HIP(hipGetLastError());
             OZ_HIP(hipDeviceSynchronize());                       // d_raw is reused by the next layer
@@ -1885,7 +1895,11 @@ OZ_API int oz_net_commit(oz_net* net) {
             if (int rc = o->alloc(&o->b3a3, B * (n - 2) * (n - 2) * rq)) return rc;
             if (int rc = o->alloc(&o->b3a4, B * (n - 4) * (n - 4) * rq)) return rc;
             if (int rc = o->alloc(&o->b3f1, B * (1024 / 32 * 12))) return rc;
-            if (int rc = o->alloc(&o->d_part_b3, (size_t)std::max(o->fc1_b3_ksplit() * 1024, o->fc2_b3_ksplit() * 512) * B)) return rc;
+            size_t part = (size_t)std::max(o->fc1_b3_ksplit() * 1024, o->fc2_b3_ksplit() * 512) * B;       // the largest set of k-slices any layer writes
+            const int px[3] = {n * n, (n - 2) * (n - 2), (n - 4) * (n - 4)};
+            for (int q = 0; q < 3; ++q)
+                if (o->conv_b3_ksplit(px[q]) > 1) part = std::max(part, (size_t)o->conv_b3_ksplit(px[q]) * B * px[q] * C);
+            if (int rc = o->alloc(&o->d_part_b3, part)) return rc;
             if (!o->d_zero) { if (int rc = o->alloc(&o->d_zero, 16)) return rc; }
             OZ_HIP(hipMemset(o->d_zero, 0, 256));
         }
