@@ -42,7 +42,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RC
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from bench_legs import (DTYPE_DETAIL, DTYPE_LABEL, FLOP_PER_EXPANSION, PRECISIONS, compact_line, config5_arena, conv3_tile_rows,  # noqa: E402,F401
+from bench_legs import (DTYPE_DETAIL, DTYPE_LABEL, FLOP_PER_EXPANSION, PRECISIONS, _finite, compact_line, config5_arena, conv3_tile_rows,  # noqa: E402,F401
                         conv_flop_per_leaf, cpu_baseline, roofline, run_secondary, tree_side)
 
 # ---------------------------------------------------------------------------------------------------------------- launcher
@@ -235,7 +235,7 @@ def write_detail(out):
         path = os.path.join(d, "bench_detail.json")
         try:
             with open(path, "w") as f:
-                json.dump(out, f, indent=1)
+                json.dump(_finite(out), f, indent=1, allow_nan=False)
             return path
         except OSError:
             continue

@@ -628,6 +628,17 @@ def _sig(x, digits=6):
     return x
 
 
+def _finite(x):
+    """a JSON-safe copy: non-finite floats become null (strict JSON has no NaN / Infinity; a single bad secondary figure must never cost the line)"""
+    if isinstance(x, float):
+        return x if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
+
+
 def compact_line(out, limit=6000):
     """THE stdout line: strict JSON, contract keys first, <= `limit` bytes whatever the rank count -- everything else of `out` lives in
     bench_detail.json (written next to bench.py) and is never needed to read the metric.  VERDICT r5 item 1: the 33 KB line of round 5 did
@@ -702,6 +713,7 @@ def compact_line(out, limit=6000):
             line[short] = _sig(out[k]["value"])
     line["tree_side_hbm_frac"] = _sig(out["tree_side_hbm"]["frac"], 3)
     line["detail"] = out.get("detail_file")
+    line = _finite(line)
     text = json.dumps(line, allow_nan=False)
     if len(text) > limit:                                        # cannot happen at N <= 8; never print a line the driver cannot keep whole
         for k in ("whole_path_note", "per_rank_ms_per_step", "flop_per_expansion", "device_calibration"):
