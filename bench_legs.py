@@ -617,6 +617,24 @@ def config5_arena(channels, precision, plies=0, games=512, sims=800, sample=2, d
         out["games_per_s"] = games / dt
     else:
         out["plies_per_game"] = plies
+    # the same regime in the library's other precisions, on the opening plies only (a whole exact-fp32 arena would take minutes): microseconds per simulation
+    # step with every expansion evaluated by itself -- what configs[4] costs in exact fp32 and in the fp32-class bf16x3 mode beside the f16x2 headline of the leg
+    del nets
+    out["other_precisions"] = {}
+    for prec in [p for p in PRECISIONS if p != precision]:
+        try:
+            pn = [NNetWrapper((n, n), num_channels_1=channels, max_batch=games, seed=sd, precision=prec) for sd in (0, 1)]
+            arena_batch(pn[0], pn[1], n, games, 8, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=2)
+            t0 = time.perf_counter()
+            rp2 = arena_batch(pn[0], pn[1], n, games, sims, 1.0, seed=11, first_game_id=0, q_mode=1, max_rounds=3, dedup=False)
+            dtp = time.perf_counter() - t0
+            steps_p = float(rp2["n_moves"].sum()) / games * sims
+            out["other_precisions"][prec] = {"us_per_sim_step": dtp / max(steps_p, 1) * 1e6, "plies": 3, "seconds": dtp,
+                                             # (whole games at the opening plies' step time: the opening's full 512-leaf batches are the slowest steps of a game)
+                                             "games_per_s_at_this_step_time": games / max(dtp / max(steps_p, 1) * (moves / games) * sims, 1e-12) if whole else None}
+            del pn
+        except Exception as e:                                   # noqa: BLE001 -- a side figure
+            out["other_precisions"][prec] = {"error": repr(e)}
     return out
 
 
@@ -705,6 +723,9 @@ def compact_line(out, limit=6000):
         line["config5_sample_mismatches"] = c5.get("sample_mismatches")
         line["config5_precision"] = c5.get("precision")
         line["config5_us_per_sim_step"] = _sig(c5.get("us_per_sim_step"), 4)
+        for p, leg in (c5.get("other_precisions") or {}).items():
+            if "us_per_sim_step" in leg:
+                line["config5_us_per_sim_step_" + p] = _sig(leg["us_per_sim_step"], 4)
     if "dropin_config0" in out:
         line["dropin_config0_s"] = _sig(out["dropin_config0"]["gpu_dropin"]["seconds"], 4)
     for k, short in (("cross_game_dedup", "value_with_cross_game_dedup"), ("eval_cache", "value_with_eval_cache"), ("other_driver", "value_other_driver"),
